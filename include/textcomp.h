@@ -1,0 +1,190 @@
+/*
+ * textcomp.h -- C ABI of libtextcomp.so: the MI355X (gfx950) BWT -> MTF -> RLE /
+ * FM-index hot path behind the Data.BWT / Data.MTF / Data.RLE / Data.FMIndex
+ * module surface of Matthew-Mosior/text-compression (v0.1.0.25).
+ *
+ * The reference has no FFI of its own (not one `foreign import`); these entry
+ * points are what a Haskell shim's `foreign import ccall safe` would bind in
+ * place of the L2 `Seq (Maybe a)` kernels (INTEGRATION.md shows the stubs).
+ * Each function cites the reference function(s) it replaces, paths relative to
+ * the reference's src/Data/.
+ *
+ * Conventions
+ *   - plain C: pointers and sizes only; no C++/torch types; no exceptions.
+ *   - `Maybe Word8` <-> int16_t, -1 = Nothing (order -1 < 0 < .. < 255 equals
+ *     `Ord (Maybe Word8)`).  A BWT is `uint8_t L[N]` + `primary` = the slot that
+ *     holds Nothing (its byte in L is 0).  N = n + 1; n == 0 <=> N == 0
+ *     (BWT.hs:58: empty input gives an empty BWT, no lone sentinel).
+ *   - caller allocates and frees every input/output buffer; the library owns only
+ *     tc_ctx / tc_fm handles.  Variable-size outputs use in/out capacity words.
+ *   - return 0 = TC_OK, negative = error; tc_last_error(ctx) has the text.
+ *     TC_ERR_MALFORMED marks inputs on which the reference itself throws
+ *     (fromJust / DS.index / read).
+ *   - one tc_ctx = one device + one HIP stream + one workspace; calls on one ctx
+ *     are serialised by the caller, distinct ctxs are independent.
+ *   - `*_dev` entry points take DEVICE pointers for the bulk arrays (the
+ *     benchmark path: inputs and outputs resident in HBM); scalar outputs are
+ *     host words.  All calls return after the ctx stream has drained.
+ *   - limits: n <= TC_MAX_N.  There is NO CPU fallback: without a usable HIP
+ *     device every compute call fails with TC_ERR_HIP.
+ */
+#ifndef TEXTCOMP_H
+#define TEXTCOMP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define TC_OK 0
+#define TC_ERR_ARG (-1)
+#define TC_ERR_CAPACITY (-2)
+#define TC_ERR_MALFORMED (-3)
+#define TC_ERR_HIP (-4)
+#define TC_ERR_OOM (-5)
+#define TC_ERR_INTERNAL (-6)
+
+#define TC_MAX_N ((uint64_t)0x7ffffff0u) /* indices are 31-bit on the device */
+#define TC_MAX_SIGMA 257                 /* 256 byte values + Nothing */
+#define TC_MAX_ROUNDS 40
+
+typedef struct tc_ctx tc_ctx;
+typedef struct tc_fm tc_fm;
+
+/* Work counters of the last encode on this ctx: the inputs of the algorithmic-
+ * byte formula of SURVEY.md 8(d) / DESIGN.md, plus per-stage device time. */
+typedef struct tc_stats {
+    uint64_t n;                      /* input bytes */
+    uint64_t N;                      /* n + 1 */
+    uint32_t sigma;                  /* present symbols incl. Nothing */
+    uint32_t rounds;                 /* suffix-sort rounds executed (round 0 = k-mer sort) */
+    uint64_t m[TC_MAX_ROUNDS];       /* suffixes sorted in round r (m[0] = N) */
+    uint32_t key_bytes[TC_MAX_ROUNDS];   /* k_r: key bytes moved per element */
+    uint32_t passes[TC_MAX_ROUNDS];      /* P_r: radix passes */
+    uint32_t h[TC_MAX_ROUNDS];           /* symbols resolved entering round r */
+    uint64_t runs;                   /* RLE runs produced */
+    float ms_sa, ms_bwt, ms_mtf, ms_rle, ms_total; /* device time, HIP events */
+} tc_stats;
+
+/* The encoded block of the fused BWT -> MTF -> RLE pipeline.  The reference has
+ * no such container (it never feeds MTF output into RLE); this is
+ * the documented glue: RLE runs over the MTF index stream as plain integers, with
+ * the BWT primary index and the MTF final list (MTF/Internal.hs:125,140-141)
+ * carried in the header. */
+typedef struct tc_block {
+    uint64_t n;                          /* out: input length */
+    uint64_t primary;                    /* out: BWT slot of Nothing */
+    uint32_t sigma;                      /* out: MTF alphabet size */
+    int16_t final_list[TC_MAX_SIGMA];    /* out: MTF list after the last move */
+    uint64_t nruns;                      /* in: capacity of the run arrays; out: runs */
+    uint32_t *run_count;                 /* [capacity] run lengths */
+    uint16_t *run_value;                 /* [capacity] MTF index of each run */
+} tc_block;
+
+/* ---- context ------------------------------------------------------------ */
+int tc_ctx_create(int device, tc_ctx **out);
+void tc_ctx_destroy(tc_ctx *ctx);
+const char *tc_last_error(const tc_ctx *ctx);
+const char *tc_version(void);
+int tc_get_stats(const tc_ctx *ctx, tc_stats *out);
+/* Stream the ctx launches on (a hipStream_t), for callers that time or order
+ * work against it. */
+void *tc_ctx_stream(const tc_ctx *ctx);
+
+/* ---- Data.BWT ------------------------------------------------------------ */
+/* bytestringToBWT (BWT.hs:68-70) = toBWT (:55-64) = createSuffixArray
+ * (BWT/Internal.hs:110-134) + saToBWT (:98-106).  L has n+1 bytes. */
+int tc_bwt_encode(tc_ctx *ctx, const uint8_t *text, uint64_t n, uint8_t *L, uint64_t *primary);
+int tc_bwt_encode_dev(tc_ctx *ctx, const uint8_t *d_text, uint64_t n, uint8_t *d_L,
+                      uint64_t *primary);
+/* createSuffixArray alone: sa[j] = 0-based start of the j-th smallest suffix of
+ * text.'$' (reference: 1-based suffixstartpos), n+1 entries. */
+int tc_suffix_array(tc_ctx *ctx, const uint8_t *text, uint64_t n, uint32_t *sa);
+
+/* bytestringFromWord8BWT (BWT.hs:108-110) = fromBWT (:93-104) + sortTB
+ * (BWT/Internal.hs:144-149) + magicInverseBWT (:163-200), for a well-formed BWT
+ * (exactly one Nothing at `primary`).  text receives N-1 bytes. */
+int tc_bwt_decode(tc_ctx *ctx, const uint8_t *L, uint64_t N, uint64_t primary, uint8_t *text);
+/* The same for ANY Seq (Maybe Word8) (zero or several Nothings):
+ * n_out = bytes produced (<= N); TC_ERR_MALFORMED where fromJust would throw. */
+int tc_bwt_decode_sym(tc_ctx *ctx, const int16_t *sym, uint64_t N, uint8_t *text,
+                      uint64_t *n_out);
+
+/* ---- Data.MTF ------------------------------------------------------------ */
+/* bytestringBWTToMTFB (MTF.hs:117-122) = seqToMTF (MTF/Internal.hs:128-175):
+ * idx[N] 0-based list positions; final_list[sigma] = list AFTER the last move;
+ * alphabet = sorted present symbols, Nothing first.  primary < 0: no Nothing. */
+int tc_mtf_encode(tc_ctx *ctx, const uint8_t *L, uint64_t N, int64_t primary, uint16_t *idx,
+                  int16_t *final_list, uint32_t *sigma);
+/* bytestringToMTFB-shaped input (MTF.hs:157-161): any Seq (Maybe Word8). */
+int tc_mtf_encode_sym(tc_ctx *ctx, const int16_t *sym, uint64_t N, uint16_t *idx,
+                      int16_t *final_list, uint32_t *sigma);
+/* bytestringBWTFromMTFB (MTF.hs:240-245) = seqFromMTF (MTF/Internal.hs:201-232):
+ * initial list = sort(unique(list)) (:214); out-of-range index => TC_ERR_MALFORMED
+ * (DS.index).  N == 0 or nlist == 0 => empty output (:202-209). */
+int tc_mtf_decode(tc_ctx *ctx, const uint16_t *idx, uint64_t N, const int16_t *list,
+                  uint32_t nlist, int16_t *sym);
+
+/* ---- Data.RLE ------------------------------------------------------------ */
+/* bytestringBWTToRLEB (RLE.hs:117-123) = seqToRLE (RLE/Internal.hs:104-153) incl.
+ * the sentinel quirks.  Pair k = (counts[k], syms[k]); the Haskell
+ * side renders counts with `show` (RLE/Internal.hs:128).  nruns: in capacity
+ * (2N is always enough), out pairs written. */
+int tc_rle_encode(tc_ctx *ctx, const uint8_t *L, uint64_t N, int64_t primary, uint32_t *counts,
+                  int16_t *syms, uint64_t *nruns);
+/* bytestringToRLEB-shaped input (RLE.hs:155-159): any Seq (Maybe Word8). */
+int tc_rle_encode_sym(tc_ctx *ctx, const int16_t *sym, uint64_t N, uint32_t *counts,
+                      int16_t *syms, uint64_t *nruns);
+/* Q4b glue: runs of a plain integer stream (the MTF indices; no sentinel). */
+int tc_rle_encode_u16(tc_ctx *ctx, const uint16_t *vals, uint64_t N, uint32_t *counts,
+                      uint16_t *run_vals, uint64_t *nruns);
+/* bytestringBWTFromRLEB (RLE.hs:237-241) = seqFromRLE (RLE/Internal.hs:155-189):
+ * (count, Nothing) => one Nothing whatever the count.  N: in capacity, out length. */
+int tc_rle_decode(tc_ctx *ctx, const uint32_t *counts, const int16_t *syms, uint64_t nruns,
+                  int16_t *sym_out, uint64_t *N);
+int tc_rle_decode_u16(tc_ctx *ctx, const uint32_t *counts, const uint16_t *run_vals,
+                      uint64_t nruns, uint16_t *vals_out, uint64_t *N);
+
+/* ---- fused pipeline (benchmark path) ------------------------------------- */
+/* bytestringToBWT -> bytestringBWTToMTFB -> RLE of the index stream, one call. */
+int tc_encode(tc_ctx *ctx, const uint8_t *text, uint64_t n, tc_block *out);
+/* d_text and out->run_count / out->run_value are device pointers. */
+int tc_encode_dev(tc_ctx *ctx, const uint8_t *d_text, uint64_t n, tc_block *out);
+/* Inverse chain: RLE -> MTF -> BWT decode; text receives blk->n bytes. */
+int tc_decode(tc_ctx *ctx, const tc_block *blk, uint8_t *text);
+int tc_decode_dev(tc_ctx *ctx, const tc_block *blk, uint8_t *d_text);
+
+/* ---- Data.FMIndex -------------------------------------------------------- */
+/* bytestringToBWTToFMIndexB (FMIndex.hs:108-111,162-183): C[c] (seqToCc,
+ * FMIndex/Internal.hs:275-316), Occ (seqToOccCK :195-259, kept as rank
+ * bit-vectors instead of the full sigma x N table) and the suffix array. */
+int tc_fm_build(tc_ctx *ctx, const uint8_t *text, uint64_t n, tc_fm **out);
+void tc_fm_free(tc_fm *fm);
+/* bytestringFMIndexCountS / ...CountP (FMIndex.hs:362-379,411-432) =
+ * countFMIndex (FMIndex/Internal.hs:347-438) mapped over the patterns in ONE
+ * batched launch; pattern j = pats[offs[j] .. offs[j+1]).  out[j] = count, 0 for
+ * Nothing (Q10); result order = pattern order. */
+int tc_fm_count(tc_ctx *ctx, const tc_fm *fm, const uint8_t *pats, const uint64_t *offs,
+                uint64_t npat, int64_t *out);
+int tc_fm_count_dev(tc_ctx *ctx, const tc_fm *fm, const uint8_t *d_pats, const uint64_t *d_offs,
+                    uint64_t npat, int64_t *d_out);
+/* bytestringFMIndexLocateS / ...LocateP (FMIndex.hs:475-497,538-563) =
+ * locateFMIndex (FMIndex/Internal.hs:448-542): 1-based text positions in SA
+ * order.  hit_offs[npat+1] (out) delimits each pattern's hits inside hits[];
+ * *nhits: in capacity, out total hits (TC_ERR_CAPACITY sets the needed total). */
+int tc_fm_locate(tc_ctx *ctx, const tc_fm *fm, const uint8_t *pats, const uint64_t *offs,
+                 uint64_t npat, uint64_t *hit_offs, uint64_t *hits, uint64_t *nhits);
+/* seqToCc / seqFromFMIndex views for the Haskell shim: present symbols (sorted,
+ * Nothing first) with C[c]; and L / primary. */
+int tc_fm_info(const tc_fm *fm, uint64_t *N, uint32_t *sigma, int16_t *c_sym, uint64_t *c_val,
+               uint64_t *primary);
+
+/* ---- synthetic inputs, generated on the device ------------- */
+/* kind 0: iid ACGTN, kind 1: printable ASCII.  d_out is a device pointer. */
+int tc_generate_dev(tc_ctx *ctx, int kind, uint64_t seed, uint64_t n, uint8_t *d_out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* TEXTCOMP_H */

@@ -1,0 +1,43 @@
+"""Quick GPU bring-up probe (not a test): runs a few encodes and prints mismatches."""
+import os, sys, time
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "text-compression_amd")); sys.path.insert(0, os.path.join(ROOT, "tests"))
+import numpy as np
+import textcomp, oracle as O
+
+ctx = textcomp.Context(0)
+print("ctx ok", ctx.lib.tc_version())
+def check(name, t):
+    t0 = time.time()
+    try:
+        sa = ctx.suffix_array(t)
+    except Exception as e:
+        print(name, "SA EXC", e); return
+    dt = time.time() - t0
+    esa = O.suffix_array(t)
+    ok = np.array_equal(sa.astype(np.int64), esa.astype(np.int64))
+    st = ctx.stats()
+    print(name, "n=%d" % len(t), "SA", "OK" if ok else "MISMATCH", "%.1f ms" % (dt * 1e3), "rounds", st.rounds, [int(st.m[i]) for i in range(st.rounds)])
+    if not ok:
+        bad = np.nonzero(sa.astype(np.int64) != esa.astype(np.int64))[0]
+        print("  first bad", bad[:5], sa[bad[:5]], esa[bad[:5]], "count", len(bad))
+        return
+    try:
+        blk = ctx.encode(t)
+    except Exception as e:
+        print(name, "ENC EXC", e); return
+    L = O.bwt_encode_arr(t); prim = int(np.nonzero(L < 0)[0][0])
+    eidx, efl = O.mtf_encode_arr(L); ec, ev = O.rle_encode_u32_arr(eidx)
+    ok2 = blk["primary"] == prim and np.array_equal(blk["run_count"], ec) and np.array_equal(blk["run_value"], ev) and blk["final_list"].tolist() == efl.tolist()
+    print("   fused", "OK" if ok2 else "MISMATCH", "runs", len(ec), len(blk["run_count"]), "prim", prim, blk["primary"])
+    if not ok2:
+        idx, fl = ctx.mtf_encode(np.where(L < 0, 0, L).astype(np.uint8), prim)
+        print("   mtf alone", np.array_equal(idx, eidx), fl.tolist(), efl.tolist())
+        bad = np.nonzero(idx != eidx)[0]; print("   mtf first bad", bad[:8])
+check("abra", b"abracadabra")
+check("miss", b"mississippi")
+check("ascii64k", O.gen_ascii(0xC1, 65536))
+check("acgtn1m", O.gen_acgtn(0xC2, 1 << 20))
+check("allA", b"A" * 10000)
+check("bytes", np.random.default_rng(1).integers(0, 256, 30000, dtype=np.uint8).tobytes())
+check("acgtn16m", O.gen_acgtn(0xC2, 1 << 24))

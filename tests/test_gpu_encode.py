@@ -1,0 +1,151 @@
+"""Parity of the HIP encode path (through the C ABI) against the CPU oracle.
+Bit-exact: everything here is integer / byte / index work."""
+import numpy as np
+import pytest
+
+import oracle as O
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    import textcomp
+    c = textcomp.Context(0)
+    yield c
+    c.close()
+
+
+def _texts():
+    rng = np.random.default_rng(11)
+    out = [b"a", b"ba", b"ab", b"aaaaaaaa", b"abababab", b"mississippi", b"abracadabra",
+           b"ACGTACGTACGT", bytes(range(256)), bytes([255, 0, 255, 0, 0]), b"aaaabbbbcccc"]
+    for sigma in (1, 2, 5, 17, 100, 256):
+        for n in (1, 2, 3, 63, 64, 65, 257, 4095, 4096, 4097, 20000):
+            out.append(rng.integers(0, sigma, n, dtype=np.uint8).tobytes())
+    return out
+
+
+TEXTS = _texts()
+
+
+def _ids(t):
+    return "n%d_s%d" % (len(t), len(set(t)))
+
+
+def _expect_bwt(t):
+    L = O.bwt_encode_arr(t)
+    prim = int(np.nonzero(L < 0)[0][0])
+    Lb = L.copy()
+    Lb[prim] = 0
+    return Lb.astype(np.uint8), prim, L
+
+
+@pytest.mark.parametrize("t", TEXTS, ids=_ids)
+def test_suffix_array_and_bwt(ctx, t):
+    sa = ctx.suffix_array(t)
+    assert sa.tolist() == O.suffix_array(t).tolist()
+    L, prim = ctx.bwt_encode(t)
+    eL, eprim, _ = _expect_bwt(t)
+    assert prim == eprim and L.tolist() == eL.tolist()
+
+
+def test_bwt_empty(ctx):
+    L, prim = ctx.bwt_encode(b"")
+    assert len(L) == 0 and prim is None
+
+
+@pytest.mark.parametrize("t", TEXTS, ids=_ids)
+def test_mtf(ctx, t):
+    eL, eprim, sym = _expect_bwt(t)
+    idx, fl = ctx.mtf_encode(eL, eprim)
+    eidx, efl = O.mtf_encode_arr(sym)
+    assert idx.tolist() == eidx.tolist() and fl.tolist() == efl.tolist()
+    idx2, fl2 = ctx.mtf_encode_sym(sym)
+    assert idx2.tolist() == eidx.tolist() and fl2.tolist() == efl.tolist()
+
+
+def test_mtf_general_path_equals_nibble_path(ctx, monkeypatch):
+    t = O.gen_acgtn(5, 50000)
+    eL, eprim, sym = _expect_bwt(t)
+    a = ctx.mtf_encode(eL, eprim)
+    monkeypatch.setenv("TC_MTF_FORCE_GENERAL", "1")
+    b = ctx.mtf_encode(eL, eprim)
+    assert a[0].tolist() == b[0].tolist() and a[1].tolist() == b[1].tolist()
+    assert a[0].tolist() == O.mtf_encode_arr(sym)[0].tolist()
+
+
+@pytest.mark.parametrize("t", TEXTS, ids=_ids)
+def test_rle(ctx, t):
+    eL, eprim, sym = _expect_bwt(t)
+    counts, syms = ctx.rle_encode(eL, eprim)
+    ec, es = O.rle_encode_arr(sym)
+    assert counts.tolist() == ec.tolist() and syms.tolist() == es.tolist()
+
+
+def test_rle_sentinel_quirks(ctx):
+    a, b = ord("a"), ord("b")
+    cases = [[a, a, None, a], [a, b, None], [a, a, a, None], [None, a], [None], [None, None],
+             [a, None, None, b], [None, None, a, a, None, b, b, b, None, None]]
+    rng = np.random.default_rng(5)
+    for _ in range(30):
+        n = int(rng.integers(1, 9000))
+        x = rng.integers(-1, 3, n).tolist()
+        cases.append([None if v < 0 else v for v in x])
+    for x in cases:
+        arr = O.arr_of(x)
+        counts, syms = ctx.rle_encode_sym(arr)
+        ec, es = O.rle_encode_arr(arr)
+        assert counts.tolist() == ec.tolist() and syms.tolist() == es.tolist(), x[:20]
+
+
+def test_rle_capacity_error(ctx):
+    import textcomp
+    with pytest.raises(textcomp.TcError) as e:
+        ctx.rle_encode_sym(np.array([1, 2, 3, 4], dtype=np.int16), cap=2)
+    assert e.value.code == -2
+
+
+@pytest.mark.parametrize("t", TEXTS, ids=_ids)
+def test_fused_encode(ctx, t):
+    blk = ctx.encode(t)
+    _, eprim, sym = _expect_bwt(t)
+    eidx, efl = O.mtf_encode_arr(sym)
+    ec, ev = O.rle_encode_u32_arr(eidx)
+    assert blk["n"] == len(t) and blk["primary"] == eprim and blk["sigma"] == len(efl)
+    assert blk["final_list"].tolist() == efl.tolist()
+    assert blk["run_count"].tolist() == ec.tolist() and blk["run_value"].tolist() == ev.tolist()
+
+
+def test_fused_empty(ctx):
+    blk = ctx.encode(b"")
+    assert blk["n"] == 0 and len(blk["run_count"]) == 0 and blk["sigma"] == 0
+
+
+@pytest.mark.parametrize("name,t", [
+    ("allA", b"A" * 70000), ("acgt_k", b"ACGT" * 20000),
+    ("n_runs", b"N" * 30000 + b"A" + b"N" * 30000 + b"ACGT" * 100),
+    ("two_level", (b"AB" * 5000 + b"C") * 5)])
+def test_adversarial_repetitive(ctx, name, t):
+    sa = ctx.suffix_array(t)
+    assert sa.tolist() == O.suffix_array(t).tolist()
+    blk = ctx.encode(t)
+    _, eprim, sym = _expect_bwt(t)
+    eidx, efl = O.mtf_encode_arr(sym)
+    ec, ev = O.rle_encode_u32_arr(eidx)
+    assert blk["primary"] == eprim
+    assert blk["run_count"].tolist() == ec.tolist() and blk["run_value"].tolist() == ev.tolist()
+
+
+@pytest.mark.parametrize("gen,seed,n", [("ascii", 0xC1, 65536), ("acgtn", 0xC2, 1 << 20),
+                                        ("acgtn", 0xC2, 1 << 24)])
+def test_configs(ctx, gen, seed, n):
+    """BASELINE.json configs[0] (64 KiB ASCII) and configs[1] (16 MiB ACGTN), bit-exact."""
+    t = (O.gen_ascii if gen == "ascii" else O.gen_acgtn)(seed, n)
+    blk = ctx.encode(t)
+    _, eprim, sym = _expect_bwt(t)
+    eidx, efl = O.mtf_encode_arr(sym)
+    ec, ev = O.rle_encode_u32_arr(eidx)
+    assert blk["primary"] == eprim and blk["final_list"].tolist() == efl.tolist()
+    assert np.array_equal(blk["run_count"], ec.astype(np.uint32))
+    assert np.array_equal(blk["run_value"], ev.astype(np.uint16))

@@ -1,0 +1,247 @@
+// tc_common.hpp -- shared host/device plumbing of libtextcomp (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+
+#include <string>
+#include <vector>
+
+#include "textcomp.h"
+
+typedef uint8_t u8;
+typedef uint16_t u16;
+typedef uint32_t u32;
+typedef uint64_t u64;
+typedef int16_t i16;
+typedef int32_t i32;
+typedef int64_t i64;
+
+#define TC_WAVE 64
+
+// ------------------------------------------------------------------ context
+struct tc_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    char *ws = nullptr;  // device workspace arena
+    size_t ws_cap = 0;
+    size_t ws_off = 0;
+    u32 *d_err = nullptr;     // device error word (look-back spin overflow etc.)
+    u64 *d_scalars = nullptr; // small device scratch for scalar results (64 words)
+    u64 *h_scalars = nullptr; // pinned mirror
+    hipEvent_t ev[8] = {};
+    std::string err;
+    tc_stats stats = {};
+};
+
+struct TcFail {
+    int code;
+};
+
+#define TC_HIP(ctx, expr)                                                                  \
+    do {                                                                                   \
+        hipError_t e__ = (expr);                                                           \
+        if (e__ != hipSuccess) {                                                           \
+            char b__[512];                                                                 \
+            snprintf(b__, sizeof b__, "%s:%d: %s -> %s", __FILE__, __LINE__, #expr,        \
+                     hipGetErrorString(e__));                                              \
+            (ctx)->err = b__;                                                              \
+            throw TcFail{e__ == hipErrorOutOfMemory ? TC_ERR_OOM : TC_ERR_HIP};            \
+        }                                                                                  \
+    } while (0)
+
+#define TC_FAIL(ctx, code_, ...)                         \
+    do {                                                 \
+        char b__[512];                                   \
+        snprintf(b__, sizeof b__, __VA_ARGS__);          \
+        (ctx)->err = b__;                                \
+        throw TcFail{code_};                             \
+    } while (0)
+
+#define TC_LAUNCH_CHECK(ctx) TC_HIP(ctx, hipGetLastError())
+
+// Bump allocator over the ctx workspace.  A top-level call first sizes its need
+// with Arena(nullptr) (dry run), grows the workspace once, then carves for real.
+struct Arena {
+    char *base;
+    size_t off = 0;
+    explicit Arena(char *b) : base(b) {}
+    template <class T>
+    T *get(size_t count) {
+        size_t bytes = (count * sizeof(T) + 255) & ~size_t(255);
+        T *p = base ? reinterpret_cast<T *>(base + off) : nullptr;
+        off += bytes;
+        return p;
+    }
+};
+
+void tc_ws_reserve(tc_ctx *ctx, size_t bytes);
+void tc_sync_check(tc_ctx *ctx);  // stream sync + device error word check
+
+static inline u32 tc_cdiv(u64 a, u64 b) { return (u32)((a + b - 1) / b); }
+
+// ------------------------------------------------------------ device helpers
+#ifdef __HIPCC__
+
+__device__ __forceinline__ u32 lane_id() { return __lane_id(); }
+
+__device__ __forceinline__ u64 lanemask_lt() {
+    return (1ull << lane_id()) - 1ull;
+}
+
+// inclusive wave scan (sum) over 64 lanes
+__device__ __forceinline__ u32 wave_incl_sum(u32 v) {
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        u32 t = __shfl_up(v, d, 64);
+        if ((int)lane_id() >= d) v += t;
+    }
+    return v;
+}
+__device__ __forceinline__ u32 wave_incl_max(u32 v) {
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        u32 t = __shfl_up(v, d, 64);
+        if ((int)lane_id() >= d) v = v > t ? v : t;
+    }
+    return v;
+}
+__device__ __forceinline__ u64 wave_incl_max64(u64 v) {
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        u64 t = __shfl_up(v, d, 64);
+        if ((int)lane_id() >= d) v = v > t ? v : t;
+    }
+    return v;
+}
+__device__ __forceinline__ u32 wave_sum(u32 v) {
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) v += __shfl_xor(v, d, 64);
+    return v;
+}
+__device__ __forceinline__ u64 wave_max64(u64 v) {
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) {
+        u64 t = __shfl_xor(v, d, 64);
+        v = v > t ? v : t;
+    }
+    return v;
+}
+
+// Block-wide exclusive sum scan for NT threads (NT multiple of 64, <= 1024).
+// `smem` needs NT/64 + 1 words.  Returns exclusive prefix; *total = block sum.
+template <int NT>
+__device__ __forceinline__ u32 block_excl_sum(u32 v, u32 *smem, u32 *total) {
+    const int w = threadIdx.x >> 6;
+    u32 inc = wave_incl_sum(v);
+    __syncthreads();
+    if (lane_id() == 63) smem[w] = inc;
+    __syncthreads();
+    u32 base = 0, tot = 0;
+#pragma unroll
+    for (int i = 0; i < NT / 64; i++) {
+        u32 s = smem[i];
+        if (i < w) base += s;
+        tot += s;
+    }
+    *total = tot;
+    return base + inc - v;
+}
+
+// Block-wide inclusive max scan (u64).  `smem` needs NT/64 u64 words.
+template <int NT>
+__device__ __forceinline__ u64 block_incl_max64(u64 v, u64 *smem, u64 *total) {
+    const int w = threadIdx.x >> 6;
+    u64 inc = wave_incl_max64(v);
+    __syncthreads();
+    if (lane_id() == 63) smem[w] = inc;
+    __syncthreads();
+    u64 base = 0, tot = 0;
+#pragma unroll
+    for (int i = 0; i < NT / 64; i++) {
+        u64 s = smem[i];
+        if (i < w) base = base > s ? base : s;
+        tot = tot > s ? tot : s;
+    }
+    *total = tot;
+    return inc > base ? inc : base;
+}
+
+// ---- decoupled look-back over tiles (single-pass chained scan) -------------
+// One 8-byte granule per tile: [63:62] flag, [61:0] value, written by ONE relaxed
+// agent-scope atomic store and polled by relaxed agent-scope atomic loads (the
+// "data-tagged granule" hand-off of the MI355X guide: no separate payload, so no
+// release/acquire fence is needed).  Tile ids come from an atomic ticket, so a
+// tile only ever waits on tiles whose blocks are already resident.
+#define LB_FLAG_AGG (1ull << 62)
+#define LB_FLAG_INC (2ull << 62)
+#define LB_VALUE(x) ((x) & ((1ull << 62) - 1))
+#define LB_SPIN_LIMIT (1u << 24)
+
+__device__ __forceinline__ void lb_store(u64 *p, u64 v) {
+    __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ u64 lb_load(const u64 *p) {
+    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+struct OpSum {
+    __device__ static u64 apply(u64 a, u64 b) { return a + b; }
+    __device__ static u64 identity() { return 0; }
+};
+struct OpMax {
+    __device__ static u64 apply(u64 a, u64 b) { return a > b ? a : b; }
+    __device__ static u64 identity() { return 0; }
+};
+// two 31-bit fields, componentwise max (both fields monotone in the tile order)
+struct OpMaxPair {
+    __device__ static u64 apply(u64 a, u64 b) {
+        u64 ah = a >> 31, bh = b >> 31, al = a & 0x7fffffffull, bl = b & 0x7fffffffull;
+        return ((ah > bh ? ah : bh) << 31) | (al > bl ? al : bl);
+    }
+    __device__ static u64 identity() { return 0; }
+};
+
+// Called by ALL threads of wave 0 of the block (other waves wait at the caller's
+// barrier).  Publishes this tile's aggregate, walks predecessors 64 at a time and
+// returns the exclusive prefix (valid in every lane of the calling wave).
+template <class Op>
+__device__ __forceinline__ u64 lb_exclusive(u64 *status, u32 tile, u64 aggregate, u32 *err) {
+    if (tile == 0) {
+        if (lane_id() == 0) lb_store(&status[0], LB_FLAG_INC | aggregate);
+        return Op::identity();
+    }
+    if (lane_id() == 0) lb_store(&status[tile], LB_FLAG_AGG | aggregate);
+    u64 excl = Op::identity();
+    i64 look = (i64)tile - 1;  // lane 0 looks at `look`, lane l at look - l
+    u32 spins = 0;
+    while (true) {
+        i64 idx = look - (i64)lane_id();
+        u64 s = LB_FLAG_INC;  // virtual tiles before 0: inclusive identity
+        if (idx >= 0) s = lb_load(&status[idx]);
+        u64 invalid = __ballot((s >> 62) == 0);
+        if (invalid) {
+            if (++spins > LB_SPIN_LIMIT) {
+                if (lane_id() == 0) atomicOr(err, 1u);
+                break;
+            }
+            __builtin_amdgcn_s_sleep(1);
+            continue;
+        }
+        u64 incmask = __ballot((s >> 62) == 2);
+        // lanes strictly beyond the first inclusive one do not contribute
+        int first_inc = incmask ? __builtin_ctzll(incmask) : 64;
+        u64 v = ((int)lane_id() <= first_inc) ? LB_VALUE(s) : Op::identity();
+        // reduce across the wave (order-insensitive ops only: sum / max)
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) v = Op::apply(v, __shfl_xor(v, d, 64));
+        excl = Op::apply(excl, v);
+        if (incmask) break;
+        look -= 64;
+    }
+    if (lane_id() == 0) lb_store(&status[tile], LB_FLAG_INC | Op::apply(excl, aggregate));
+    return excl;
+}
+
+#endif  // __HIPCC__

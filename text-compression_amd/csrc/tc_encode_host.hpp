@@ -1,0 +1,395 @@
+// tc_encode_host.hpp -- host orchestration of the encode path (device pointers in,
+// device pointers out).  Included by textcomp.hip only.
+#pragma once
+#include <math.h>
+#include <stdlib.h>
+
+#include "tc_mtf.hpp"
+#include "tc_radix_host.hpp"
+#include "tc_rle.hpp"
+#include "tc_sa.hpp"
+
+// ---------------------------------------------------------------- small helpers
+static inline void tc_memset_async(tc_ctx *ctx, void *p, int v, size_t bytes) {
+    TC_HIP(ctx, hipMemsetAsync(p, v, bytes, ctx->stream));
+}
+static inline void tc_d2h(tc_ctx *ctx, void *dst, const void *src, size_t bytes) {
+    TC_HIP(ctx, hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, ctx->stream));
+}
+static inline void tc_h2d(tc_ctx *ctx, void *dst, const void *src, size_t bytes) {
+    TC_HIP(ctx, hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, ctx->stream));
+}
+static inline int ceil_log2_u64(u64 v) {  // bits needed to hold values < v
+    int b = 0;
+    while (b < 63 && (1ull << b) < v) b++;
+    return b;
+}
+static inline int env_int(const char *name, int dflt) {
+    const char *e = getenv(name);
+    return e && *e ? atoi(e) : dflt;
+}
+
+// Alphabet of a Seq (Maybe Word8): counts257[0] = #Nothing, [1+b] = #byte b.
+// nubSeq' (reference MTF/Internal.hs:79-99): present symbols, sorted, Nothing first.
+struct Alphabet {
+    u32 sigma = 0;
+    i16 sym_of_code[TC_MAX_SIGMA];
+    u16 code_of_sym[TC_MAX_SIGMA];  // index = sym + 1
+    void build(const u32 *counts257) {
+        sigma = 0;
+        for (int v = 0; v < 257; v++) {
+            code_of_sym[v] = 0;
+            if (counts257[v]) {
+                code_of_sym[v] = (u16)sigma;
+                sym_of_code[sigma++] = (i16)(v - 1);
+            }
+        }
+    }
+};
+
+// ------------------------------------------------------------------ suffix array
+struct SaBuffers {
+    u64 *k0, *k1;
+    u32 *v0, *v1;
+    u32 *isa;
+    u32 *act[2][3];  // [set][slot, idx, grp]
+    u32 *hist;
+    u64 *rstatus;
+    u64 *gstatus;  // 2*tiles + 2
+    u32 *counts;   // 256 byte counts
+};
+
+static size_t sa_carve(Arena &A, u64 N, SaBuffers &b, bool own_v1) {
+    b.k0 = A.get<u64>(N);
+    b.k1 = A.get<u64>(N);
+    b.v0 = A.get<u32>(N);
+    b.v1 = own_v1 ? A.get<u32>(N) : nullptr;
+    b.isa = A.get<u32>(N + 1);
+    for (int s = 0; s < 2; s++)
+        for (int q = 0; q < 3; q++) b.act[s][q] = A.get<u32>(N);
+    b.hist = A.get<u32>(RDX_MAX_PASSES * RDX_BINS);
+    b.rstatus = A.get<u64>(radix_status_words(N));
+    b.gstatus = A.get<u64>(2 * (size_t)tc_cdiv(N, SA_TILE) + 4);
+    b.counts = A.get<u32>(260);
+    return A.off;
+}
+
+static void sa_choose_config(tc_ctx *ctx, const u32 *counts, u64 n, SaConfig &c) {
+    (void)ctx;
+    u32 sig = 0;
+    double H = 0;
+    for (int v = 0; v < 256; v++) {
+        c.lut[v] = 0;
+        if (counts[v]) {
+            c.lut[v] = (u16)(++sig);
+            double p = (double)counts[v] / (double)n;
+            H -= p * log2(p);
+        }
+    }
+    c.sigma_text = sig;
+    c.B = sig + 1;
+    if (c.B <= 16) {
+        c.w = 8;
+        c.s = 1;
+        u32 pw = c.B;
+        while (pw * c.B <= 256) {
+            pw *= c.B;
+            c.s++;
+        }
+    } else {
+        c.s = 1;
+        c.w = (u32)ceil_log2_u64(c.B);
+    }
+    u32 pmax = 56 / c.w;  // the low 8 key bits carry the preceding text byte
+    // fields so that an iid text of this entropy has ~2^-8 of its suffixes still tied
+    double need = (double)ceil_log2_u64(n + 1) + 8.0;
+    double per_field = H * c.s;
+    u32 P = pmax;
+    if (per_field > 1e-9) {
+        double pf = ceil(need / per_field);
+        if (pf < (double)pmax) P = (u32)pf;
+    }
+    if (P < 1) P = 1;
+    int forced = env_int("TC_SA_FIELDS", 0);
+    if (forced > 0) P = (u32)forced;
+    if (P > pmax) P = pmax;
+    c.P = P;
+    c.h0 = P * c.s;
+}
+
+// Builds SA (d_sa, N entries), last column (d_L, N bytes) and primary for the
+// device text.  d_sa may be null (workspace buffer used).  counts256_out (host,
+// optional) receives the byte histogram.
+static void sa_build(tc_ctx *ctx, Arena &A, const u8 *d_text, u64 n, u32 *d_sa, u8 *d_L,
+                     u64 *primary, u32 *counts256_out, bool dry) {
+    const u64 N = n + 1;
+    SaBuffers b;
+    sa_carve(A, N, b, d_sa == nullptr);
+    if (dry) return;
+    hipStream_t s = ctx->stream;
+    tc_stats &st = ctx->stats;
+
+    // 1. alphabet
+    tc_memset_async(ctx, b.counts, 0, 256 * sizeof(u32));
+    {
+        u32 grid = tc_cdiv(n, 256 * 64);
+        if (grid > 2048) grid = 2048;
+        if (grid < 1) grid = 1;
+        hist256_kernel<<<grid, 256, 0, s>>>(d_text, n, b.counts);
+        TC_LAUNCH_CHECK(ctx);
+    }
+    u32 counts[256];
+    tc_d2h(ctx, counts, b.counts, sizeof counts);
+    TC_HIP(ctx, hipStreamSynchronize(s));
+    if (counts256_out) memcpy(counts256_out, counts, sizeof counts);
+    SaConfig cfg;
+    sa_choose_config(ctx, counts, n, cfg);
+
+    // 2. round-0 keys + digit histograms
+    RadixPlan plan;
+    plan.add_range(64 - (int)(cfg.P * cfg.w), 64);
+    KeyBuildParams kp;
+    kp.B = cfg.B; kp.w = cfg.w; kp.s = cfg.s; kp.P = cfg.P;
+    memcpy(kp.lut, cfg.lut, sizeof kp.lut);
+    kp.plan.npass = plan.npass;
+    for (int p = 0; p < plan.npass; p++) {
+        kp.plan.shift[p] = plan.shift[p];
+        kp.plan.mask[p] = plan.mask[p];
+    }
+    tc_memset_async(ctx, b.hist, 0, sizeof(u32) * RDX_MAX_PASSES * RDX_BINS);
+    keybuild_kernel<<<tc_cdiv(N, SA_TILE), SA_NT, 0, s>>>(d_text, (u32)n, kp, b.k0, b.hist);
+    TC_LAUNCH_CHECK(ctx);
+
+    // 3. radix sort; arrange the ping-pong so the SA lands in the wanted buffer
+    u32 *va = d_sa ? d_sa : b.v1;
+    RadixBuffers rb;
+    rb.keys = b.k0; rb.keys_alt = b.k1;
+    if (plan.npass % 2 == 0) { rb.vals = va; rb.vals_alt = b.v0; }
+    else { rb.vals = b.v0; rb.vals_alt = va; }
+    rb.hist = b.hist;
+    rb.status = b.rstatus;
+    radix_sort_pairs(ctx, rb, (u32)N, plan, /*gen_idx=*/true, /*hist_ready=*/true);
+    u32 *sa = rb.vals;  // == va
+    u64 *skeys = rb.keys;
+
+    // 4. groups, ranks, last column, first active set
+    const u32 gtiles = tc_cdiv(N, SA_TILE);
+    auto run_group = [&](bool init, const u64 *keys, const u32 *idx, const u32 *slot, u32 count,
+                         int outset) {
+        u32 tiles = tc_cdiv(count, SA_TILE);
+        tc_memset_async(ctx, b.gstatus, 0, (2 * (size_t)gtiles + 4) * sizeof(u64));
+        GroupArgs ga;
+        ga.keys = keys; ga.idx = idx; ga.slot = slot; ga.count = count;
+        ga.text = d_text; ga.sa = sa; ga.isa = b.isa; ga.L = d_L;
+        ga.out_slot = b.act[outset][0]; ga.out_idx = b.act[outset][1]; ga.out_grp = b.act[outset][2];
+        ga.status_max = b.gstatus; ga.status_sum = b.gstatus + gtiles;
+        ga.ticket = reinterpret_cast<u32 *>(b.gstatus + 2 * (size_t)gtiles);
+        ga.scalars = ctx->d_scalars; ga.err = ctx->d_err;
+        if (init) group_kernel<true><<<tiles, SA_NT, 0, s>>>(ga);
+        else group_kernel<false><<<tiles, SA_NT, 0, s>>>(ga);
+        TC_LAUNCH_CHECK(ctx);
+        tc_d2h(ctx, ctx->h_scalars, ctx->d_scalars, 2 * sizeof(u64));
+        TC_HIP(ctx, hipStreamSynchronize(s));
+    };
+    tc_memset_async(ctx, ctx->d_scalars, 0, 8 * sizeof(u64));
+    run_group(true, skeys, sa, nullptr, (u32)N, 0);
+    u64 m = ctx->h_scalars[1];
+    st.rounds = 1;
+    st.m[0] = N; st.key_bytes[0] = 8; st.passes[0] = (u32)plan.npass; st.h[0] = 0;
+
+    // 5. prefix doubling on the tied suffixes
+    int cur = 0;
+    u64 h = cfg.h0;
+    const int rbits = ceil_log2_u64(N);
+    while (m > 0) {
+        if (st.rounds >= TC_MAX_ROUNDS) TC_FAIL(ctx, TC_ERR_INTERNAL, "suffix sort did not converge");
+        u32 mm = (u32)m;
+        u32 hh = h > N ? (u32)N : (u32)h;
+        u64 *k2 = b.k0, *k2alt = b.k1;  // round-0 keys are dead by now
+        key2_kernel<<<tc_cdiv(mm, 256), 256, 0, s>>>(b.act[cur][1], b.act[cur][2], b.isa, mm, hh,
+                                                    (u32)N, k2);
+        TC_LAUNCH_CHECK(ctx);
+        RadixPlan p2;
+        p2.add_range(0, rbits);
+        p2.add_range(32, 32 + rbits);
+        RadixBuffers r2;
+        r2.keys = k2; r2.keys_alt = k2alt;
+        r2.vals = b.act[cur][1]; r2.vals_alt = b.v0;
+        r2.hist = b.hist; r2.status = b.rstatus;
+        radix_sort_pairs(ctx, r2, mm, p2, false, false);
+        run_group(false, r2.keys, r2.vals, b.act[cur][0], mm, cur ^ 1);
+        st.m[st.rounds] = m; st.key_bytes[st.rounds] = 8; st.passes[st.rounds] = (u32)p2.npass;
+        st.h[st.rounds] = hh;
+        st.rounds++;
+        // the sort may have left act[cur][1] pointing at v0: nothing to restore, the
+        // next set is rebuilt by the group kernel
+        m = ctx->h_scalars[1];
+        cur ^= 1;
+        h *= 2;
+    }
+    *primary = ctx->h_scalars[0];
+    st.sigma = cfg.sigma_text + 1;
+}
+
+// ------------------------------------------------------------------- accessors
+template <class Acc>
+static Acc make_acc(const void *d_src, i64 primary);
+template <>
+BwtAcc make_acc<BwtAcc>(const void *d_src, i64 primary) {
+    return BwtAcc{reinterpret_cast<const u8 *>(d_src), primary};
+}
+template <>
+SymAcc make_acc<SymAcc>(const void *d_src, i64) {
+    return SymAcc{reinterpret_cast<const i16 *>(d_src)};
+}
+template <>
+U16Acc make_acc<U16Acc>(const void *d_src, i64) {
+    return U16Acc{reinterpret_cast<const u16 *>(d_src)};
+}
+
+// Symbol histogram of an accessor stream -> host counts257.
+template <class Acc>
+static void sym_hist_host(tc_ctx *ctx, Acc acc, u64 N, u32 *d_counts, u32 *counts257) {
+    tc_memset_async(ctx, d_counts, 0, 260 * sizeof(u32));
+    u32 grid = tc_cdiv(N, 256 * 32);
+    if (grid > 2048) grid = 2048;
+    sym_hist_kernel<Acc><<<grid, 256, 0, ctx->stream>>>(acc, N, d_counts);
+    TC_LAUNCH_CHECK(ctx);
+    tc_d2h(ctx, counts257, d_counts, 257 * sizeof(u32));
+    TC_HIP(ctx, hipStreamSynchronize(ctx->stream));
+}
+
+// ------------------------------------------------------------------------- MTF
+template <class Acc, int ROWS>
+static void mtf_general_launch(tc_ctx *ctx, Acc acc, u64 N, const Lut16 &lut, u16 *lists,
+                               u32 *seen, u32 chunks, u16 *d_idx) {
+    hipStream_t s = ctx->stream;
+    mtf_gen_summary_kernel<Acc, ROWS><<<chunks, 64, 0, s>>>(acc, N, lut, lists, seen);
+    TC_LAUNCH_CHECK(ctx);
+    mtf_gen_scan_kernel<ROWS><<<1, 64, 0, s>>>(lists, seen, chunks);
+    TC_LAUNCH_CHECK(ctx);
+    mtf_gen_apply_kernel<Acc, ROWS><<<chunks, 64, 0, s>>>(acc, N, lut, lists, d_idx);
+    TC_LAUNCH_CHECK(ctx);
+}
+
+// seqToMTF on the device.  counts257 (host) may be null: then it is measured here.
+template <class Acc>
+static void mtf_encode_device(tc_ctx *ctx, Arena &A, Acc acc, u64 N, const u32 *counts257,
+                              u16 *d_idx, i16 *final_list, u32 *sigma, bool dry) {
+    const u32 tiles = tc_cdiv(N, MTF_TILE);
+    const u32 chunks = tc_cdiv(N, MTFG_CH);
+    u32 *d_counts = A.get<u32>(260);
+    u64 *t_perm = A.get<u64>(tiles + 1);
+    u32 *t_mask = A.get<u32>(tiles + 1);
+    u16 *lists = A.get<u16>(((size_t)chunks + 1) * 320);
+    u32 *seen = A.get<u32>(chunks + 1);
+    if (dry) return;
+    hipStream_t s = ctx->stream;
+    u32 local[257];
+    if (!counts257) {
+        sym_hist_host<Acc>(ctx, acc, N, d_counts, local);
+        counts257 = local;
+    }
+    Alphabet al;
+    al.build(counts257);
+    *sigma = al.sigma;
+    const bool force_general = env_int("TC_MTF_FORCE_GENERAL", 0) != 0;
+    if (al.sigma <= 16 && !force_general) {
+        Lut8 lut;
+        for (int v = 0; v < 257; v++) lut.v[v] = (u8)al.code_of_sym[v];
+        mtf_nib_summary_kernel<Acc><<<tiles, MTF_NT, 0, s>>>(acc, N, lut, t_perm, t_mask);
+        TC_LAUNCH_CHECK(ctx);
+        mtf_nib_scan_kernel<<<1, MTF_NT, 0, s>>>(t_perm, t_mask, tiles);
+        TC_LAUNCH_CHECK(ctx);
+        mtf_nib_apply_kernel<Acc><<<tiles, MTF_NT, 0, s>>>(acc, N, lut, t_perm, d_idx);
+        TC_LAUNCH_CHECK(ctx);
+        tc_d2h(ctx, &ctx->h_scalars[8], t_perm + tiles, sizeof(u64));
+        TC_HIP(ctx, hipStreamSynchronize(s));
+        u64 perm = ctx->h_scalars[8];
+        for (u32 i = 0; i < al.sigma; i++) final_list[i] = al.sym_of_code[(perm >> (4 * i)) & 15];
+    } else {
+        Lut16 lut;
+        for (int v = 0; v < 257; v++) lut.v[v] = al.code_of_sym[v];
+        int rows = al.sigma <= 64 ? 1 : (al.sigma <= 128 ? 2 : 5);
+        if (rows == 1) mtf_general_launch<Acc, 1>(ctx, acc, N, lut, lists, seen, chunks, d_idx);
+        else if (rows == 2) mtf_general_launch<Acc, 2>(ctx, acc, N, lut, lists, seen, chunks, d_idx);
+        else mtf_general_launch<Acc, 5>(ctx, acc, N, lut, lists, seen, chunks, d_idx);
+        std::vector<u16> fl(rows * 64);
+        tc_d2h(ctx, fl.data(), lists + (size_t)chunks * (rows * 64), fl.size() * sizeof(u16));
+        TC_HIP(ctx, hipStreamSynchronize(s));
+        for (u32 i = 0; i < al.sigma; i++) final_list[i] = al.sym_of_code[fl[i]];
+    }
+}
+
+// ------------------------------------------------------------------------- RLE
+template <class Acc, class SymT>
+static void rle_encode_device(tc_ctx *ctx, Arena &A, Acc acc, u64 N, u32 *d_counts, SymT *d_syms,
+                              u64 cap, u64 *total, bool dry) {
+    const u32 tiles = tc_cdiv(N, RLE_TILE);
+    u64 *status = A.get<u64>(2 * (size_t)tiles + 4);
+    if (dry) return;
+    tc_memset_async(ctx, status, 0, (2 * (size_t)tiles + 4) * sizeof(u64));
+    RleArgs a;
+    a.N = N; a.counts = d_counts; a.syms = d_syms; a.cap = cap;
+    a.status_pair = status; a.status_sum = status + tiles;
+    a.ticket = reinterpret_cast<u32 *>(status + 2 * (size_t)tiles);
+    a.scalars = ctx->d_scalars; a.err = ctx->d_err;
+    rle_encode_kernel<Acc, SymT><<<tiles, RLE_NT, 0, ctx->stream>>>(acc, a);
+    TC_LAUNCH_CHECK(ctx);
+    tc_d2h(ctx, &ctx->h_scalars[2], ctx->d_scalars + 2, sizeof(u64));
+    TC_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    *total = ctx->h_scalars[2];
+}
+
+// --------------------------------------------------------------- fused pipeline
+// bytestringToBWT -> bytestringBWTToMTFB -> runs of the index stream.
+static void encode_device(tc_ctx *ctx, const u8 *d_text, u64 n, tc_block *out, u64 cap) {
+    const u64 N = n + 1;
+    ctx->stats = tc_stats{};
+    ctx->stats.n = n; ctx->stats.N = N;
+    u8 *d_L = nullptr;
+    u16 *d_idx = nullptr;
+    u64 primary = 0, total = 0;
+    u32 counts[256], counts257[257];
+    u32 sigma = 0;
+    hipStream_t s = ctx->stream;
+    auto plan = [&](Arena &A, bool dry) {
+        d_L = A.get<u8>(N + 16);
+        d_idx = A.get<u16>(N);
+        size_t mark = A.off;
+        if (!dry) TC_HIP(ctx, hipEventRecord(ctx->ev[0], s));
+        sa_build(ctx, A, d_text, n, nullptr, d_L, &primary, counts, dry);
+        size_t end_sa = A.off;
+        A.off = mark;  // the suffix-sort buffers are dead: MTF / RLE scratch overlays them
+        if (!dry) {
+            TC_HIP(ctx, hipEventRecord(ctx->ev[1], s));
+            counts257[0] = 1;
+            for (int b = 0; b < 256; b++) counts257[1 + b] = counts[b];
+        }
+        BwtAcc acc{d_L, (i64)primary};
+        mtf_encode_device<BwtAcc>(ctx, A, acc, N, dry ? nullptr : counts257, d_idx,
+                                  out->final_list, &sigma, dry);
+        if (!dry) TC_HIP(ctx, hipEventRecord(ctx->ev[2], s));
+        U16Acc iacc{d_idx};
+        rle_encode_device<U16Acc, u16>(ctx, A, iacc, N, out->run_count, out->run_value, cap,
+                                       &total, dry);
+        if (!dry) TC_HIP(ctx, hipEventRecord(ctx->ev[3], s));
+        if (A.off < end_sa) A.off = end_sa;
+    };
+    Arena dry(nullptr);
+    plan(dry, true);
+    tc_ws_reserve(ctx, dry.off);
+    Arena A(ctx->ws);
+    plan(A, false);
+    tc_sync_check(ctx);
+    out->n = n; out->primary = primary; out->sigma = sigma; out->nruns = total;
+    tc_stats &st = ctx->stats;
+    st.runs = total;
+    (void)hipEventElapsedTime(&st.ms_sa, ctx->ev[0], ctx->ev[1]);
+    (void)hipEventElapsedTime(&st.ms_mtf, ctx->ev[1], ctx->ev[2]);
+    (void)hipEventElapsedTime(&st.ms_rle, ctx->ev[2], ctx->ev[3]);
+    (void)hipEventElapsedTime(&st.ms_total, ctx->ev[0], ctx->ev[3]);
+    st.ms_bwt = 0;  // the last column is produced inside the suffix-sort kernels
+    if (total > cap) TC_FAIL(ctx, TC_ERR_CAPACITY, "need %llu run slots, have %llu",
+                             (unsigned long long)total, (unsigned long long)cap);
+}

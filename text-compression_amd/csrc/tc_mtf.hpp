@@ -1,0 +1,435 @@
+// tc_mtf.hpp -- move-to-front transform and its inverse on the device.
+//
+// Replaces seqToMTF (reference MTF/Internal.hs:128-175; a strictly sequential
+// findIndexL + deleteAt + cons per symbol) and seqFromMTF (:201-232).
+//
+// MTF is a scan over list states.  A chunk's effect on ANY incoming list L is
+// "its distinct symbols, most recent first, followed by the rest of L in order"
+// so a chunk is summarised by its recency list, and summaries compose
+// associatively (apply the right chunk's recency list, least recent first, to the
+// left one).  Three launches: per-chunk summaries -> scan of summaries -> replay of
+// every chunk from its true incoming list.
+//   sigma <= 16: the list is 16 nibbles in one 64-bit register, one chunk per
+//                lane (ACGTN + '$' has sigma = 6).
+//   sigma <= 257: the list lives across the lanes of a wave, one chunk per wave,
+//                find by ballot, shift by lane rotate.
+#pragma once
+#include "tc_common.hpp"
+
+// ---- symbol accessors (-1 = Nothing) -------------------------------------------
+struct BwtAcc {  // (L, primary): the shape bytestringToBWT returns
+    const u8 *L;
+    i64 primary;
+    __device__ __forceinline__ int operator()(u64 j) const {
+        return (i64)j == primary ? -1 : (int)L[j];
+    }
+};
+struct SymAcc {  // Seq (Maybe Word8) as int16
+    const i16 *s;
+    __device__ __forceinline__ int operator()(u64 j) const { return (int)s[j]; }
+};
+struct U16Acc {  // plain integers (MTF index stream); never Nothing
+    const u16 *v;
+    __device__ __forceinline__ int operator()(u64 j) const { return (int)v[j]; }
+};
+
+#define MTF_NT 256
+#define MTF_CH 64                       // symbols per lane chunk (nibble path)
+#define MTF_TILE (MTF_NT * MTF_CH)      // 16384
+#define MTF_STRIDE (MTF_CH + 4)         // LDS chunk stride in bytes: 17 dwords, conflict-free
+#define MTFG_CH 4096                    // symbols per wave chunk (general path), multiple of 64
+
+struct Lut8 { u8 v[260]; };     // index = sym + 1 -> code
+struct Lut16 { u16 v[260]; };
+struct SymTab { i16 v[260]; };  // code -> sym
+
+#ifdef __HIPCC__
+
+// presence histogram over an accessor (standalone MTF / RLE / FM entry points)
+template <class Acc>
+__global__ __launch_bounds__(256) void sym_hist_kernel(Acc acc, u64 N, u32 *__restrict__ counts) {
+    __shared__ u32 s_h[257];
+    for (int i = threadIdx.x; i < 257; i += 256) s_h[i] = 0;
+    __syncthreads();
+    for (u64 j = (u64)blockIdx.x * 256 + threadIdx.x; j < N; j += (u64)gridDim.x * 256)
+        atomicAdd(&s_h[acc(j) + 1], 1u);
+    __syncthreads();
+    for (int i = threadIdx.x; i < 257; i += 256)
+        if (s_h[i]) atomicAdd(&counts[i], s_h[i]);
+}
+
+// ================================ nibble path ==================================
+struct NibSumm {
+    u64 perm;  // list, front = low nibble
+    u32 mask;  // codes seen
+};
+#define NIB_IDENT 0xFEDCBA9876543210ull
+
+__device__ __forceinline__ u32 nib_find(u64 list, u32 c) {
+    u64 x = list ^ (0x1111111111111111ull * c);
+    u64 t = (x - 0x1111111111111111ull) & ~x & 0x8888888888888888ull;
+    return (u32)__builtin_ctzll(t) >> 2;
+}
+__device__ __forceinline__ u64 nib_front(u64 list, u32 pos, u32 c) {
+    u64 lowmask = (1ull << (4 * pos)) - 1ull;      // nibbles [0, pos)
+    u64 upto = (2ull << (4 * pos + 3)) - 1ull;     // nibbles [0, pos]
+    return (list & ~upto) | ((list & lowmask) << 4) | (u64)c;
+}
+// a then b
+__device__ __forceinline__ NibSumm nib_combine(NibSumm a, NibSumm b) {
+    int d = __popc(b.mask);
+    u64 perm = a.perm;
+    for (int i = d - 1; i >= 0; i--) {
+        u32 c = (u32)(b.perm >> (4 * i)) & 15u;
+        perm = nib_front(perm, nib_find(perm, c), c);
+    }
+    return NibSumm{perm, a.mask | b.mask};
+}
+__device__ __forceinline__ NibSumm nib_shfl_up(NibSumm v, int d) {
+    NibSumm r;
+    r.perm = __shfl_up(v.perm, d, 64);
+    r.mask = __shfl_up(v.mask, d, 64);
+    return r;
+}
+
+// Stage one tile of codes into LDS (chunk-major, padded) and return this lane's
+// chunk summary (from the identity list).  0xFF marks padding past N.
+template <class Acc>
+__device__ __forceinline__ void nib_stage(Acc acc, u64 N, u64 base, const u8 *s_lut, u8 *s_code) {
+    for (u32 p = threadIdx.x; p < MTF_TILE; p += MTF_NT) {
+        u64 j = base + p;
+        u8 c = 0xFF;
+        if (j < N) c = s_lut[acc(j) + 1];
+        s_code[(p / MTF_CH) * MTF_STRIDE + (p % MTF_CH)] = c;
+    }
+}
+
+__device__ __forceinline__ NibSumm nib_chunk_summary(const u8 *s_code) {
+    const u32 *cw = reinterpret_cast<const u32 *>(s_code + threadIdx.x * MTF_STRIDE);
+    NibSumm s{NIB_IDENT, 0u};
+#pragma unroll 4
+    for (int q = 0; q < MTF_CH / 4; q++) {
+        u32 wv = cw[q];
+#pragma unroll
+        for (int b = 0; b < 4; b++) {
+            u32 c = (wv >> (8 * b)) & 0xff;
+            if (c != 0xFF) {
+                s.perm = nib_front(s.perm, nib_find(s.perm, c), c);
+                s.mask |= 1u << c;
+            }
+        }
+    }
+    return s;
+}
+
+// inclusive block scan of summaries; returns this thread's EXCLUSIVE prefix and
+// the block aggregate.  s_w needs MTF_NT/64 entries.
+__device__ __forceinline__ NibSumm nib_block_excl(NibSumm mine, NibSumm *s_w, NibSumm *agg) {
+    const int w = threadIdx.x >> 6, l = threadIdx.x & 63;
+    NibSumm inc = mine;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        NibSumm t = nib_shfl_up(inc, d);
+        if (l >= d) inc = nib_combine(t, inc);
+    }
+    NibSumm exc = nib_shfl_up(inc, 1);
+    if (l == 0) exc = NibSumm{NIB_IDENT, 0u};
+    if (l == 63) s_w[w] = inc;
+    __syncthreads();
+    NibSumm pre{NIB_IDENT, 0u}, tot{NIB_IDENT, 0u};
+    for (int i = 0; i < MTF_NT / 64; i++) {
+        if (i < w) pre = nib_combine(pre, s_w[i]);
+        tot = nib_combine(tot, s_w[i]);
+    }
+    *agg = tot;
+    return nib_combine(pre, exc);
+}
+
+template <class Acc>
+__global__ __launch_bounds__(MTF_NT) void mtf_nib_summary_kernel(Acc acc, u64 N,
+                                                                  Lut8 lut,
+                                                                  u64 *__restrict__ t_perm,
+                                                                  u32 *__restrict__ t_mask) {
+    __shared__ u8 s_code[MTF_NT * MTF_STRIDE];
+    __shared__ u8 s_lut[260];
+    __shared__ NibSumm s_w[MTF_NT / 64];
+    for (int i = threadIdx.x; i < 257; i += MTF_NT) s_lut[i] = lut.v[i];
+    __syncthreads();
+    nib_stage(acc, N, (u64)blockIdx.x * MTF_TILE, s_lut, s_code);
+    __syncthreads();
+    NibSumm mine = nib_chunk_summary(s_code);
+    NibSumm agg;
+    (void)nib_block_excl(mine, s_w, &agg);
+    if (threadIdx.x == 0) {
+        t_perm[blockIdx.x] = agg.perm;
+        t_mask[blockIdx.x] = agg.mask;
+    }
+}
+
+// exclusive scan over the tile summaries, in place; one block.  Element `tiles`
+// receives the grand total (the final list).
+__global__ __launch_bounds__(MTF_NT) void mtf_nib_scan_kernel(u64 *t_perm, u32 *t_mask, u32 tiles) {
+    __shared__ NibSumm s_w[MTF_NT / 64];
+    const u32 per = (tiles + MTF_NT - 1) / MTF_NT;
+    const u32 lo = threadIdx.x * per, hi = lo + per < tiles ? lo + per : tiles;
+    NibSumm mine{NIB_IDENT, 0u};
+    for (u32 t = lo; t < hi; t++) mine = nib_combine(mine, NibSumm{t_perm[t], t_mask[t]});
+    NibSumm agg;
+    NibSumm run = nib_block_excl(mine, s_w, &agg);
+    for (u32 t = lo; t < hi; t++) {
+        NibSumm cur{t_perm[t], t_mask[t]};
+        t_perm[t] = run.perm;
+        t_mask[t] = run.mask;
+        run = nib_combine(run, cur);
+    }
+    if (threadIdx.x == 0) {
+        t_perm[tiles] = agg.perm;
+        t_mask[tiles] = agg.mask;
+    }
+}
+
+template <class Acc>
+__global__ __launch_bounds__(MTF_NT) void mtf_nib_apply_kernel(Acc acc, u64 N,
+                                                                Lut8 lut,
+                                                                const u64 *__restrict__ t_perm,
+                                                                u16 *__restrict__ idx) {
+    __shared__ u8 s_code[MTF_NT * MTF_STRIDE];
+    __shared__ u8 s_lut[260];
+    __shared__ NibSumm s_w[MTF_NT / 64];
+    for (int i = threadIdx.x; i < 257; i += MTF_NT) s_lut[i] = lut.v[i];
+    __syncthreads();
+    const u64 base = (u64)blockIdx.x * MTF_TILE;
+    nib_stage(acc, N, base, s_lut, s_code);
+    __syncthreads();
+    NibSumm mine = nib_chunk_summary(s_code);
+    NibSumm agg;
+    NibSumm exc = nib_block_excl(mine, s_w, &agg);
+    // true incoming list of this lane's chunk: tile's incoming list, then the
+    // block-local prefix applied to it
+    NibSumm in = nib_combine(NibSumm{t_perm[blockIdx.x], 0u}, exc);
+    u64 list = in.perm;
+    u32 *cw = reinterpret_cast<u32 *>(s_code + threadIdx.x * MTF_STRIDE);
+#pragma unroll 4
+    for (int q = 0; q < MTF_CH / 4; q++) {
+        u32 wv = cw[q], ov = 0;
+#pragma unroll
+        for (int b = 0; b < 4; b++) {
+            u32 c = (wv >> (8 * b)) & 0xff;
+            u32 pos = 0;
+            if (c != 0xFF) {
+                pos = nib_find(list, c);
+                list = nib_front(list, pos, c);
+            }
+            ov |= pos << (8 * b);
+        }
+        cw[q] = ov;  // indices overwrite the codes in place
+    }
+    __syncthreads();
+    for (u32 p = threadIdx.x; p < MTF_TILE; p += MTF_NT) {
+        u64 j = base + p;
+        if (j < N) idx[j] = (u16)s_code[(p / MTF_CH) * MTF_STRIDE + (p % MTF_CH)];
+    }
+}
+
+// ================================ general path ==================================
+// List position q = r*64 + lane lives in row[r] of lane `lane`.  ROWS = ceil(sigma/64).
+template <int ROWS>
+struct WaveList {
+    u32 row[ROWS];
+    __device__ __forceinline__ void init_identity() {
+#pragma unroll
+        for (int r = 0; r < ROWS; r++) row[r] = r * 64 + lane_id();
+    }
+    // move code c (wave-uniform, present in the list) to the front; returns its position
+    __device__ __forceinline__ u32 step(u32 c) {
+        int pos = 0;
+#pragma unroll
+        for (int r = 0; r < ROWS; r++) {
+            u64 m = __ballot(row[r] == c);
+            if (m) pos = r * 64 + __builtin_ctzll(m);
+        }
+        u32 carry = c;
+#pragma unroll
+        for (int r = 0; r < ROWS; r++) {
+            u32 last = __shfl(row[r], 63, 64);
+            u32 sh = __shfl_up(row[r], 1, 64);
+            if (lane_id() == 0) sh = carry;
+            int q = r * 64 + (int)lane_id();
+            row[r] = (q <= pos) ? sh : row[r];
+            carry = last;
+        }
+        return (u32)pos;
+    }
+    __device__ __forceinline__ void load(const u16 *p) {
+#pragma unroll
+        for (int r = 0; r < ROWS; r++) row[r] = p[r * 64 + lane_id()];
+    }
+    __device__ __forceinline__ void store(u16 *p) const {
+#pragma unroll
+        for (int r = 0; r < ROWS; r++) p[r * 64 + lane_id()] = (u16)row[r];
+    }
+};
+
+// one wave per chunk: final list from identity + number of distinct codes seen.
+// lists: [chunks][ROWS*64] u16; seen: [chunks] u32.  Seen codes end up in front.
+template <class Acc, int ROWS>
+__global__ __launch_bounds__(64) void mtf_gen_summary_kernel(Acc acc, u64 N,
+                                                             Lut16 lut,
+                                                             u16 *__restrict__ lists,
+                                                             u32 *__restrict__ seen) {
+    const u64 base = (u64)blockIdx.x * MTFG_CH;
+    WaveList<ROWS> wl;
+    wl.init_identity();
+    u32 maxpos1 = 0;  // distinct seen = 1 + max position ever found... tracked via first-seen count
+    u32 nseen = 0;
+    for (u32 o = 0; o < MTFG_CH; o += 64) {
+        u64 j = base + o + lane_id();
+        u32 code = (j < N) ? (u32)lut.v[acc(j) + 1] : 0xFFFFu;
+        u32 cnt = (base + o + 64 <= N) ? 64u : (u32)(N > base + o ? N - (base + o) : 0);
+        for (u32 t = 0; t < cnt; t++) {
+            u32 c = __shfl(code, t, 64);
+            u32 pos = wl.step(c);
+            // a first occurrence is found at position >= nseen (unseen codes sit behind
+            // the seen ones)
+            if (pos >= nseen) nseen++;
+        }
+    }
+    (void)maxpos1;
+    wl.store(lists + (u64)blockIdx.x * (ROWS * 64));
+    if (lane_id() == 0) seen[blockIdx.x] = nseen;
+}
+
+// single wave: incoming[c] = list before chunk c; lists[c] is overwritten with it.
+// tail slot `chunks` receives the final list.
+template <int ROWS>
+__global__ __launch_bounds__(64) void mtf_gen_scan_kernel(u16 *lists, const u32 *seen, u32 chunks) {
+    WaveList<ROWS> st;
+    st.init_identity();
+    for (u32 c = 0; c < chunks; c++) {
+        u16 *lp = lists + (u64)c * (ROWS * 64);
+        WaveList<ROWS> rec;
+        rec.load(lp);
+        st.store(lp);
+        u32 d = seen[c];
+        for (int i = (int)d - 1; i >= 0; i--) {
+            u32 code = __shfl(rec.row[i >> 6], i & 63, 64);
+            (void)st.step(code);
+        }
+    }
+    st.store(lists + (u64)chunks * (ROWS * 64));
+}
+
+template <class Acc, int ROWS>
+__global__ __launch_bounds__(64) void mtf_gen_apply_kernel(Acc acc, u64 N,
+                                                           Lut16 lut,
+                                                           const u16 *__restrict__ lists,
+                                                           u16 *__restrict__ idx) {
+    const u64 base = (u64)blockIdx.x * MTFG_CH;
+    WaveList<ROWS> wl;
+    wl.load(lists + (u64)blockIdx.x * (ROWS * 64));
+    for (u32 o = 0; o < MTFG_CH; o += 64) {
+        u64 j = base + o + lane_id();
+        u32 code = (j < N) ? (u32)lut.v[acc(j) + 1] : 0xFFFFu;
+        u32 cnt = (base + o + 64 <= N) ? 64u : (u32)(N > base + o ? N - (base + o) : 0);
+        u32 out = 0;
+        for (u32 t = 0; t < cnt; t++) {
+            u32 c = __shfl(code, t, 64);
+            u32 pos = wl.step(c);
+            if (lane_id() == t) out = pos;
+        }
+        if (j < N) idx[j] = (u16)out;
+    }
+}
+
+// ---- inverse MTF (seqFromMTF): same scan, but a chunk's effect is a general
+// permutation of list POSITIONS (index -> move that position to the front) -------
+// perm maps: new_list[q] = old_list[perm[q]].
+template <int ROWS>
+__device__ __forceinline__ u32 wl_step_pos(WaveList<ROWS> &wl, u32 pos) {
+    // move the entry at `pos` (wave-uniform) to the front; returns the entry
+    u32 c = __shfl(wl.row[0], 0, 64);
+#pragma unroll
+    for (int r = 0; r < ROWS; r++) {
+        u32 v = __shfl(wl.row[r], pos & 63, 64);
+        if ((int)(pos >> 6) == r) c = v;
+    }
+    u32 carry = c;
+#pragma unroll
+    for (int r = 0; r < ROWS; r++) {
+        u32 last = __shfl(wl.row[r], 63, 64);
+        u32 sh = __shfl_up(wl.row[r], 1, 64);
+        if (lane_id() == 0) sh = carry;
+        u32 q = r * 64 + lane_id();
+        wl.row[r] = (q <= pos) ? sh : wl.row[r];
+        carry = last;
+    }
+    return c;
+}
+
+// one wave per chunk: position permutation of the chunk (applied to identity)
+template <int ROWS>
+__global__ __launch_bounds__(64) void imtf_summary_kernel(const u16 *__restrict__ idx, u64 N,
+                                                          u32 sigma, u16 *__restrict__ perms,
+                                                          u32 *err) {
+    const u64 base = (u64)blockIdx.x * MTFG_CH;
+    WaveList<ROWS> wl;
+    wl.init_identity();
+    for (u32 o = 0; o < MTFG_CH; o += 64) {
+        u64 j = base + o + lane_id();
+        u32 p = (j < N) ? (u32)idx[j] : 0u;
+        if (j < N && p >= sigma) atomicOr(err, 0x100u);  // DS.index out of range
+        u32 cnt = (base + o + 64 <= N) ? 64u : (u32)(N > base + o ? N - (base + o) : 0);
+        for (u32 t = 0; t < cnt; t++) {
+            u32 pos = __shfl(p, t, 64);
+            if (pos >= sigma) pos = 0;
+            (void)wl_step_pos<ROWS>(wl, pos);
+        }
+    }
+    wl.store(perms + (u64)blockIdx.x * (ROWS * 64));
+}
+
+// single wave: state[c] = list (of codes) before chunk c; compose with chunk perms.
+template <int ROWS>
+__global__ __launch_bounds__(64) void imtf_scan_kernel(u16 *perms, u32 chunks) {
+    __shared__ u16 s_list[ROWS * 64];
+    WaveList<ROWS> st;
+    st.init_identity();
+    for (u32 c = 0; c < chunks; c++) {
+        u16 *pp = perms + (u64)c * (ROWS * 64);
+        WaveList<ROWS> pm;
+        pm.load(pp);
+        st.store(pp);
+        // new_state[q] = state[pm[q]]
+        st.store(s_list);
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int r = 0; r < ROWS; r++) st.row[r] = s_list[pm.row[r]];
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+
+template <int ROWS>
+__global__ __launch_bounds__(64) void imtf_apply_kernel(const u16 *__restrict__ idx, u64 N,
+                                                        u32 sigma,
+                                                        const u16 *__restrict__ states,
+                                                        SymTab sym_of_code,
+                                                        i16 *__restrict__ out) {
+    const u64 base = (u64)blockIdx.x * MTFG_CH;
+    WaveList<ROWS> wl;
+    wl.load(states + (u64)blockIdx.x * (ROWS * 64));
+    for (u32 o = 0; o < MTFG_CH; o += 64) {
+        u64 j = base + o + lane_id();
+        u32 p = (j < N) ? (u32)idx[j] : 0u;
+        u32 cnt = (base + o + 64 <= N) ? 64u : (u32)(N > base + o ? N - (base + o) : 0);
+        u32 res = 0;
+        for (u32 t = 0; t < cnt; t++) {
+            u32 pos = __shfl(p, t, 64);
+            if (pos >= sigma) pos = 0;
+            u32 c = wl_step_pos<ROWS>(wl, pos);
+            if (lane_id() == t) res = c;
+        }
+        if (j < N) out[j] = sym_of_code.v[res];
+    }
+}
+
+#endif  // __HIPCC__

@@ -1,0 +1,388 @@
+// textcomp.hip -- libtextcomp.so: C ABI (include/textcomp.h) over the HIP kernels.
+// Single translation unit for gfx950: hipcc --offload-arch=gfx950 -shared -fPIC.
+#include "tc_common.hpp"
+#include "tc_encode_host.hpp"
+#include "tc_decode_host.hpp"
+#include "tc_fm_host.hpp"
+
+// ================================================================== context
+void tc_ws_reserve(tc_ctx *ctx, size_t bytes) {
+    if (bytes <= ctx->ws_cap) return;
+    if (ctx->ws) {
+        TC_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        TC_HIP(ctx, hipFree(ctx->ws));
+        ctx->ws = nullptr;
+        ctx->ws_cap = 0;
+    }
+    size_t want = bytes + (bytes >> 4) + (1u << 20);
+    hipError_t e = hipMalloc((void **)&ctx->ws, want);
+    if (e != hipSuccess) {
+        want = bytes;
+        e = hipMalloc((void **)&ctx->ws, want);
+    }
+    if (e != hipSuccess) {
+        (void)hipGetLastError();
+        TC_FAIL(ctx, TC_ERR_OOM, "workspace of %zu bytes: %s", bytes, hipGetErrorString(e));
+    }
+    ctx->ws_cap = want;
+}
+
+void tc_sync_check(tc_ctx *ctx) {
+    u32 err = 0;
+    TC_HIP(ctx, hipMemcpyAsync(&ctx->h_scalars[63], ctx->d_err, sizeof(u32), hipMemcpyDeviceToHost,
+                               ctx->stream));
+    TC_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    err = (u32)ctx->h_scalars[63];
+    if (err) {
+        (void)hipMemsetAsync(ctx->d_err, 0, sizeof(u32), ctx->stream);
+        if (err & 0xff00u) TC_FAIL(ctx, TC_ERR_MALFORMED, "malformed input (device flag 0x%x)", err);
+        TC_FAIL(ctx, TC_ERR_INTERNAL, "device-side failure flag 0x%x", err);
+    }
+}
+
+#define TC_API_BEGIN(ctx)                                  \
+    if (!(ctx)) return TC_ERR_ARG;                         \
+    try {                                                  \
+        if (hipSetDevice((ctx)->device) != hipSuccess) {   \
+            (ctx)->err = "hipSetDevice failed";            \
+            return TC_ERR_HIP;                             \
+        }
+#define TC_API_END(ctx)                                    \
+        return TC_OK;                                      \
+    } catch (const TcFail &f) {                            \
+        (void)hipGetLastError();                           \
+        return f.code;                                     \
+    } catch (...) {                                        \
+        (ctx)->err = "unexpected exception";               \
+        return TC_ERR_INTERNAL;                            \
+    }
+
+// host-pointer form: stage H2D, run, stage D2H
+static void bwt_host(tc_ctx *ctx, const u8 *text, u64 n, u8 *L, u32 *sa, u64 *primary) {
+    const u64 N = n + 1;
+    ctx->stats = tc_stats{};
+    ctx->stats.n = n; ctx->stats.N = N;
+    auto plan = [&](Arena &A, bool dry, u8 *&d_text, u8 *&d_L, u32 *&d_sa) {
+        d_text = A.get<u8>(n + 16);
+        d_L = A.get<u8>(N + 16);
+        d_sa = A.get<u32>(N);
+        sa_build(ctx, A, d_text, n, d_sa, d_L, primary, nullptr, dry);
+    };
+    u8 *d_text, *d_L;
+    u32 *d_sa;
+    Arena dry(nullptr);
+    plan(dry, true, d_text, d_L, d_sa);
+    tc_ws_reserve(ctx, dry.off);
+    // carve input first, upload, then run
+    {
+        Arena A0(ctx->ws);
+        u8 *t = A0.get<u8>(n + 16);
+        tc_h2d(ctx, t, text, n);
+    }
+    Arena A(ctx->ws);
+    plan(A, false, d_text, d_L, d_sa);
+    if (L) tc_d2h(ctx, L, d_L, N);
+    if (sa) tc_d2h(ctx, sa, d_sa, N * sizeof(u32));
+    tc_sync_check(ctx);
+}
+
+
+template <class Acc>
+static void mtf_host(tc_ctx *ctx, const void *src, size_t src_bytes, bool is_sym, u64 N,
+                     i64 primary, u16 *idx, i16 *final_list, u32 *sigma) {
+    u8 *d_src = nullptr;
+    u16 *d_idx = nullptr;
+    auto plan = [&](Arena &A, bool dry) {
+        d_src = A.get<u8>(src_bytes + 16);
+        d_idx = A.get<u16>(N);
+        if (!dry) tc_h2d(ctx, d_src, src, src_bytes);
+        Acc acc = make_acc<Acc>(d_src, primary);
+        (void)is_sym;
+        mtf_encode_device<Acc>(ctx, A, acc, N, nullptr, d_idx, final_list, sigma, dry);
+    };
+    Arena dry(nullptr);
+    plan(dry, true);
+    tc_ws_reserve(ctx, dry.off);
+    Arena A(ctx->ws);
+    plan(A, false);
+    tc_d2h(ctx, idx, d_idx, N * sizeof(u16));
+    tc_sync_check(ctx);
+}
+
+
+template <class Acc, class SymT>
+static void rle_host(tc_ctx *ctx, const void *src, size_t src_bytes, u64 N, i64 primary,
+                     u32 *counts, SymT *syms, u64 *nruns) {
+    const u64 cap = *nruns;
+    u8 *d_src = nullptr;
+    u32 *d_counts = nullptr;
+    SymT *d_syms = nullptr;
+    u64 total = 0;
+    auto plan = [&](Arena &A, bool dry) {
+        d_src = A.get<u8>(src_bytes + 16);
+        d_counts = A.get<u32>(cap + 1);
+        d_syms = A.get<SymT>(cap + 1);
+        if (!dry) tc_h2d(ctx, d_src, src, src_bytes);
+        Acc acc = make_acc<Acc>(d_src, primary);
+        rle_encode_device<Acc, SymT>(ctx, A, acc, N, d_counts, d_syms, cap, &total, dry);
+    };
+    Arena dry(nullptr);
+    plan(dry, true);
+    tc_ws_reserve(ctx, dry.off);
+    Arena A(ctx->ws);
+    plan(A, false);
+    *nruns = total;
+    if (total > cap) TC_FAIL(ctx, TC_ERR_CAPACITY, "need %llu run slots, have %llu",
+                             (unsigned long long)total, (unsigned long long)cap);
+    tc_d2h(ctx, counts, d_counts, total * sizeof(u32));
+    tc_d2h(ctx, syms, d_syms, total * sizeof(SymT));
+    tc_sync_check(ctx);
+}
+
+
+__global__ __launch_bounds__(256) void generate_kernel(int kind, u64 seed, u64 n, u8 *out) {
+    for (u64 i = (u64)blockIdx.x * 256 + threadIdx.x; i < n; i += (u64)gridDim.x * 256) {
+        u64 z = seed + (i + 1) * 0x9E3779B97F4A7C15ull;
+        z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+        z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+        z = z ^ (z >> 31);
+        u32 hi = (u32)(z >> 32);
+        if (kind == 0) {
+            u32 k = (u32)(((u64)hi * 5) >> 32);
+            out[i] = (u8)(0x4E54474341ull >> (8 * k));  // "ACGTN"
+        } else {
+            out[i] = (u8)(0x20 + (u32)(((u64)hi * 95) >> 32));
+        }
+    }
+}
+
+
+extern "C" {
+
+const char *tc_version(void) { return "textcomp-amd 0.1 (gfx950)"; }
+
+int tc_ctx_create(int device, tc_ctx **out) {
+    if (!out) return TC_ERR_ARG;
+    *out = nullptr;
+    int count = 0;
+    if (hipGetDeviceCount(&count) != hipSuccess || count <= 0) {
+        (void)hipGetLastError();
+        return TC_ERR_HIP;  // no CPU fallback, by design
+    }
+    if (device < 0 || device >= count) return TC_ERR_ARG;
+    tc_ctx *ctx = new tc_ctx();
+    ctx->device = device;
+    try {
+        TC_HIP(ctx, hipSetDevice(device));
+        TC_HIP(ctx, hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking));
+        TC_HIP(ctx, hipMalloc((void **)&ctx->d_err, 256));
+        TC_HIP(ctx, hipMalloc((void **)&ctx->d_scalars, 64 * sizeof(u64)));
+        TC_HIP(ctx, hipHostMalloc((void **)&ctx->h_scalars, 64 * sizeof(u64), hipHostMallocDefault));
+        TC_HIP(ctx, hipMemsetAsync(ctx->d_err, 0, 256, ctx->stream));
+        TC_HIP(ctx, hipMemsetAsync(ctx->d_scalars, 0, 64 * sizeof(u64), ctx->stream));
+        for (int i = 0; i < 8; i++) TC_HIP(ctx, hipEventCreate(&ctx->ev[i]));
+        TC_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    } catch (const TcFail &f) {
+        int code = f.code;
+        tc_ctx_destroy(ctx);
+        return code;
+    }
+    *out = ctx;
+    return TC_OK;
+}
+
+void tc_ctx_destroy(tc_ctx *ctx) {
+    if (!ctx) return;
+    (void)hipSetDevice(ctx->device);
+    if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
+    for (int i = 0; i < 8; i++)
+        if (ctx->ev[i]) (void)hipEventDestroy(ctx->ev[i]);
+    if (ctx->ws) (void)hipFree(ctx->ws);
+    if (ctx->d_err) (void)hipFree(ctx->d_err);
+    if (ctx->d_scalars) (void)hipFree(ctx->d_scalars);
+    if (ctx->h_scalars) (void)hipHostFree(ctx->h_scalars);
+    if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
+    delete ctx;
+}
+
+const char *tc_last_error(const tc_ctx *ctx) { return ctx ? ctx->err.c_str() : "null ctx"; }
+
+int tc_get_stats(const tc_ctx *ctx, tc_stats *out) {
+    if (!ctx || !out) return TC_ERR_ARG;
+    *out = ctx->stats;
+    return TC_OK;
+}
+
+void *tc_ctx_stream(const tc_ctx *ctx) { return ctx ? (void *)ctx->stream : nullptr; }
+
+// ================================================================= Data.BWT
+int tc_bwt_encode_dev(tc_ctx *ctx, const uint8_t *d_text, uint64_t n, uint8_t *d_L,
+                      uint64_t *primary) {
+    TC_API_BEGIN(ctx)
+    if (n > TC_MAX_N || !primary) TC_FAIL(ctx, TC_ERR_ARG, "bad argument");
+    if (n == 0) { *primary = 0; return TC_OK; }  // BWT.hs:58
+    if (!d_text || !d_L) TC_FAIL(ctx, TC_ERR_ARG, "null buffer");
+    ctx->stats = tc_stats{};
+    ctx->stats.n = n; ctx->stats.N = n + 1;
+    Arena dry(nullptr);
+    sa_build(ctx, dry, d_text, n, nullptr, d_L, primary, nullptr, true);
+    tc_ws_reserve(ctx, dry.off);
+    Arena A(ctx->ws);
+    sa_build(ctx, A, d_text, n, nullptr, d_L, primary, nullptr, false);
+    tc_sync_check(ctx);
+    TC_API_END(ctx)
+}
+
+int tc_bwt_encode(tc_ctx *ctx, const uint8_t *text, uint64_t n, uint8_t *L, uint64_t *primary) {
+    TC_API_BEGIN(ctx)
+    if (n > TC_MAX_N || !primary) TC_FAIL(ctx, TC_ERR_ARG, "bad argument");
+    if (n == 0) { *primary = 0; return TC_OK; }
+    if (!text || !L) TC_FAIL(ctx, TC_ERR_ARG, "null buffer");
+    bwt_host(ctx, text, n, L, nullptr, primary);
+    TC_API_END(ctx)
+}
+
+int tc_suffix_array(tc_ctx *ctx, const uint8_t *text, uint64_t n, uint32_t *sa) {
+    TC_API_BEGIN(ctx)
+    if (n > TC_MAX_N || !sa) TC_FAIL(ctx, TC_ERR_ARG, "bad argument");
+    if (n == 0) { sa[0] = 0; return TC_OK; }
+    if (!text) TC_FAIL(ctx, TC_ERR_ARG, "null buffer");
+    u64 primary;
+    bwt_host(ctx, text, n, nullptr, sa, &primary);
+    TC_API_END(ctx)
+}
+
+// ================================================================= Data.MTF
+int tc_mtf_encode(tc_ctx *ctx, const uint8_t *L, uint64_t N, int64_t primary, uint16_t *idx,
+                  int16_t *final_list, uint32_t *sigma) {
+    TC_API_BEGIN(ctx)
+    if (!sigma || N > TC_MAX_N + 1) TC_FAIL(ctx, TC_ERR_ARG, "bad argument");
+    if (N == 0) { *sigma = 0; return TC_OK; }  // MTF/Internal.hs:129-132
+    if (!L || !idx || !final_list || primary >= (i64)N) TC_FAIL(ctx, TC_ERR_ARG, "bad argument");
+    mtf_host<BwtAcc>(ctx, L, N, false, N, primary < 0 ? -1 : primary, idx, final_list, sigma);
+    TC_API_END(ctx)
+}
+
+int tc_mtf_encode_sym(tc_ctx *ctx, const int16_t *sym, uint64_t N, uint16_t *idx,
+                      int16_t *final_list, uint32_t *sigma) {
+    TC_API_BEGIN(ctx)
+    if (!sigma || N > TC_MAX_N + 1) TC_FAIL(ctx, TC_ERR_ARG, "bad argument");
+    if (N == 0) { *sigma = 0; return TC_OK; }
+    if (!sym || !idx || !final_list) TC_FAIL(ctx, TC_ERR_ARG, "null buffer");
+    mtf_host<SymAcc>(ctx, sym, N * sizeof(i16), true, N, -1, idx, final_list, sigma);
+    TC_API_END(ctx)
+}
+
+// ================================================================= Data.RLE
+int tc_rle_encode(tc_ctx *ctx, const uint8_t *L, uint64_t N, int64_t primary, uint32_t *counts,
+                  int16_t *syms, uint64_t *nruns) {
+    TC_API_BEGIN(ctx)
+    if (!nruns || N > TC_MAX_N + 1) TC_FAIL(ctx, TC_ERR_ARG, "bad argument");
+    if (N == 0) { *nruns = 0; return TC_OK; }  // RLE.hs:119
+    if (!L || !counts || !syms || primary >= (i64)N) TC_FAIL(ctx, TC_ERR_ARG, "bad argument");
+    rle_host<BwtAcc, i16>(ctx, L, N, N, primary < 0 ? -1 : primary, counts, syms, nruns);
+    TC_API_END(ctx)
+}
+
+int tc_rle_encode_sym(tc_ctx *ctx, const int16_t *sym, uint64_t N, uint32_t *counts,
+                      int16_t *syms, uint64_t *nruns) {
+    TC_API_BEGIN(ctx)
+    if (!nruns || N > TC_MAX_N + 1) TC_FAIL(ctx, TC_ERR_ARG, "bad argument");
+    if (N == 0) { *nruns = 0; return TC_OK; }  // RLE.hs:157
+    if (!sym || !counts || !syms) TC_FAIL(ctx, TC_ERR_ARG, "null buffer");
+    rle_host<SymAcc, i16>(ctx, sym, N * sizeof(i16), N, -1, counts, syms, nruns);
+    TC_API_END(ctx)
+}
+
+int tc_rle_encode_u16(tc_ctx *ctx, const uint16_t *vals, uint64_t N, uint32_t *counts,
+                      uint16_t *run_vals, uint64_t *nruns) {
+    TC_API_BEGIN(ctx)
+    if (!nruns || N > TC_MAX_N + 1) TC_FAIL(ctx, TC_ERR_ARG, "bad argument");
+    if (N == 0) { *nruns = 0; return TC_OK; }
+    if (!vals || !counts || !run_vals) TC_FAIL(ctx, TC_ERR_ARG, "null buffer");
+    rle_host<U16Acc, u16>(ctx, vals, N * sizeof(u16), N, -1, counts, run_vals, nruns);
+    TC_API_END(ctx)
+}
+
+// ============================================================ fused pipeline
+int tc_encode_dev(tc_ctx *ctx, const uint8_t *d_text, uint64_t n, tc_block *out) {
+    TC_API_BEGIN(ctx)
+    if (!out || n > TC_MAX_N) TC_FAIL(ctx, TC_ERR_ARG, "bad argument");
+    const u64 cap = out->nruns;
+    out->n = n; out->primary = 0; out->sigma = 0; out->nruns = 0;
+    if (n == 0) return TC_OK;  // empty in, empty out (BWT.hs:58, MTF.hs:157, RLE.hs:119)
+    if (!d_text || !out->run_count || !out->run_value) TC_FAIL(ctx, TC_ERR_ARG, "null buffer");
+    encode_device(ctx, d_text, n, out, cap);
+    TC_API_END(ctx)
+}
+
+int tc_encode(tc_ctx *ctx, const uint8_t *text, uint64_t n, tc_block *out) {
+    TC_API_BEGIN(ctx)
+    if (!out || n > TC_MAX_N) TC_FAIL(ctx, TC_ERR_ARG, "bad argument");
+    const u64 cap = out->nruns;
+    u32 *h_count = out->run_count;
+    u16 *h_value = out->run_value;
+    out->n = n; out->primary = 0; out->sigma = 0; out->nruns = 0;
+    if (n == 0) return TC_OK;
+    if (!text || !h_count || !h_value) TC_FAIL(ctx, TC_ERR_ARG, "null buffer");
+    // device staging buffers live outside the workspace (the pipeline re-carves it)
+    u8 *d_text = nullptr;
+    u32 *d_count = nullptr;
+    u16 *d_value = nullptr;
+    int rc = TC_OK;
+    try {
+        TC_HIP(ctx, hipMalloc((void **)&d_text, n + 16));
+        TC_HIP(ctx, hipMalloc((void **)&d_count, (cap + 1) * sizeof(u32)));
+        TC_HIP(ctx, hipMalloc((void **)&d_value, (cap + 1) * sizeof(u16)));
+        tc_h2d(ctx, d_text, text, n);
+        tc_block dev = *out;
+        dev.nruns = cap; dev.run_count = d_count; dev.run_value = d_value;
+        encode_device(ctx, d_text, n, &dev, cap);
+        *out = dev;
+        out->run_count = h_count; out->run_value = h_value;
+        tc_d2h(ctx, h_count, d_count, dev.nruns * sizeof(u32));
+        tc_d2h(ctx, h_value, d_value, dev.nruns * sizeof(u16));
+        TC_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    } catch (const TcFail &f) {
+        rc = f.code;
+    }
+    (void)hipStreamSynchronize(ctx->stream);
+    if (d_text) (void)hipFree(d_text);
+    if (d_count) (void)hipFree(d_count);
+    if (d_value) (void)hipFree(d_value);
+    if (rc != TC_OK) throw TcFail{rc};
+    TC_API_END(ctx)
+}
+
+// ============================================================ synthetic input
+int tc_generate_dev(tc_ctx *ctx, int kind, uint64_t seed, uint64_t n, uint8_t *d_out) {
+    TC_API_BEGIN(ctx)
+    if (kind < 0 || kind > 1) TC_FAIL(ctx, TC_ERR_ARG, "bad kind");
+    if (n == 0) return TC_OK;
+    if (!d_out) TC_FAIL(ctx, TC_ERR_ARG, "null buffer");
+    u32 grid = tc_cdiv(n, 256 * 16);
+    if (grid > 4096) grid = 4096;
+    generate_kernel<<<grid, 256, 0, ctx->stream>>>(kind, seed, n, d_out);
+    TC_LAUNCH_CHECK(ctx);
+    TC_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    TC_API_END(ctx)
+}
+
+
+// ====================================================== not yet implemented
+#define TC_STUB(ctx) do { if (!(ctx)) return TC_ERR_ARG; (ctx)->err = "not implemented yet"; return TC_ERR_INTERNAL; } while (0)
+int tc_bwt_decode(tc_ctx *ctx, const uint8_t *, uint64_t, uint64_t, uint8_t *) { TC_STUB(ctx); }
+int tc_bwt_decode_sym(tc_ctx *ctx, const int16_t *, uint64_t, uint8_t *, uint64_t *) { TC_STUB(ctx); }
+int tc_mtf_decode(tc_ctx *ctx, const uint16_t *, uint64_t, const int16_t *, uint32_t, int16_t *) { TC_STUB(ctx); }
+int tc_rle_decode(tc_ctx *ctx, const uint32_t *, const int16_t *, uint64_t, int16_t *, uint64_t *) { TC_STUB(ctx); }
+int tc_rle_decode_u16(tc_ctx *ctx, const uint32_t *, const uint16_t *, uint64_t, uint16_t *, uint64_t *) { TC_STUB(ctx); }
+int tc_decode(tc_ctx *ctx, const tc_block *, uint8_t *) { TC_STUB(ctx); }
+int tc_decode_dev(tc_ctx *ctx, const tc_block *, uint8_t *) { TC_STUB(ctx); }
+int tc_fm_build(tc_ctx *ctx, const uint8_t *, uint64_t, tc_fm **) { TC_STUB(ctx); }
+void tc_fm_free(tc_fm *) {}
+int tc_fm_count(tc_ctx *ctx, const tc_fm *, const uint8_t *, const uint64_t *, uint64_t, int64_t *) { TC_STUB(ctx); }
+int tc_fm_count_dev(tc_ctx *ctx, const tc_fm *, const uint8_t *, const uint64_t *, uint64_t, int64_t *) { TC_STUB(ctx); }
+int tc_fm_locate(tc_ctx *ctx, const tc_fm *, const uint8_t *, const uint64_t *, uint64_t, uint64_t *, uint64_t *, uint64_t *) { TC_STUB(ctx); }
+int tc_fm_info(const tc_fm *, uint64_t *, uint32_t *, int16_t *, uint64_t *, uint64_t *) { return TC_ERR_INTERNAL; }
+
+}  // extern "C"

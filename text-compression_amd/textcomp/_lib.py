@@ -1,0 +1,97 @@
+"""ctypes binding of libtextcomp.so (include/textcomp.h).  No CPU fallback: if the
+HIP library is missing or no MI355X is usable, calls raise."""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(os.path.dirname(_HERE), "libtextcomp.so")
+
+TC_OK = 0
+TC_ERR_ARG, TC_ERR_CAPACITY, TC_ERR_MALFORMED, TC_ERR_HIP, TC_ERR_OOM, TC_ERR_INTERNAL = (
+    -1, -2, -3, -4, -5, -6)
+TC_MAX_SIGMA = 257
+TC_MAX_ROUNDS = 40
+
+ERR_NAMES = {-1: "TC_ERR_ARG", -2: "TC_ERR_CAPACITY", -3: "TC_ERR_MALFORMED", -4: "TC_ERR_HIP",
+             -5: "TC_ERR_OOM", -6: "TC_ERR_INTERNAL"}
+
+
+class TcError(RuntimeError):
+    def __init__(self, code, msg=""):
+        super().__init__("%s (%d): %s" % (ERR_NAMES.get(code, "?"), code, msg))
+        self.code = code
+
+
+class TcMalformed(TcError):
+    """Input on which the reference itself throws (fromJust / DS.index / read)."""
+
+
+class Stats(C.Structure):
+    _fields_ = [("n", C.c_uint64), ("N", C.c_uint64), ("sigma", C.c_uint32), ("rounds", C.c_uint32),
+                ("m", C.c_uint64 * TC_MAX_ROUNDS), ("key_bytes", C.c_uint32 * TC_MAX_ROUNDS),
+                ("passes", C.c_uint32 * TC_MAX_ROUNDS), ("h", C.c_uint32 * TC_MAX_ROUNDS),
+                ("runs", C.c_uint64), ("ms_sa", C.c_float), ("ms_bwt", C.c_float),
+                ("ms_mtf", C.c_float), ("ms_rle", C.c_float), ("ms_total", C.c_float)]
+
+
+class Block(C.Structure):
+    _fields_ = [("n", C.c_uint64), ("primary", C.c_uint64), ("sigma", C.c_uint32),
+                ("final_list", C.c_int16 * TC_MAX_SIGMA), ("nruns", C.c_uint64),
+                ("run_count", C.c_void_p), ("run_value", C.c_void_p)]
+
+
+# every symbol include/textcomp.h declares: (name, restype, argtypes)
+_P, _U64, _I64, _U32, _INT = C.c_void_p, C.c_uint64, C.c_int64, C.c_uint32, C.c_int
+_PU64 = C.POINTER(C.c_uint64)
+_PU32 = C.POINTER(C.c_uint32)
+SYMBOLS = [
+    ("tc_ctx_create", _INT, [_INT, C.POINTER(_P)]),
+    ("tc_ctx_destroy", None, [_P]),
+    ("tc_last_error", C.c_char_p, [_P]),
+    ("tc_version", C.c_char_p, []),
+    ("tc_get_stats", _INT, [_P, C.POINTER(Stats)]),
+    ("tc_ctx_stream", _P, [_P]),
+    ("tc_bwt_encode", _INT, [_P, _P, _U64, _P, _PU64]),
+    ("tc_bwt_encode_dev", _INT, [_P, _P, _U64, _P, _PU64]),
+    ("tc_suffix_array", _INT, [_P, _P, _U64, _P]),
+    ("tc_bwt_decode", _INT, [_P, _P, _U64, _U64, _P]),
+    ("tc_bwt_decode_sym", _INT, [_P, _P, _U64, _P, _PU64]),
+    ("tc_mtf_encode", _INT, [_P, _P, _U64, _I64, _P, _P, _PU32]),
+    ("tc_mtf_encode_sym", _INT, [_P, _P, _U64, _P, _P, _PU32]),
+    ("tc_mtf_decode", _INT, [_P, _P, _U64, _P, _U32, _P]),
+    ("tc_rle_encode", _INT, [_P, _P, _U64, _I64, _P, _P, _PU64]),
+    ("tc_rle_encode_sym", _INT, [_P, _P, _U64, _P, _P, _PU64]),
+    ("tc_rle_encode_u16", _INT, [_P, _P, _U64, _P, _P, _PU64]),
+    ("tc_rle_decode", _INT, [_P, _P, _P, _U64, _P, _PU64]),
+    ("tc_rle_decode_u16", _INT, [_P, _P, _P, _U64, _P, _PU64]),
+    ("tc_encode", _INT, [_P, _P, _U64, C.POINTER(Block)]),
+    ("tc_encode_dev", _INT, [_P, _P, _U64, C.POINTER(Block)]),
+    ("tc_decode", _INT, [_P, C.POINTER(Block), _P]),
+    ("tc_decode_dev", _INT, [_P, C.POINTER(Block), _P]),
+    ("tc_fm_build", _INT, [_P, _P, _U64, C.POINTER(_P)]),
+    ("tc_fm_free", None, [_P]),
+    ("tc_fm_count", _INT, [_P, _P, _P, _P, _U64, _P]),
+    ("tc_fm_count_dev", _INT, [_P, _P, _P, _P, _U64, _P]),
+    ("tc_fm_locate", _INT, [_P, _P, _P, _P, _U64, _P, _P, _PU64]),
+    ("tc_fm_info", _INT, [_P, _PU64, _PU32, _P, _P, _PU64]),
+    ("tc_generate_dev", _INT, [_P, _INT, _U64, _U64, _P]),
+]
+
+_LIB = None
+
+
+def load():
+    """dlopen libtextcomp.so and type every entry point; raises if it is missing."""
+    global _LIB
+    if _LIB is None:
+        if not os.path.exists(LIB_PATH):
+            raise ImportError(
+                "libtextcomp.so not built (%s): run __graft_entry__.build() or `make -C "
+                "text-compression_amd`; there is no CPU fallback" % LIB_PATH)
+        lib = C.CDLL(LIB_PATH)
+        for name, res, args in SYMBOLS:
+            fn = getattr(lib, name)  # AttributeError if the .so lacks a declared symbol
+            fn.restype = res
+            fn.argtypes = args
+        _LIB = lib
+    return _LIB
