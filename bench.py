@@ -1,0 +1,190 @@
+#!/usr/bin/env python3
+"""bench.py -- BWT+MTF+RLE encode throughput on synthetic ACGTN records.
+
+  python bench.py --gpus N --steps K --warmup W        (N > 1: launched by torchrun)
+
+A "step" = one fused BWT -> MTF -> RLE encode (tc_encode_dev) of this rank's record,
+input and output resident in HBM; with N > 1 each rank owns one independent record
+(seed 0xC500 + rank) and the step ends with the gather of the
+encoded blocks on rank 0 over RCCL.  Rank 0 prints ONE JSON line.
+
+PyTorch here is plumbing only: device buffers, torch.distributed (nccl = RCCL),
+barriers.  The compute is libtextcomp.so through its C ABI.
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.join(ROOT, "text-compression_amd"))
+
+GIB = 1 << 30
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--n", type=int, default=GIB, help="record size in bytes (default 1 GiB = BASELINE configs[2])")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-sample", type=int, default=32 << 20, help="bytes of the workload timed on the CPU port")
+    return ap.parse_args()
+
+
+def algorithmic_bytes(st, n):
+    """A = A_sa + A_bwt + A_mtf + A_rle from the counters the library reports."""
+    N = n + 1
+    a_sa = n
+    for r in range(st.rounds):
+        m, k, P = int(st.m[r]), int(st.key_bytes[r]), int(st.passes[r])
+        a_sa += m * ((k + 4) * 2 * P + k) + m * (k + 12) + m * (k + 8)
+    return a_sa + 6 * N + 2 * N + N + 5 * int(st.runs)
+
+
+def cpu_baseline(n_sample, seed):
+    """The CPU restatement (oracle/, kind "port", 1 thread) on a bounded sample of the workload."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import oracle as O
+    t = O.gen_acgtn(seed, n_sample)
+    t0 = time.perf_counter()
+    L = O.bwt_encode_arr(t)
+    idx, _ = O.mtf_encode_arr(L)
+    O.rle_encode_u32_arr(idx)
+    dt = time.perf_counter() - t0
+    return {"value": round(n_sample / dt / 1e6, 3), "unit": "MB/s", "cores": 1, "kind": "port",
+            "sample": "first %d MiB of the rank-0 record, BWT+MTF+RLE encode by oracle/tc_oracle.c, %.1f s"
+                      % (n_sample >> 20, dt)}
+
+
+def main():
+    a = parse()
+    import torch
+    import torch.distributed as dist
+    import textcomp
+    from textcomp import Block
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != a.gpus:
+        if world == 1 and a.gpus > 1:
+            sys.exit("bench.py --gpus %d must be launched with torch.distributed.run (one rank per GPU)" % a.gpus)
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=dev)
+
+    n = a.n
+    cap = n + 2
+    ctx = textcomp.Context(local)
+    lib = ctx.lib
+    lib.tc_ctx_set_profile(ctx.handle, 1)
+    d_text = torch.empty(n, dtype=torch.uint8, device=dev)
+    d_cnt = torch.empty(cap, dtype=torch.int32, device=dev)
+    d_val = torch.empty(cap, dtype=torch.int16, device=dev)
+    seed = 0xC3 if world == 1 else 0xC500 + rank
+    rc = lib.tc_generate_dev(ctx.handle, 0, seed, n, C.c_void_p(d_text.data_ptr()))
+    assert rc == 0, rc
+    torch.cuda.synchronize()
+
+    # gather buffers on rank 0 (one slot per peer), sized after the first step
+    recv_cnt = recv_val = None
+    blk = Block()
+
+    def step():
+        nonlocal recv_cnt, recv_val
+        blk.nruns = cap
+        blk.run_count = d_cnt.data_ptr()
+        blk.run_value = d_val.data_ptr()
+        rc = lib.tc_encode_dev(ctx.handle, C.c_void_p(d_text.data_ptr()), n, C.byref(blk))
+        if rc != 0:
+            raise RuntimeError("tc_encode_dev rc=%d: %s" % (rc, lib.tc_last_error(ctx.handle).decode()))
+        if world > 1:
+            # header all-gather (tiny), then the run arrays to rank 0: 7 concurrent
+            # receives spread over rank 0's point-to-point xGMI links.
+            hdr = torch.tensor([int(blk.nruns), int(blk.primary), int(blk.sigma), n], dtype=torch.int64, device=dev)
+            hdrs = torch.empty(world * 4, dtype=torch.int64, device=dev)
+            dist.all_gather_into_tensor(hdrs, hdr)
+            k = int(blk.nruns)
+            if rank == 0:
+                sizes = hdrs.view(world, 4)[:, 0].tolist()
+                if recv_cnt is None:
+                    recv_cnt = [None] + [torch.empty(cap, dtype=torch.int32, device=dev) for _ in range(1, world)]
+                    recv_val = [None] + [torch.empty(cap, dtype=torch.int16, device=dev) for _ in range(1, world)]
+                ops = []
+                for r in range(1, world):
+                    ops.append(dist.P2POp(dist.irecv, recv_cnt[r][:sizes[r]], r))
+                    ops.append(dist.P2POp(dist.irecv, recv_val[r][:sizes[r]], r))
+            else:
+                ops = [dist.P2POp(dist.isend, d_cnt[:k], 0), dist.P2POp(dist.isend, d_val[:k], 0)]
+            for w in dist.batch_isend_irecv(ops):
+                w.wait()
+
+    def fence():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(a.warmup):
+        step()
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        step()
+    fence()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+
+    if rank == 0:
+        st = ctx.stats()
+        total_bytes = n * world * a.steps
+        value = total_bytes / dt / 1e6
+        A = algorithmic_bytes(st, n)
+        launches = int(st.radix_launches)
+        roof = None
+        if launches:
+            avg_ms = st.ms_radix / launches
+            per_launch = 24 * (n + 1)  # (k+4)*2 bytes per suffix per pass, k = 8 (SURVEY 8d sort term)
+            ach = per_launch / (avg_ms * 1e-3) / 1e9
+            roof = {"bound": "hbm", "kernel": "radix_pass_kernel", "achieved": round(ach, 1), "peak": 8000.0,
+                    "unit": "GB/s", "frac": round(ach / 8000.0, 4), "traffic": None,
+                    "launches_per_step": launches, "avg_launch_ms": round(avg_ms, 4),
+                    "algorithmic_bytes_per_launch": per_launch,
+                    "pipeline_algorithmic_bytes": A, "pipeline_bytes_per_input_byte": round(A / n, 1),
+                    "pipeline_achieved_GBps": round(A / (dt / a.steps) / 1e9, 1)}
+            pj = os.path.join(ROOT, "profiles", "traffic_latest.json")
+            if os.path.exists(pj):
+                try:
+                    roof["traffic"] = json.load(open(pj)).get("radix_pass_kernel_bytes_per_launch")
+                except Exception:
+                    pass
+        out = {
+            "metric": "BWT+MTF+RLE encode MB/s on 1 GiB ACGTN", "value": round(value, 1), "unit": "MB/s",
+            "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(dt / a.steps * 1e3, 3),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u8",
+            "data": "synthetic",
+            "config": {"workload": "%d x %d-byte iid ACGTN record(s) (splitmix64 counter generator), fused BWT->MTF->RLE encode, "
+                                   "in/out resident in HBM%s" % (world, n, ", + RCCL gather of encoded blocks to rank 0" if world > 1 else ""),
+                       "record_bytes": n, "records": world, "parallelism": "record-per-gpu x%d" % world},
+            "roofline": roof,
+            "stages_ms": {"suffix_sort+bwt": round(st.ms_sa, 3), "mtf": round(st.ms_mtf, 3), "rle": round(st.ms_rle, 3),
+                          "rounds": int(st.rounds), "m": [int(st.m[i]) for i in range(st.rounds)],
+                          "passes": [int(st.passes[i]) for i in range(st.rounds)], "runs": int(st.runs)},
+        }
+        if not a.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(min(a.cpu_sample, n), seed)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -65,6 +65,10 @@ typedef struct tc_stats {
     uint32_t h[TC_MAX_ROUNDS];           /* symbols resolved entering round r */
     uint64_t runs;                   /* RLE runs produced */
     float ms_sa, ms_bwt, ms_mtf, ms_rle, ms_total; /* device time, HIP events */
+    /* dominant kernel (one radix-sort pass over all N suffixes), timed with HIP
+     * events on the ctx stream when tc_ctx_set_profile(ctx, 1) is on */
+    uint32_t radix_launches;         /* round-0 pass launches timed */
+    float ms_radix;                  /* their summed duration */
 } tc_stats;
 
 /* The encoded block of the fused BWT -> MTF -> RLE pipeline.  The reference has
@@ -91,6 +95,8 @@ int tc_get_stats(const tc_ctx *ctx, tc_stats *out);
 /* Stream the ctx launches on (a hipStream_t), for callers that time or order
  * work against it. */
 void *tc_ctx_stream(const tc_ctx *ctx);
+/* on != 0: bracket every round-0 radix pass with HIP events (tc_stats.ms_radix). */
+int tc_ctx_set_profile(tc_ctx *ctx, int on);
 
 /* ---- Data.BWT ------------------------------------------------------------ */
 /* bytestringToBWT (BWT.hs:68-70) = toBWT (:55-64) = createSuffixArray

@@ -31,6 +31,9 @@ struct tc_ctx {
     u64 *d_scalars = nullptr; // small device scratch for scalar results (64 words)
     u64 *h_scalars = nullptr; // pinned mirror
     hipEvent_t ev[8] = {};
+    hipEvent_t pev[2 * 16] = {};  // per-pass event pairs (profile mode)
+    int profile = 0;
+    int pev_used = 0;
     std::string err;
     tc_stats stats = {};
 };

@@ -168,7 +168,8 @@ static void sa_build(tc_ctx *ctx, Arena &A, const u8 *d_text, u64 n, u32 *d_sa, 
     else { rb.vals = b.v0; rb.vals_alt = va; }
     rb.hist = b.hist;
     rb.status = b.rstatus;
-    radix_sort_pairs(ctx, rb, (u32)N, plan, /*gen_idx=*/true, /*hist_ready=*/true);
+    ctx->pev_used = 0;
+    radix_sort_pairs(ctx, rb, (u32)N, plan, /*gen_idx=*/true, /*hist_ready=*/true, /*timed=*/true);
     u32 *sa = rb.vals;  // == va
     u64 *skeys = rb.keys;
 
@@ -229,6 +230,15 @@ static void sa_build(tc_ctx *ctx, Arena &A, const u8 *d_text, u64 n, u32 *d_sa, 
     }
     *primary = ctx->h_scalars[0];
     st.sigma = cfg.sigma_text + 1;
+    st.radix_launches = 0;
+    st.ms_radix = 0;
+    for (int i = 0; i < ctx->pev_used; i++) {  // stream is idle here (last group sync)
+        float ms = 0;
+        if (hipEventElapsedTime(&ms, ctx->pev[2 * i], ctx->pev[2 * i + 1]) == hipSuccess) {
+            st.ms_radix += ms;
+            st.radix_launches++;
+        }
+    }
 }
 
 // ------------------------------------------------------------------- accessors

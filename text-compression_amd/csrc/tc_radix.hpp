@@ -206,4 +206,4 @@ struct RadixBuffers {
 static inline size_t radix_status_words(u64 n) { return (size_t)tc_cdiv(n, RDX_TILE) * RDX_BINS + 2; }
 
 void radix_sort_pairs(tc_ctx *ctx, RadixBuffers &b, u32 n, const RadixPlan &plan, bool gen_idx,
-                      bool hist_ready);
+                      bool hist_ready, bool timed = false);

@@ -181,6 +181,7 @@ int tc_ctx_create(int device, tc_ctx **out) {
         TC_HIP(ctx, hipMemsetAsync(ctx->d_err, 0, 256, ctx->stream));
         TC_HIP(ctx, hipMemsetAsync(ctx->d_scalars, 0, 64 * sizeof(u64), ctx->stream));
         for (int i = 0; i < 8; i++) TC_HIP(ctx, hipEventCreate(&ctx->ev[i]));
+        for (int i = 0; i < 32; i++) TC_HIP(ctx, hipEventCreate(&ctx->pev[i]));
         TC_HIP(ctx, hipStreamSynchronize(ctx->stream));
     } catch (const TcFail &f) {
         int code = f.code;
@@ -197,6 +198,8 @@ void tc_ctx_destroy(tc_ctx *ctx) {
     if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
     for (int i = 0; i < 8; i++)
         if (ctx->ev[i]) (void)hipEventDestroy(ctx->ev[i]);
+    for (int i = 0; i < 32; i++)
+        if (ctx->pev[i]) (void)hipEventDestroy(ctx->pev[i]);
     if (ctx->ws) (void)hipFree(ctx->ws);
     if (ctx->d_err) (void)hipFree(ctx->d_err);
     if (ctx->d_scalars) (void)hipFree(ctx->d_scalars);
@@ -214,6 +217,12 @@ int tc_get_stats(const tc_ctx *ctx, tc_stats *out) {
 }
 
 void *tc_ctx_stream(const tc_ctx *ctx) { return ctx ? (void *)ctx->stream : nullptr; }
+
+int tc_ctx_set_profile(tc_ctx *ctx, int on) {
+    if (!ctx) return TC_ERR_ARG;
+    ctx->profile = on ? 1 : 0;
+    return TC_OK;
+}
 
 // ================================================================= Data.BWT
 int tc_bwt_encode_dev(tc_ctx *ctx, const uint8_t *d_text, uint64_t n, uint8_t *d_L,

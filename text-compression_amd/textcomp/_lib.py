@@ -31,7 +31,8 @@ class Stats(C.Structure):
                 ("m", C.c_uint64 * TC_MAX_ROUNDS), ("key_bytes", C.c_uint32 * TC_MAX_ROUNDS),
                 ("passes", C.c_uint32 * TC_MAX_ROUNDS), ("h", C.c_uint32 * TC_MAX_ROUNDS),
                 ("runs", C.c_uint64), ("ms_sa", C.c_float), ("ms_bwt", C.c_float),
-                ("ms_mtf", C.c_float), ("ms_rle", C.c_float), ("ms_total", C.c_float)]
+                ("ms_mtf", C.c_float), ("ms_rle", C.c_float), ("ms_total", C.c_float),
+                ("radix_launches", C.c_uint32), ("ms_radix", C.c_float)]
 
 
 class Block(C.Structure):
@@ -51,6 +52,7 @@ SYMBOLS = [
     ("tc_version", C.c_char_p, []),
     ("tc_get_stats", _INT, [_P, C.POINTER(Stats)]),
     ("tc_ctx_stream", _P, [_P]),
+    ("tc_ctx_set_profile", _INT, [_P, _INT]),
     ("tc_bwt_encode", _INT, [_P, _P, _U64, _P, _PU64]),
     ("tc_bwt_encode_dev", _INT, [_P, _P, _U64, _P, _PU64]),
     ("tc_suffix_array", _INT, [_P, _P, _U64, _P]),
