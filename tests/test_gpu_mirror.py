@@ -1,0 +1,57 @@
+"""The reference's own HUnit cases (RLE.hs:313-320, MTF.hs:287-299), run through the
+host-side mirror of Data.BWT / Data.MTF / Data.RLE on the HIP library -- written to
+read like the reference's tests -- plus mirror-vs-oracle checks on the reference's
+value shapes."""
+import numpy as np
+import pytest
+
+import oracle as O
+
+pytestmark = pytest.mark.gpu
+
+
+def _b(g):
+    return [None if e is None else e.encode() for e in g]
+
+
+def test_hunit_rle(golden):
+    from textcomp import rle
+    for v in golden["rle"]:
+        assert rle.textToBWTToRLEB(v["text"]) == _b(v["rle"])          # "test 1", "test 2"
+        assert rle.textFromBWTFromRLEB(_b(v["rle"])) == v["text"]      # "test 3", "test 4"
+
+
+def test_hunit_mtf(golden):
+    from textcomp import mtf
+    v = golden["mtf"][0]
+    assert mtf.textToBWTToMTFB(v["text"]) == (v["indices"], _b(v["final_list"]))   # "test 1"
+    assert mtf.textFromBWTFromMTFB((v["indices"], _b(v["final_list"]))) == v["text"]  # "test 2"
+
+
+def test_mirror_matches_oracle_shapes():
+    from textcomp import bwt, mtf, rle
+    rng = np.random.default_rng(2)
+    for t in [b"", b"a", b"ba", b"abracadabra", bytes(rng.integers(0, 256, 700, dtype=np.uint8))]:
+        B = bwt.bytestringToBWT(t)
+        assert B == O.bytestringToBWT(t)
+        assert bwt.bytestringFromWord8BWT(B) == t
+        assert mtf.bytestringBWTToMTFB(B) == O.bytestringBWTToMTFB(B)
+        assert mtf.bytestringToBWTToMTFB(t) == O.bytestringToBWTToMTFB(t)
+        assert mtf.bytestringBWTFromMTFB(mtf.bytestringBWTToMTFB(B)) == B
+        assert mtf.bytestringFromBWTFromMTFB(mtf.bytestringToBWTToMTFB(t)) == t
+        R = rle.bytestringBWTToRLEB(B)
+        assert R == O.bytestringBWTToRLEB(B) == rle.bytestringToBWTToRLEB(t)
+        assert rle.bytestringBWTFromRLEB(R) == O.bytestringBWTFromRLEB(R)
+        assert rle.bytestringFromBWTFromRLEB(R) == O.bytestringFromBWTFromRLEB(R)   # incl. Q6 for "a", "ba"
+
+
+def test_mirror_error_behaviour():
+    import textcomp
+    from textcomp import mtf, rle
+    with pytest.raises(textcomp.TcMalformed):
+        rle.bytestringBWTFromRLEB([b"x", b"a"])            # Prelude.read: no parse
+    with pytest.raises(textcomp.TcMalformed):
+        rle.bytestringBWTFromRLEB([None, b"a"])            # fromJust Nothing
+    assert rle.bytestringBWTFromRLEB([b"2", b"a", b"9"]) == [97, 97]   # odd tail ignored
+    with pytest.raises(textcomp.TcMalformed):
+        mtf.bytestringBWTFromMTFB(([5], [b"a", None]))     # DS.index out of range

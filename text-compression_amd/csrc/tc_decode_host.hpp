@@ -1,3 +1,284 @@
-// tc_decode_host.hpp -- decode path (inverse RLE / MTF / BWT).
+// tc_decode_host.hpp -- decode path: inverse RLE, inverse MTF, inverse BWT.
+//
+// Inverse BWT replaces fromBWT (reference BWT.hs:93-104: sort (symbol, position))
+// + magicInverseBWT (BWT/Internal.hs:163-200: an n-step dependent pointer chase
+//   f <- snd (index ys f) from the Nothing row until it returns to row e).
+// On the device:
+//   1. stable counting sort of positions by symbol (Nothing first) = one/two radix
+//      passes -> spos[d] (the `snd` column of the sorted Seq); the `fst` column is
+//      implied by the symbol boundaries C[].
+//   2. the chase becomes list ranking: every row r with r % S == 0 is a splitter;
+//      each splitter walks to the next splitter (independent walks, in parallel),
+//      the splitter chain is ranked by pointer jumping (log K rounds), then every
+//      splitter on row e's chain re-walks its segment writing text bytes at their
+//      final offsets.  Works for ANY Seq (Maybe Word8): no Nothing => empty output;
+//      a second Nothing met on the chain => TC_ERR_MALFORMED (fromJust, :195).
 #pragma once
 #include "tc_encode_host.hpp"
+
+#define IBWT_S 256  // splitter spacing (rows)
+
+#ifdef __HIPCC__
+
+template <class Acc>
+__global__ __launch_bounds__(256) void ibwt_keys_kernel(Acc acc, u32 N, Lut16 lut,
+                                                        u64 *__restrict__ keys) {
+    u32 j = blockIdx.x * 256 + threadIdx.x;
+    if (j < N) keys[j] = (u64)lut.v[acc(j) + 1];
+}
+
+struct CTable {
+    u32 c[260];  // c[code] = first sorted row of that code; c[sigma] = N
+    i16 sym[260];
+    u32 sigma;
+};
+
+__device__ __forceinline__ int ibwt_sym_of_row(const u32 *s_c, const i16 *s_sym, u32 sigma, u32 r) {
+    // largest code with c[code] <= r
+    u32 lo = 0, hi = sigma;  // invariant: c[lo] <= r < c[hi]
+    while (hi - lo > 1) {
+        u32 mid = (lo + hi) >> 1;
+        if (s_c[mid] <= r) lo = mid; else hi = mid;
+    }
+    return (int)s_sym[lo];
+}
+
+// splitter q = row q*S walks to the next splitter row
+__global__ __launch_bounds__(256) void ibwt_walk1_kernel(const u32 *__restrict__ spos, u32 N, u32 K,
+                                                         u32 *__restrict__ nxt,
+                                                         u32 *__restrict__ dist) {
+    u32 q = blockIdx.x * 256 + threadIdx.x;
+    if (q >= K) return;
+    u32 r = q * IBWT_S, steps = 0;
+    do {
+        r = spos[r];
+        steps++;
+    } while (r % IBWT_S != 0 && steps <= N);
+    nxt[q] = r / IBWT_S;
+    dist[q] = steps;
+}
+
+// keep splitter 0's real successor aside and make it the terminal of the chain
+__global__ void ibwt_terminal_kernel(u32 *nxt, u32 *dist, u64 *scalars) {
+    scalars[4] = nxt[0];
+    scalars[5] = dist[0];
+    nxt[0] = 0;
+    dist[0] = 0;
+}
+
+__global__ __launch_bounds__(256) void ibwt_jump_kernel(const u32 *__restrict__ nxt,
+                                                        const u32 *__restrict__ dist,
+                                                        u32 *__restrict__ nxt2,
+                                                        u32 *__restrict__ dist2, u32 K) {
+    u32 q = blockIdx.x * 256 + threadIdx.x;
+    if (q >= K) return;
+    u32 n = nxt[q];
+    nxt2[q] = nxt[n];
+    dist2[q] = dist[q] + dist[n];
+}
+
+// Lc = length of row e's cycle; scalars[6] = Lc
+__global__ void ibwt_len_kernel(const u32 *nxt, const u32 *dist, u64 *scalars, u32 *err) {
+    u32 n0 = (u32)scalars[4], d0 = (u32)scalars[5];
+    if (n0 != 0 && nxt[n0] != 0) atomicOr(err, 4u);  // e's chain must come back to e
+    scalars[6] = (u64)d0 + (n0 == 0 ? 0u : dist[n0]);
+}
+
+__global__ __launch_bounds__(256) void ibwt_walk2_kernel(const u32 *__restrict__ spos, u32 N, u32 K,
+                                                         const u32 *__restrict__ nxt,
+                                                         const u32 *__restrict__ dist,
+                                                         const u64 *__restrict__ scalars,
+                                                         CTable ct, u8 *__restrict__ text,
+                                                         u32 *err) {
+    __shared__ u32 s_c[260];
+    __shared__ i16 s_sym[260];
+    for (int i = threadIdx.x; i < 260; i += 256) {
+        s_c[i] = ct.c[i];
+        s_sym[i] = ct.sym[i];
+    }
+    __syncthreads();
+    u32 q = blockIdx.x * 256 + threadIdx.x;
+    if (q >= K) return;
+    if (q != 0 && nxt[q] != 0) return;  // not on row e's chain
+    const u32 Lc = (u32)scalars[6];
+    u32 p = (q == 0) ? 0u : Lc - dist[q];
+    u32 r = q * IBWT_S, steps = 0;
+    while (steps++ <= N) {
+        r = spos[r];
+        if (r == 0) break;
+        int sym = ibwt_sym_of_row(s_c, s_sym, ct.sigma, r);
+        if (sym < 0) {
+            atomicOr(err, 0x200u);  // fromJust Nothing (BWT/Internal.hs:195)
+            break;
+        }
+        text[p++] = (u8)sym;
+        if (r % IBWT_S == 0) break;
+    }
+}
+
+#endif  // __HIPCC__
+
+// Inverse BWT of an accessor stream; d_text receives *n_out bytes (<= N).
+template <class Acc>
+static void ibwt_device(tc_ctx *ctx, Arena &A, Acc acc, u64 N, const u32 *counts257, u8 *d_text,
+                        u64 *n_out, bool dry) {
+    const u32 K = tc_cdiv(N, IBWT_S);
+    u32 *d_counts = A.get<u32>(260);
+    u64 *k0 = A.get<u64>(N);
+    u64 *k1 = A.get<u64>(N);
+    u32 *v0 = A.get<u32>(N);
+    u32 *v1 = A.get<u32>(N);
+    u32 *hist = A.get<u32>(RDX_MAX_PASSES * RDX_BINS);
+    u64 *rstatus = A.get<u64>(radix_status_words(N));
+    u32 *nx[2] = {A.get<u32>(K + 1), A.get<u32>(K + 1)};
+    u32 *ds[2] = {A.get<u32>(K + 1), A.get<u32>(K + 1)};
+    if (dry) return;
+    hipStream_t s = ctx->stream;
+    u32 local[257];
+    if (!counts257) {
+        sym_hist_host<Acc>(ctx, acc, N, d_counts, local);
+        counts257 = local;
+    }
+    *n_out = 0;
+    if (counts257[0] == 0) return;  // no Nothing: magicInverseBWT returns empty (:173-174)
+    Alphabet al;
+    al.build(counts257);
+    Lut16 lut;
+    CTable ct;
+    u32 acc_c = 0;
+    for (int v = 0; v < 257; v++) lut.v[v] = al.code_of_sym[v];
+    for (u32 c = 0; c < al.sigma; c++) {
+        ct.c[c] = acc_c;
+        ct.sym[c] = al.sym_of_code[c];
+        acc_c += counts257[al.sym_of_code[c] + 1];
+    }
+    ct.c[al.sigma] = (u32)N;
+    ct.sigma = al.sigma;
+    // 1. sorted (symbol, position): spos
+    ibwt_keys_kernel<Acc><<<tc_cdiv(N, 256), 256, 0, s>>>(acc, (u32)N, lut, k0);
+    TC_LAUNCH_CHECK(ctx);
+    RadixPlan plan;
+    plan.add_range(0, ceil_log2_u64(al.sigma) > 0 ? ceil_log2_u64(al.sigma) : 1);
+    RadixBuffers rb;
+    rb.keys = k0; rb.keys_alt = k1; rb.vals = v0; rb.vals_alt = v1;
+    rb.hist = hist; rb.status = rstatus;
+    radix_sort_pairs(ctx, rb, (u32)N, plan, /*gen_idx=*/true, /*hist_ready=*/false);
+    const u32 *spos = rb.vals;
+    // 2. splitter walks, chain ranking, output walks
+    ibwt_walk1_kernel<<<tc_cdiv(K, 256), 256, 0, s>>>(spos, (u32)N, K, nx[0], ds[0]);
+    TC_LAUNCH_CHECK(ctx);
+    ibwt_terminal_kernel<<<1, 1, 0, s>>>(nx[0], ds[0], ctx->d_scalars);
+    TC_LAUNCH_CHECK(ctx);
+    int cur = 0;
+    for (int r = 0; r < ceil_log2_u64(K) + 1; r++) {
+        ibwt_jump_kernel<<<tc_cdiv(K, 256), 256, 0, s>>>(nx[cur], ds[cur], nx[cur ^ 1], ds[cur ^ 1], K);
+        TC_LAUNCH_CHECK(ctx);
+        cur ^= 1;
+    }
+    ibwt_len_kernel<<<1, 1, 0, s>>>(nx[cur], ds[cur], ctx->d_scalars, ctx->d_err);
+    TC_LAUNCH_CHECK(ctx);
+    ibwt_walk2_kernel<<<tc_cdiv(K, 256), 256, 0, s>>>(spos, (u32)N, K, nx[cur], ds[cur],
+                                                     ctx->d_scalars, ct, d_text, ctx->d_err);
+    TC_LAUNCH_CHECK(ctx);
+    tc_d2h(ctx, &ctx->h_scalars[6], ctx->d_scalars + 6, sizeof(u64));
+    TC_HIP(ctx, hipStreamSynchronize(s));
+    u64 Lc = ctx->h_scalars[6];
+    *n_out = Lc ? Lc - 1 : 0;
+}
+
+// ---- inverse MTF ---------------------------------------------------------------
+template <int ROWS>
+static void imtf_launch(tc_ctx *ctx, const u16 *d_idx, u64 N, u32 sigma, u16 *perms, u32 chunks,
+                        const SymTab &tab, i16 *d_out) {
+    hipStream_t s = ctx->stream;
+    imtf_summary_kernel<ROWS><<<chunks, 64, 0, s>>>(d_idx, N, sigma, perms, ctx->d_err);
+    TC_LAUNCH_CHECK(ctx);
+    imtf_scan_kernel<ROWS><<<1, 64, 0, s>>>(perms, chunks);
+    TC_LAUNCH_CHECK(ctx);
+    imtf_apply_kernel<ROWS><<<chunks, 64, 0, s>>>(d_idx, N, sigma, perms, tab, d_out);
+    TC_LAUNCH_CHECK(ctx);
+}
+
+// seqFromMTF: initial list = sort(unique(list)) (MTF/Internal.hs:214).
+static void mtf_decode_device(tc_ctx *ctx, Arena &A, const u16 *d_idx, u64 N, const i16 *list,
+                              u32 nlist, i16 *d_out, bool dry) {
+    const u32 chunks = tc_cdiv(N, MTFG_CH);
+    u16 *perms = A.get<u16>(((size_t)chunks + 1) * 320);
+    if (dry) return;
+    bool seen[257] = {false};
+    for (u32 i = 0; i < nlist; i++) {
+        if (list[i] < -1 || list[i] > 255) TC_FAIL(ctx, TC_ERR_ARG, "list symbol out of range");
+        seen[list[i] + 1] = true;
+    }
+    SymTab tab;
+    u32 sigma = 0;
+    for (int v = 0; v < 257; v++)
+        if (seen[v]) tab.v[sigma++] = (i16)(v - 1);
+    if (sigma <= 64) imtf_launch<1>(ctx, d_idx, N, sigma, perms, chunks, tab, d_out);
+    else if (sigma <= 128) imtf_launch<2>(ctx, d_idx, N, sigma, perms, chunks, tab, d_out);
+    else imtf_launch<5>(ctx, d_idx, N, sigma, perms, chunks, tab, d_out);
+}
+
+// ---- inverse RLE ---------------------------------------------------------------
+template <class SymT>
+static void rle_decode_device(tc_ctx *ctx, Arena &A, const u32 *d_counts, const SymT *d_syms,
+                              u64 nruns, bool has_nothing, SymT *d_out, u64 cap, u64 *N_out,
+                              bool dry) {
+    const u64 tiles = tc_cdiv(nruns, SCAN_TILE);
+    u64 *len = A.get<u64>(nruns + 1);
+    u64 *offs = A.get<u64>(nruns + 1);
+    u64 *tsum = A.get<u64>(tiles + 2);
+    if (dry) return;
+    hipStream_t s = ctx->stream;
+    rle_len_kernel<SymT><<<tc_cdiv(nruns, 256), 256, 0, s>>>(d_counts, d_syms, nruns, has_nothing, len);
+    TC_LAUNCH_CHECK(ctx);
+    scan64_reduce_kernel<<<(u32)tiles, SCAN_NT, 0, s>>>(len, nruns, tsum);
+    TC_LAUNCH_CHECK(ctx);
+    scan64_spine_kernel<<<1, 1024, 0, s>>>(tsum, tiles);
+    TC_LAUNCH_CHECK(ctx);
+    scan64_down_kernel<<<(u32)tiles, SCAN_NT, 0, s>>>(len, nruns, tsum, offs);
+    TC_LAUNCH_CHECK(ctx);
+    tc_d2h(ctx, &ctx->h_scalars[7], tsum + tiles, sizeof(u64));
+    TC_HIP(ctx, hipStreamSynchronize(s));
+    *N_out = ctx->h_scalars[7];
+    if (*N_out > cap) return;  // caller reports TC_ERR_CAPACITY
+    rle_fill_kernel<SymT><<<tc_cdiv(nruns, 256), 256, 0, s>>>(offs, d_counts, d_syms, nruns,
+                                                              has_nothing, cap, d_out);
+    TC_LAUNCH_CHECK(ctx);
+}
+
+// ---- fused decode: runs -> MTF indices -> BWT symbols -> text -------------------
+static void decode_device(tc_ctx *ctx, const tc_block *blk, u8 *d_text) {
+    const u64 n = blk->n, N = n + 1;
+    u16 *d_idx = nullptr;
+    i16 *d_sym = nullptr;
+    u64 got = 0, n_out = 0;
+    auto plan = [&](Arena &A, bool dry) {
+        d_idx = A.get<u16>(N + 64);
+        d_sym = A.get<i16>(N + 64);
+        size_t mark = A.off, hi = mark;
+        rle_decode_device<u16>(ctx, A, blk->run_count, blk->run_value, blk->nruns, false, d_idx, N,
+                               &got, dry);
+        if (!dry && got != N)
+            TC_FAIL(ctx, TC_ERR_MALFORMED, "runs expand to %llu symbols, block says %llu",
+                    (unsigned long long)got, (unsigned long long)N);
+        hi = A.off > hi ? A.off : hi;
+        A.off = mark;
+        mtf_decode_device(ctx, A, d_idx, N, blk->final_list, blk->sigma, d_sym, dry);
+        hi = A.off > hi ? A.off : hi;
+        A.off = mark;
+        SymAcc acc{d_sym};
+        ibwt_device<SymAcc>(ctx, A, acc, N, nullptr, d_text, &n_out, dry);
+        hi = A.off > hi ? A.off : hi;
+        A.off = hi;
+    };
+    Arena dry(nullptr);
+    plan(dry, true);
+    tc_ws_reserve(ctx, dry.off);
+    Arena A(ctx->ws);
+    plan(A, false);
+    tc_sync_check(ctx);
+    if (n_out != n)
+        TC_FAIL(ctx, TC_ERR_MALFORMED, "block decodes to %llu bytes, header says %llu",
+                (unsigned long long)n_out, (unsigned long long)n);
+}

@@ -157,6 +157,59 @@ __global__ __launch_bounds__(256) void generate_kernel(int kind, u64 seed, u64 n
 }
 
 
+// ------------------------------------------------------------ decode helpers
+template <class Acc>
+static void ibwt_host(tc_ctx *ctx, const void *src, size_t src_bytes, u64 N, i64 primary, u8 *text,
+                      u64 *n_out) {
+    u8 *d_src = nullptr, *d_text = nullptr;
+    auto plan = [&](Arena &A, bool dry) {
+        d_src = A.get<u8>(src_bytes + 16);
+        d_text = A.get<u8>(N + 16);
+        if (!dry) tc_h2d(ctx, d_src, src, src_bytes);
+        Acc acc = make_acc<Acc>(d_src, primary);
+        ibwt_device<Acc>(ctx, A, acc, N, nullptr, d_text, n_out, dry);
+    };
+    Arena dry(nullptr);
+    plan(dry, true);
+    tc_ws_reserve(ctx, dry.off);
+    Arena A(ctx->ws);
+    plan(A, false);
+    tc_sync_check(ctx);
+    if (*n_out) {
+        tc_d2h(ctx, text, d_text, *n_out);
+        TC_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    }
+}
+
+template <class SymT>
+static void rle_decode_host(tc_ctx *ctx, const u32 *counts, const SymT *syms, u64 nruns,
+                            bool has_nothing, SymT *out, u64 *N) {
+    const u64 cap = *N;
+    u32 *d_counts = nullptr;
+    SymT *d_syms = nullptr, *d_out = nullptr;
+    u64 total = 0;
+    auto plan = [&](Arena &A, bool dry) {
+        d_counts = A.get<u32>(nruns + 1);
+        d_syms = A.get<SymT>(nruns + 1);
+        d_out = A.get<SymT>(cap + 1);
+        if (!dry) {
+            tc_h2d(ctx, d_counts, counts, nruns * sizeof(u32));
+            tc_h2d(ctx, d_syms, syms, nruns * sizeof(SymT));
+        }
+        rle_decode_device<SymT>(ctx, A, d_counts, d_syms, nruns, has_nothing, d_out, cap, &total, dry);
+    };
+    Arena dry(nullptr);
+    plan(dry, true);
+    tc_ws_reserve(ctx, dry.off);
+    Arena A(ctx->ws);
+    plan(A, false);
+    *N = total;
+    if (total > cap) TC_FAIL(ctx, TC_ERR_CAPACITY, "need %llu output slots, have %llu",
+                             (unsigned long long)total, (unsigned long long)cap);
+    if (total) tc_d2h(ctx, out, d_out, total * sizeof(SymT));
+    tc_sync_check(ctx);
+}
+
 extern "C" {
 
 const char *tc_version(void) { return "textcomp-amd 0.1 (gfx950)"; }
@@ -378,15 +431,118 @@ int tc_generate_dev(tc_ctx *ctx, int kind, uint64_t seed, uint64_t n, uint8_t *d
 }
 
 
+// ===================================================================== decode
+int tc_bwt_decode(tc_ctx *ctx, const uint8_t *L, uint64_t N, uint64_t primary, uint8_t *text) {
+    TC_API_BEGIN(ctx)
+    if (N > TC_MAX_N + 1) TC_FAIL(ctx, TC_ERR_ARG, "bad argument");
+    if (N == 0) return TC_OK;
+    if (!L || !text || primary >= N) TC_FAIL(ctx, TC_ERR_ARG, "bad argument");
+    u64 n_out = 0;
+    ibwt_host<BwtAcc>(ctx, L, N, N, (i64)primary, text, &n_out);
+    if (n_out != N - 1) TC_FAIL(ctx, TC_ERR_ARG, "not the BWT of any text (cycle of %llu rows)",
+                                (unsigned long long)(n_out + 1));
+    TC_API_END(ctx)
+}
+
+int tc_bwt_decode_sym(tc_ctx *ctx, const int16_t *sym, uint64_t N, uint8_t *text, uint64_t *n_out) {
+    TC_API_BEGIN(ctx)
+    if (!n_out || N > TC_MAX_N + 1) TC_FAIL(ctx, TC_ERR_ARG, "bad argument");
+    *n_out = 0;
+    if (N == 0) return TC_OK;  // BWT/Internal.hs:164-167
+    if (!sym || !text) TC_FAIL(ctx, TC_ERR_ARG, "null buffer");
+    ibwt_host<SymAcc>(ctx, sym, N * sizeof(i16), N, -1, text, n_out);
+    TC_API_END(ctx)
+}
+
+int tc_mtf_decode(tc_ctx *ctx, const uint16_t *idx, uint64_t N, const int16_t *list,
+                  uint32_t nlist, int16_t *sym) {
+    TC_API_BEGIN(ctx)
+    if (N > TC_MAX_N + 1 || nlist > TC_MAX_SIGMA) TC_FAIL(ctx, TC_ERR_ARG, "bad argument");
+    if (N == 0 || nlist == 0) return TC_OK;  // MTF/Internal.hs:202-209
+    if (!idx || !list || !sym) TC_FAIL(ctx, TC_ERR_ARG, "null buffer");
+    u16 *d_idx = nullptr;
+    i16 *d_sym = nullptr;
+    auto plan = [&](Arena &A, bool dry) {
+        d_idx = A.get<u16>(N + 64);
+        d_sym = A.get<i16>(N + 64);
+        if (!dry) tc_h2d(ctx, d_idx, idx, N * sizeof(u16));
+        mtf_decode_device(ctx, A, d_idx, N, list, nlist, d_sym, dry);
+    };
+    Arena dry(nullptr);
+    plan(dry, true);
+    tc_ws_reserve(ctx, dry.off);
+    Arena A(ctx->ws);
+    plan(A, false);
+    tc_d2h(ctx, sym, d_sym, N * sizeof(i16));
+    tc_sync_check(ctx);
+    TC_API_END(ctx)
+}
+
+int tc_rle_decode(tc_ctx *ctx, const uint32_t *counts, const int16_t *syms, uint64_t nruns,
+                  int16_t *sym_out, uint64_t *N) {
+    TC_API_BEGIN(ctx)
+    if (!N) TC_FAIL(ctx, TC_ERR_ARG, "bad argument");
+    if (nruns == 0) { *N = 0; return TC_OK; }  // RLE/Internal.hs:156-159
+    if (!counts || !syms || (!sym_out && *N)) TC_FAIL(ctx, TC_ERR_ARG, "null buffer");
+    rle_decode_host<i16>(ctx, counts, syms, nruns, true, sym_out, N);
+    TC_API_END(ctx)
+}
+
+int tc_rle_decode_u16(tc_ctx *ctx, const uint32_t *counts, const uint16_t *run_vals,
+                      uint64_t nruns, uint16_t *vals_out, uint64_t *N) {
+    TC_API_BEGIN(ctx)
+    if (!N) TC_FAIL(ctx, TC_ERR_ARG, "bad argument");
+    if (nruns == 0) { *N = 0; return TC_OK; }
+    if (!counts || !run_vals || (!vals_out && *N)) TC_FAIL(ctx, TC_ERR_ARG, "null buffer");
+    rle_decode_host<u16>(ctx, counts, run_vals, nruns, false, vals_out, N);
+    TC_API_END(ctx)
+}
+
+int tc_decode_dev(tc_ctx *ctx, const tc_block *blk, uint8_t *d_text) {
+    TC_API_BEGIN(ctx)
+    if (!blk || blk->n > TC_MAX_N || blk->sigma > TC_MAX_SIGMA) TC_FAIL(ctx, TC_ERR_ARG, "bad argument");
+    if (blk->n == 0) return TC_OK;
+    if (!d_text || !blk->run_count || !blk->run_value || blk->nruns == 0)
+        TC_FAIL(ctx, TC_ERR_ARG, "bad block");
+    decode_device(ctx, blk, d_text);
+    TC_API_END(ctx)
+}
+
+int tc_decode(tc_ctx *ctx, const tc_block *blk, uint8_t *text) {
+    TC_API_BEGIN(ctx)
+    if (!blk || blk->n > TC_MAX_N || blk->sigma > TC_MAX_SIGMA) TC_FAIL(ctx, TC_ERR_ARG, "bad argument");
+    if (blk->n == 0) return TC_OK;
+    if (!text || !blk->run_count || !blk->run_value || blk->nruns == 0)
+        TC_FAIL(ctx, TC_ERR_ARG, "bad block");
+    u8 *d_text = nullptr;
+    u32 *d_count = nullptr;
+    u16 *d_value = nullptr;
+    int rc = TC_OK;
+    try {
+        TC_HIP(ctx, hipMalloc((void **)&d_text, blk->n + 16));
+        TC_HIP(ctx, hipMalloc((void **)&d_count, blk->nruns * sizeof(u32)));
+        TC_HIP(ctx, hipMalloc((void **)&d_value, blk->nruns * sizeof(u16)));
+        tc_h2d(ctx, d_count, blk->run_count, blk->nruns * sizeof(u32));
+        tc_h2d(ctx, d_value, blk->run_value, blk->nruns * sizeof(u16));
+        tc_block dev = *blk;
+        dev.run_count = d_count;
+        dev.run_value = d_value;
+        decode_device(ctx, &dev, d_text);
+        tc_d2h(ctx, text, d_text, blk->n);
+        TC_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    } catch (const TcFail &f) {
+        rc = f.code;
+    }
+    (void)hipStreamSynchronize(ctx->stream);
+    if (d_text) (void)hipFree(d_text);
+    if (d_count) (void)hipFree(d_count);
+    if (d_value) (void)hipFree(d_value);
+    if (rc != TC_OK) throw TcFail{rc};
+    TC_API_END(ctx)
+}
+
 // ====================================================== not yet implemented
 #define TC_STUB(ctx) do { if (!(ctx)) return TC_ERR_ARG; (ctx)->err = "not implemented yet"; return TC_ERR_INTERNAL; } while (0)
-int tc_bwt_decode(tc_ctx *ctx, const uint8_t *, uint64_t, uint64_t, uint8_t *) { TC_STUB(ctx); }
-int tc_bwt_decode_sym(tc_ctx *ctx, const int16_t *, uint64_t, uint8_t *, uint64_t *) { TC_STUB(ctx); }
-int tc_mtf_decode(tc_ctx *ctx, const uint16_t *, uint64_t, const int16_t *, uint32_t, int16_t *) { TC_STUB(ctx); }
-int tc_rle_decode(tc_ctx *ctx, const uint32_t *, const int16_t *, uint64_t, int16_t *, uint64_t *) { TC_STUB(ctx); }
-int tc_rle_decode_u16(tc_ctx *ctx, const uint32_t *, const uint16_t *, uint64_t, uint16_t *, uint64_t *) { TC_STUB(ctx); }
-int tc_decode(tc_ctx *ctx, const tc_block *, uint8_t *) { TC_STUB(ctx); }
-int tc_decode_dev(tc_ctx *ctx, const tc_block *, uint8_t *) { TC_STUB(ctx); }
 int tc_fm_build(tc_ctx *ctx, const uint8_t *, uint64_t, tc_fm **) { TC_STUB(ctx); }
 void tc_fm_free(tc_fm *) {}
 int tc_fm_count(tc_ctx *ctx, const tc_fm *, const uint8_t *, const uint64_t *, uint64_t, int64_t *) { TC_STUB(ctx); }
