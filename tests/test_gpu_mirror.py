@@ -42,7 +42,16 @@ def test_mirror_matches_oracle_shapes():
         R = rle.bytestringBWTToRLEB(B)
         assert R == O.bytestringBWTToRLEB(B) == rle.bytestringToBWTToRLEB(t)
         assert rle.bytestringBWTFromRLEB(R) == O.bytestringBWTFromRLEB(R)
-        assert rle.bytestringFromBWTFromRLEB(R) == O.bytestringFromBWTFromRLEB(R)   # incl. Q6 for "a", "ba"
+        # Q6 class ("a", "ba": the text is its own greatest suffix): the reference's own
+        # round trip is broken -- "ba" comes back as "a", "a" dies in fromJust -- and so is ours
+        try:
+            exp = O.bytestringFromBWTFromRLEB(R)
+        except O.OracleMalformed:
+            import textcomp
+            with pytest.raises(textcomp.TcMalformed):
+                rle.bytestringFromBWTFromRLEB(R)
+        else:
+            assert rle.bytestringFromBWTFromRLEB(R) == exp
 
 
 def test_mirror_error_behaviour():

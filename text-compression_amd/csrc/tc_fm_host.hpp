@@ -1,3 +1,254 @@
-// tc_fm_host.hpp -- FM-index build / count / locate.
+// tc_fm_host.hpp -- FM-index: build, batched count, locate.
+//
+// Replaces (reference FMIndex/Internal.hs) seqToCc :275-316 (C[c], there derived
+// from an O(n^2) rotation matrix, BWT/Internal.hs:209-241; here a byte histogram),
+// seqToOccCK :195-259 (a full sigma x N table of inclusive counts; here one rank
+// bit-vector per present byte: 64-byte lines = {u64 ones-before, 7 x u64 bits}, so
+// every Occ(c,k) lookup touches exactly one line), countFMIndex :347-438 and
+// locateFMIndex :448-542 mapped over the pattern list (FMIndex.hs:362-379,
+// 411-432, 475-497: serial or parListChunk sparks; here one lane per pattern in one
+// launch, result order = pattern order).
 #pragma once
-#include "tc_encode_host.hpp"
+#include "tc_decode_host.hpp"
+
+#define FM_LINE_BITS 448  // 7 words of payload per 64-byte line
+
+struct tc_fm {
+    int device = 0;
+    u64 n = 0, N = 0, primary = 0;
+    u32 sigma_bytes = 0;  // present byte values
+    u8 *d_L = nullptr;
+    u32 *d_sa = nullptr;
+    u64 *d_bits = nullptr;  // [sigma_bytes][lines][8]
+    u32 *d_tab = nullptr;   // [0..255] code of byte (0xFFFFFFFF absent), [256..511] C[code], [512..767] cnt[code]
+    u64 lines = 0;
+    u32 counts[256];
+    i16 sym_of_code[256];
+};
+
+#ifdef __HIPCC__
+
+// one wave per line: ballots of (symbol == c) for the line's 7 words
+__global__ __launch_bounds__(256) void fm_bits_kernel(const u8 *__restrict__ L, u64 N, u64 primary,
+                                                      const u32 *__restrict__ tab, u32 sigma,
+                                                      u64 lines, u64 *__restrict__ bits) {
+    __shared__ u32 s_code[256];
+    s_code[threadIdx.x] = tab[threadIdx.x];
+    __syncthreads();
+    const u64 line = (u64)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (line >= lines) return;
+    const u32 l = threadIdx.x & 63;
+    u32 sw[7];
+#pragma unroll
+    for (int w = 0; w < 7; w++) {
+        u64 j = line * FM_LINE_BITS + (u64)w * 64 + l;
+        sw[w] = (j < N && j != primary) ? s_code[L[j]] : 0xFFFFFFFFu;
+    }
+    for (u32 c = 0; c < sigma; c++) {
+        u64 mine = 0;
+        u32 pc = 0;
+#pragma unroll
+        for (int w = 0; w < 7; w++) {
+            u64 m = __ballot(sw[w] == c);
+            pc += (u32)__popcll(m);
+            if ((int)l == w + 1) mine = m;
+        }
+        if (l == 0) mine = pc;  // ones in this line; made cumulative by fm_scan_kernel
+        if (l < 8) bits[((u64)c * lines + line) * 8 + l] = mine;
+    }
+}
+
+// per symbol: exclusive scan of the line counts (word 0 of each line); block c
+__global__ __launch_bounds__(1024) void fm_scan_kernel(u64 *bits, u64 lines) {
+    __shared__ u64 s_part[1024];
+    u64 *b = bits + (u64)blockIdx.x * lines * 8;
+    u64 per = (lines + 1023) / 1024;
+    u64 lo = threadIdx.x * per, hi = lo + per < lines ? lo + per : lines;
+    u64 v = 0;
+    for (u64 t = lo; t < hi; t++) v += b[t * 8];
+    s_part[threadIdx.x] = v;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        u64 run = 0;
+        for (int i = 0; i < 1024; i++) {
+            u64 c = s_part[i];
+            s_part[i] = run;
+            run += c;
+        }
+    }
+    __syncthreads();
+    u64 run = s_part[threadIdx.x];
+    for (u64 t = lo; t < hi; t++) {
+        u64 c = b[t * 8];
+        b[t * 8] = run;
+        run += c;
+    }
+}
+
+// Occ(c, k): occurrences of code c in L[0 .. k)
+__device__ __forceinline__ u64 fm_occ(const u64 *__restrict__ bits, u64 lines, u32 c, u64 k) {
+    u64 line = k / FM_LINE_BITS;
+    u32 off = (u32)(k - line * FM_LINE_BITS);
+    const ulonglong2 *p = reinterpret_cast<const ulonglong2 *>(bits + ((u64)c * lines + line) * 8);
+    ulonglong2 a = p[0], b = p[1], cc = p[2], d = p[3];
+    u64 w[7] = {a.y, b.x, b.y, cc.x, cc.y, d.x, d.y};
+    u64 r = a.x;
+    u32 full = off >> 6, rem = off & 63;
+#pragma unroll
+    for (int i = 0; i < 7; i++) {
+        u64 m = ((u32)i < full) ? ~0ull : (((u32)i == full) ? ((1ull << rem) - 1ull) : 0ull);
+        r += (u64)__popcll(w[i] & m);
+    }
+    return r;
+}
+
+// countFMIndex (FMIndex/Internal.hs:347-438), one pattern per lane.
+// ranges (optional): [2p] = s, [2p+1] = e (1-based inclusive) for non-empty results.
+__global__ __launch_bounds__(256) void fm_count_kernel(const u64 *__restrict__ bits, u64 lines,
+                                                       const u32 *__restrict__ tab,
+                                                       const u8 *__restrict__ pats,
+                                                       const u64 *__restrict__ offs, u64 npat,
+                                                       i64 *__restrict__ out,
+                                                       u64 *__restrict__ ranges) {
+    __shared__ u32 s_tab[768];
+    for (int i = threadIdx.x; i < 768; i += 256) s_tab[i] = tab[i];
+    __syncthreads();
+    u64 p = (u64)blockIdx.x * 256 + threadIdx.x;
+    if (p >= npat) return;
+    const u64 beg = offs[p], end = offs[p + 1];
+    i64 s = -1, e = -1;
+    bool first = true, flag = false;
+    for (u64 q = end; q > beg; q--) {  // right to left (:375)
+        if (s > e) {                    // :387-389
+            flag = true;
+            break;
+        }
+        u32 c = s_tab[pats[q - 1]];
+        if (c == 0xFFFFFFFFu) break;    // findIndexL = Nothing: the loop just stops (:393,:421)
+        i64 C = (i64)s_tab[256 + c];
+        if (first) {                    // :391-418
+            s = C + 1;
+            e = C + (i64)s_tab[512 + c];
+            first = false;
+        } else {                        // :424-432
+            i64 ns = C + (i64)fm_occ(bits, lines, c, (u64)(s - 1)) + 1;
+            i64 ne = C + (i64)fm_occ(bits, lines, c, (u64)e);
+            s = ns;
+            e = ne;
+        }
+    }
+    i64 cnt = (first || (e - s + 1) == 0 || flag) ? 0 : (e - s + 1);  // :366-371
+    out[p] = cnt;
+    if (ranges) {
+        ranges[2 * p] = cnt ? (u64)s : 0;
+        ranges[2 * p + 1] = cnt ? (u64)e : 0;
+    }
+}
+
+__global__ __launch_bounds__(256) void fm_cnt_to_u64_kernel(const i64 *__restrict__ cnt, u64 npat,
+                                                            u64 *__restrict__ len) {
+    u64 p = (u64)blockIdx.x * 256 + threadIdx.x;
+    if (p < npat) len[p] = (u64)cnt[p];
+}
+
+// locate: hits[off[p] + t] = sa[s - 1 + t] + 1 (FMIndex.hs:496: suffixstartpos, 1-based)
+__global__ __launch_bounds__(256) void fm_locate_fill_kernel(const u64 *__restrict__ ranges,
+                                                             const u64 *__restrict__ hoffs,
+                                                             const u32 *__restrict__ sa, u64 npat,
+                                                             u64 cap, u64 *__restrict__ hits) {
+    u64 p = (u64)blockIdx.x * 256 + threadIdx.x;
+    bool in = p < npat;
+    u64 s = in ? ranges[2 * p] : 0, e = in ? ranges[2 * p + 1] : 0;
+    u64 o = in ? hoffs[p] : 0;
+    u64 len = (in && s) ? e - s + 1 : 0;
+    const u64 LONG = 32;
+    if (len && len < LONG)
+        for (u64 t = 0; t < len; t++)
+            if (o + t < cap) hits[o + t] = (u64)sa[s - 1 + t] + 1;
+    u64 longmask = __ballot(len >= LONG);
+    while (longmask) {
+        int src = __builtin_ctzll(longmask);
+        longmask &= longmask - 1;
+        u64 ls = __shfl(s, src, 64), ll = __shfl(len, src, 64), lo = __shfl(o, src, 64);
+        for (u64 t = lane_id(); t < ll; t += 64)
+            if (lo + t < cap) hits[lo + t] = (u64)sa[ls - 1 + t] + 1;
+    }
+}
+
+#endif  // __HIPCC__
+
+static void fm_release(tc_fm *fm) {
+    if (!fm) return;
+    (void)hipSetDevice(fm->device);
+    if (fm->d_L) (void)hipFree(fm->d_L);
+    if (fm->d_sa) (void)hipFree(fm->d_sa);
+    if (fm->d_bits) (void)hipFree(fm->d_bits);
+    if (fm->d_tab) (void)hipFree(fm->d_tab);
+    delete fm;
+}
+
+static tc_fm *fm_build_device(tc_ctx *ctx, const u8 *text_host, u64 n) {
+    tc_fm *fm = new tc_fm();
+    fm->device = ctx->device;
+    fm->n = n;
+    fm->N = n + 1;
+    try {
+        const u64 N = n + 1;
+        hipStream_t s = ctx->stream;
+        TC_HIP(ctx, hipMalloc((void **)&fm->d_L, N + 16));
+        TC_HIP(ctx, hipMalloc((void **)&fm->d_sa, N * sizeof(u32)));
+        TC_HIP(ctx, hipMalloc((void **)&fm->d_tab, 768 * sizeof(u32)));
+        u8 *d_text = nullptr;
+        auto plan = [&](Arena &A, bool dry) {
+            d_text = A.get<u8>(n + 16);
+            if (!dry) tc_h2d(ctx, d_text, text_host, n);
+            sa_build(ctx, A, d_text, n, fm->d_sa, fm->d_L, &fm->primary, fm->counts, dry);
+        };
+        ctx->stats = tc_stats{};
+        ctx->stats.n = n; ctx->stats.N = N;
+        Arena dry(nullptr);
+        plan(dry, true);
+        tc_ws_reserve(ctx, dry.off);
+        Arena A(ctx->ws);
+        plan(A, false);
+        // C[c] = #symbols of text.'$' smaller than c ('$' = Nothing counts once)
+        u32 tab[768];
+        u32 sig = 0, acc = 1;
+        for (int b = 0; b < 256; b++) {
+            tab[b] = 0xFFFFFFFFu;
+            if (fm->counts[b]) {
+                tab[b] = sig;
+                tab[256 + sig] = acc;
+                tab[512 + sig] = fm->counts[b];
+                fm->sym_of_code[sig] = (i16)b;
+                acc += fm->counts[b];
+                sig++;
+            }
+        }
+        for (u32 c = sig; c < 256; c++) tab[256 + c] = tab[512 + c] = 0;
+        fm->sigma_bytes = sig;
+        fm->lines = N / FM_LINE_BITS + 1;
+        TC_HIP(ctx, hipMalloc((void **)&fm->d_bits, (size_t)sig * fm->lines * 64));
+        tc_h2d(ctx, fm->d_tab, tab, sizeof tab);
+        TC_HIP(ctx, hipStreamSynchronize(s));  // tab is a stack buffer
+        fm_bits_kernel<<<tc_cdiv(fm->lines, 4), 256, 0, s>>>(fm->d_L, N, fm->primary, fm->d_tab, sig,
+                                                            fm->lines, fm->d_bits);
+        TC_LAUNCH_CHECK(ctx);
+        fm_scan_kernel<<<sig, 1024, 0, s>>>(fm->d_bits, fm->lines);
+        TC_LAUNCH_CHECK(ctx);
+        tc_sync_check(ctx);
+    } catch (...) {
+        fm_release(fm);
+        throw;
+    }
+    return fm;
+}
+
+// ranges (device, 2*npat u64) may be null
+static void fm_count_device(tc_ctx *ctx, const tc_fm *fm, const u8 *d_pats, const u64 *d_offs,
+                            u64 npat, i64 *d_out, u64 *d_ranges) {
+    fm_count_kernel<<<tc_cdiv(npat, 256), 256, 0, ctx->stream>>>(fm->d_bits, fm->lines, fm->d_tab,
+                                                                 d_pats, d_offs, npat, d_out,
+                                                                 d_ranges);
+    TC_LAUNCH_CHECK(ctx);
+}

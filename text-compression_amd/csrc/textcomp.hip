@@ -541,13 +541,151 @@ int tc_decode(tc_ctx *ctx, const tc_block *blk, uint8_t *text) {
     TC_API_END(ctx)
 }
 
-// ====================================================== not yet implemented
-#define TC_STUB(ctx) do { if (!(ctx)) return TC_ERR_ARG; (ctx)->err = "not implemented yet"; return TC_ERR_INTERNAL; } while (0)
-int tc_fm_build(tc_ctx *ctx, const uint8_t *, uint64_t, tc_fm **) { TC_STUB(ctx); }
-void tc_fm_free(tc_fm *) {}
-int tc_fm_count(tc_ctx *ctx, const tc_fm *, const uint8_t *, const uint64_t *, uint64_t, int64_t *) { TC_STUB(ctx); }
-int tc_fm_count_dev(tc_ctx *ctx, const tc_fm *, const uint8_t *, const uint64_t *, uint64_t, int64_t *) { TC_STUB(ctx); }
-int tc_fm_locate(tc_ctx *ctx, const tc_fm *, const uint8_t *, const uint64_t *, uint64_t, uint64_t *, uint64_t *, uint64_t *) { TC_STUB(ctx); }
-int tc_fm_info(const tc_fm *, uint64_t *, uint32_t *, int16_t *, uint64_t *, uint64_t *) { return TC_ERR_INTERNAL; }
+// =============================================================== Data.FMIndex
+int tc_fm_build(tc_ctx *ctx, const uint8_t *text, uint64_t n, tc_fm **out) {
+    TC_API_BEGIN(ctx)
+    if (!out || n > TC_MAX_N) TC_FAIL(ctx, TC_ERR_ARG, "bad argument");
+    *out = nullptr;
+    if (n == 0) {  // FMIndex.hs:366: empty input => every query returns the empty result
+        tc_fm *fm = new tc_fm();
+        fm->device = ctx->device;
+        *out = fm;
+        return TC_OK;
+    }
+    if (!text) TC_FAIL(ctx, TC_ERR_ARG, "null buffer");
+    *out = fm_build_device(ctx, text, n);
+    TC_API_END(ctx)
+}
+
+void tc_fm_free(tc_fm *fm) { fm_release(fm); }
+
+int tc_fm_count_dev(tc_ctx *ctx, const tc_fm *fm, const uint8_t *d_pats, const uint64_t *d_offs,
+                    uint64_t npat, int64_t *d_out) {
+    TC_API_BEGIN(ctx)
+    if (!fm) TC_FAIL(ctx, TC_ERR_ARG, "null index");
+    if (npat == 0) return TC_OK;
+    if (!d_pats || !d_offs || !d_out) TC_FAIL(ctx, TC_ERR_ARG, "null buffer");
+    if (fm->n == 0) {
+        tc_memset_async(ctx, d_out, 0, npat * sizeof(i64));
+    } else {
+        fm_count_device(ctx, fm, d_pats, d_offs, npat, d_out, nullptr);
+    }
+    tc_sync_check(ctx);
+    TC_API_END(ctx)
+}
+
+int tc_fm_count(tc_ctx *ctx, const tc_fm *fm, const uint8_t *pats, const uint64_t *offs,
+                uint64_t npat, int64_t *out) {
+    TC_API_BEGIN(ctx)
+    if (!fm) TC_FAIL(ctx, TC_ERR_ARG, "null index");
+    if (npat == 0) return TC_OK;
+    if (!pats || !offs || !out) TC_FAIL(ctx, TC_ERR_ARG, "null buffer");
+    if (fm->n == 0) {
+        memset(out, 0, npat * sizeof(i64));
+        return TC_OK;
+    }
+    const u64 total = offs[npat];
+    u8 *d_pats = nullptr;
+    u64 *d_offs = nullptr;
+    i64 *d_out = nullptr;
+    Arena dry(nullptr);
+    auto carve = [&](Arena &A) {
+        d_pats = A.get<u8>(total + 16);
+        d_offs = A.get<u64>(npat + 1);
+        d_out = A.get<i64>(npat);
+    };
+    carve(dry);
+    tc_ws_reserve(ctx, dry.off);
+    Arena A(ctx->ws);
+    carve(A);
+    tc_h2d(ctx, d_pats, pats, total);
+    tc_h2d(ctx, d_offs, offs, (npat + 1) * sizeof(u64));
+    fm_count_device(ctx, fm, d_pats, d_offs, npat, d_out, nullptr);
+    tc_d2h(ctx, out, d_out, npat * sizeof(i64));
+    tc_sync_check(ctx);
+    TC_API_END(ctx)
+}
+
+int tc_fm_locate(tc_ctx *ctx, const tc_fm *fm, const uint8_t *pats, const uint64_t *offs,
+                 uint64_t npat, uint64_t *hit_offs, uint64_t *hits, uint64_t *nhits) {
+    TC_API_BEGIN(ctx)
+    if (!fm || !nhits) TC_FAIL(ctx, TC_ERR_ARG, "bad argument");
+    const u64 cap = *nhits;
+    *nhits = 0;
+    if (npat == 0) return TC_OK;
+    if (!pats || !offs || !hit_offs || (!hits && cap)) TC_FAIL(ctx, TC_ERR_ARG, "null buffer");
+    if (fm->n == 0) {
+        memset(hit_offs, 0, (npat + 1) * sizeof(u64));
+        return TC_OK;
+    }
+    const u64 total = offs[npat];
+    const u64 tiles = tc_cdiv(npat, SCAN_TILE);
+    u8 *d_pats = nullptr;
+    u64 *d_offs = nullptr, *d_ranges = nullptr, *d_len = nullptr, *d_hoffs = nullptr, *d_tsum = nullptr,
+        *d_hits = nullptr;
+    i64 *d_cnt = nullptr;
+    auto carve = [&](Arena &A) {
+        d_pats = A.get<u8>(total + 16);
+        d_offs = A.get<u64>(npat + 1);
+        d_cnt = A.get<i64>(npat);
+        d_ranges = A.get<u64>(2 * npat);
+        d_len = A.get<u64>(npat + 1);
+        d_hoffs = A.get<u64>(npat + 1);
+        d_tsum = A.get<u64>(tiles + 2);
+        d_hits = A.get<u64>(cap + 1);
+    };
+    Arena dry(nullptr);
+    carve(dry);
+    tc_ws_reserve(ctx, dry.off);
+    Arena A(ctx->ws);
+    carve(A);
+    hipStream_t s = ctx->stream;
+    tc_h2d(ctx, d_pats, pats, total);
+    tc_h2d(ctx, d_offs, offs, (npat + 1) * sizeof(u64));
+    fm_count_device(ctx, fm, d_pats, d_offs, npat, d_cnt, d_ranges);
+    fm_cnt_to_u64_kernel<<<tc_cdiv(npat, 256), 256, 0, s>>>(d_cnt, npat, d_len);
+    TC_LAUNCH_CHECK(ctx);
+    scan64_reduce_kernel<<<(u32)tiles, SCAN_NT, 0, s>>>(d_len, npat, d_tsum);
+    TC_LAUNCH_CHECK(ctx);
+    scan64_spine_kernel<<<1, 1024, 0, s>>>(d_tsum, tiles);
+    TC_LAUNCH_CHECK(ctx);
+    scan64_down_kernel<<<(u32)tiles, SCAN_NT, 0, s>>>(d_len, npat, d_tsum, d_hoffs);
+    TC_LAUNCH_CHECK(ctx);
+    tc_d2h(ctx, &ctx->h_scalars[9], d_tsum + tiles, sizeof(u64));
+    TC_HIP(ctx, hipStreamSynchronize(s));
+    const u64 need = ctx->h_scalars[9];
+    *nhits = need;
+    if (need > cap) TC_FAIL(ctx, TC_ERR_CAPACITY, "need %llu hit slots, have %llu",
+                            (unsigned long long)need, (unsigned long long)cap);
+    fm_locate_fill_kernel<<<tc_cdiv(npat, 256), 256, 0, s>>>(d_ranges, d_hoffs, fm->d_sa, npat, cap,
+                                                            d_hits);
+    TC_LAUNCH_CHECK(ctx);
+    tc_d2h(ctx, hit_offs, d_hoffs, npat * sizeof(u64));
+    if (need) tc_d2h(ctx, hits, d_hits, need * sizeof(u64));
+    tc_sync_check(ctx);
+    hit_offs[npat] = need;
+    TC_API_END(ctx)
+}
+
+int tc_fm_info(const tc_fm *fm, uint64_t *N, uint32_t *sigma, int16_t *c_sym, uint64_t *c_val,
+               uint64_t *primary) {
+    if (!fm) return TC_ERR_ARG;
+    if (N) *N = fm->N;
+    if (primary) *primary = fm->primary;
+    u32 sg = 0;
+    if (fm->n) {  // seqToCc rows: (0, Nothing) first, then every present byte
+        u64 acc = 1;
+        if (c_sym) c_sym[0] = -1;
+        if (c_val) c_val[0] = 0;
+        sg = 1;
+        for (u32 c = 0; c < fm->sigma_bytes; c++, sg++) {
+            if (c_sym) c_sym[sg] = fm->sym_of_code[c];
+            if (c_val) c_val[sg] = acc;
+            acc += fm->counts[fm->sym_of_code[c]];
+        }
+    }
+    if (sigma) *sigma = sg;
+    return TC_OK;
+}
 
 }  // extern "C"
