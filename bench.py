@@ -91,38 +91,23 @@ def main():
     assert rc == 0, rc
     torch.cuda.synchronize()
 
-    # gather buffers on rank 0 (one slot per peer), sized after the first step
-    recv_cnt = recv_val = None
+    gatherer = None
+    if world > 1:
+        from textcomp.gather import BlockGather
+        gatherer = BlockGather(cap, dev)
     blk = Block()
 
     def step():
-        nonlocal recv_cnt, recv_val
         blk.nruns = cap
         blk.run_count = d_cnt.data_ptr()
         blk.run_value = d_val.data_ptr()
         rc = lib.tc_encode_dev(ctx.handle, C.c_void_p(d_text.data_ptr()), n, C.byref(blk))
         if rc != 0:
             raise RuntimeError("tc_encode_dev rc=%d: %s" % (rc, lib.tc_last_error(ctx.handle).decode()))
-        if world > 1:
-            # header all-gather (tiny), then the run arrays to rank 0: 7 concurrent
+        if gatherer is not None:
+            # header all-gather (tiny), then the run arrays to rank 0: concurrent
             # receives spread over rank 0's point-to-point xGMI links.
-            hdr = torch.tensor([int(blk.nruns), int(blk.primary), int(blk.sigma), n], dtype=torch.int64, device=dev)
-            hdrs = torch.empty(world * 4, dtype=torch.int64, device=dev)
-            dist.all_gather_into_tensor(hdrs, hdr)
-            k = int(blk.nruns)
-            if rank == 0:
-                sizes = hdrs.view(world, 4)[:, 0].tolist()
-                if recv_cnt is None:
-                    recv_cnt = [None] + [torch.empty(cap, dtype=torch.int32, device=dev) for _ in range(1, world)]
-                    recv_val = [None] + [torch.empty(cap, dtype=torch.int16, device=dev) for _ in range(1, world)]
-                ops = []
-                for r in range(1, world):
-                    ops.append(dist.P2POp(dist.irecv, recv_cnt[r][:sizes[r]], r))
-                    ops.append(dist.P2POp(dist.irecv, recv_val[r][:sizes[r]], r))
-            else:
-                ops = [dist.P2POp(dist.isend, d_cnt[:k], 0), dist.P2POp(dist.isend, d_val[:k], 0)]
-            for w in dist.batch_isend_irecv(ops):
-                w.wait()
+            gatherer.gather(int(blk.nruns), int(blk.primary), int(blk.sigma), n, d_cnt, d_val)
 
     def fence():
         if world > 1:
