@@ -149,3 +149,15 @@ def test_configs(ctx, gen, seed, n):
     assert blk["primary"] == eprim and blk["final_list"].tolist() == efl.tolist()
     assert np.array_equal(blk["run_count"], ec.astype(np.uint32))
     assert np.array_equal(blk["run_value"], ev.astype(np.uint16))
+
+
+def test_dense_and_sparse_rank_modes_agree(ctx, monkeypatch):
+    """The tied-suffix refinement has two rank stores (sparse table / dense ISA)."""
+    t = O.gen_acgtn(77, 300000).tobytes() + b"ACGTACGT" * 3000
+    exp = O.suffix_array(t).tolist()
+    monkeypatch.setenv("TC_SA_FIELDS", "2")          # short round-0 key: many tied suffixes
+    assert ctx.suffix_array(t).tolist() == exp
+    monkeypatch.setenv("TC_SA_DENSE", "1")
+    assert ctx.suffix_array(t).tolist() == exp
+    monkeypatch.delenv("TC_SA_FIELDS")
+    assert ctx.suffix_array(t).tolist() == exp

@@ -52,7 +52,13 @@ struct SaBuffers {
     u64 *k0, *k1;
     u32 *v0, *v1;
     u32 *isa;
-    u32 *act[2][3];  // [set][slot, idx, grp]
+    u32 *v2;
+    u32 *act[2][4];  // [set][slot, idx, grp, tpos]
+    // sparse mode (few tied suffixes): round buffers + rank table, each `sparse_cap` long
+    u64 *sk[2];
+    u32 *sv[2];
+    u32 *t_idx, *t_rank;
+    u64 sparse_cap;
     u32 *hist;
     u64 *rstatus;
     u64 *gstatus;  // 2*tiles + 2
@@ -65,11 +71,19 @@ static size_t sa_carve(Arena &A, u64 N, SaBuffers &b, bool own_v1) {
     b.v0 = A.get<u32>(N);
     b.v1 = own_v1 ? A.get<u32>(N) : nullptr;
     b.isa = A.get<u32>(N + 1);
-    for (int s = 0; s < 2; s++)
+    b.v2 = A.get<u32>(N);
+    b.sparse_cap = N / 8 + 1024;
+    for (int s = 0; s < 2; s++) {
         for (int q = 0; q < 3; q++) b.act[s][q] = A.get<u32>(N);
+        b.act[s][3] = A.get<u32>(b.sparse_cap);
+        b.sk[s] = A.get<u64>(b.sparse_cap);
+        b.sv[s] = A.get<u32>(b.sparse_cap);
+    }
+    b.t_idx = A.get<u32>(b.sparse_cap);
+    b.t_rank = A.get<u32>(b.sparse_cap);
     b.hist = A.get<u32>(RDX_MAX_PASSES * RDX_BINS);
     b.rstatus = A.get<u64>(radix_status_words(N));
-    b.gstatus = A.get<u64>(2 * (size_t)tc_cdiv(N, SA_TILE) + 4);
+    b.gstatus = A.get<u64>(2 * (size_t)tc_cdiv(N, GRP_TILE) + 4);
     b.counts = A.get<u32>(260);
     return A.off;
 }
@@ -173,61 +187,103 @@ static void sa_build(tc_ctx *ctx, Arena &A, const u8 *d_text, u64 n, u32 *d_sa, 
     u32 *sa = rb.vals;  // == va
     u64 *skeys = rb.keys;
 
-    // 4. groups, ranks, last column, first active set
-    const u32 gtiles = tc_cdiv(N, SA_TILE);
-    auto run_group = [&](bool init, const u64 *keys, const u32 *idx, const u32 *slot, u32 count,
-                         int outset) {
-        u32 tiles = tc_cdiv(count, SA_TILE);
+    // 4. groups, last column, first active set
+    const u32 gtiles = tc_cdiv(N, GRP_TILE);
+    auto run_group = [&](bool init, GroupArgs ga) {
+        u32 tiles = tc_cdiv(ga.count, GRP_TILE);
         tc_memset_async(ctx, b.gstatus, 0, (2 * (size_t)gtiles + 4) * sizeof(u64));
-        GroupArgs ga;
-        ga.keys = keys; ga.idx = idx; ga.slot = slot; ga.count = count;
-        ga.text = d_text; ga.sa = sa; ga.isa = b.isa; ga.L = d_L;
-        ga.out_slot = b.act[outset][0]; ga.out_idx = b.act[outset][1]; ga.out_grp = b.act[outset][2];
+        ga.text = d_text; ga.sa = sa; ga.L = d_L;
         ga.status_max = b.gstatus; ga.status_sum = b.gstatus + gtiles;
         ga.ticket = reinterpret_cast<u32 *>(b.gstatus + 2 * (size_t)gtiles);
         ga.scalars = ctx->d_scalars; ga.err = ctx->d_err;
-        if (init) group_kernel<true><<<tiles, SA_NT, 0, s>>>(ga);
-        else group_kernel<false><<<tiles, SA_NT, 0, s>>>(ga);
+        if (init) group_kernel<true><<<tiles, GRP_NT, 0, s>>>(ga);
+        else group_kernel<false><<<tiles, GRP_NT, 0, s>>>(ga);
         TC_LAUNCH_CHECK(ctx);
+    };
+    auto fetch_m = [&]() {
         tc_d2h(ctx, ctx->h_scalars, ctx->d_scalars, 2 * sizeof(u64));
         TC_HIP(ctx, hipStreamSynchronize(s));
+        return ctx->h_scalars[1];
     };
     tc_memset_async(ctx, ctx->d_scalars, 0, 8 * sizeof(u64));
-    run_group(true, skeys, sa, nullptr, (u32)N, 0);
-    u64 m = ctx->h_scalars[1];
+    GroupArgs g0 = {};
+    g0.keys = skeys; g0.count = (u32)N; g0.vals = sa;
+    g0.out_slot = b.act[0][0]; g0.out_idx = b.act[0][1]; g0.out_grp = b.act[0][2]; g0.out_tpos = b.act[0][3];
+    run_group(true, g0);
+    u64 m = fetch_m();
     st.rounds = 1;
     st.m[0] = N; st.key_bytes[0] = 8; st.passes[0] = (u32)plan.npass; st.h[0] = 0;
 
-    // 5. prefix doubling on the tied suffixes
+    // 5. ranks: dense ISA when many suffixes are tied, else a sparse table of the tied
+    //    positions + binary search in the sorted round-0 keys for everything else
+    const int rbits = ceil_log2_u64(N);
+    const bool dense = m > b.sparse_cap - 1024 || env_int("TC_SA_DENSE", 0) != 0;
+    RankLookup rl = {};
+    rl.text = d_text; rl.n = (u32)n; rl.N = (u32)N;
+    rl.B = cfg.B; rl.w = cfg.w; rl.s = cfg.s; rl.P = cfg.P;
+    memcpy(rl.lut, cfg.lut, sizeof rl.lut);
+    if (dense) {
+        if (m > 0) {
+            GroupArgs gi = g0;
+            gi.isa = b.isa; gi.isa_only = 1;
+            run_group(true, gi);
+        }
+        rl.isa = b.isa;
+    } else {
+        rl.skeys = skeys; rl.t_idx = b.t_idx; rl.t_rank = b.t_rank; rl.t_n = (u32)m;
+        if (m > 0) {
+            u32 mm = (u32)m;
+            widen_u32_kernel<<<tc_cdiv(mm, 256), 256, 0, s>>>(b.act[0][1], b.sk[0], mm);
+            TC_LAUNCH_CHECK(ctx);
+            RadixPlan pt;
+            pt.add_range(0, rbits);
+            RadixBuffers rt;
+            rt.keys = b.sk[0]; rt.keys_alt = b.sk[1]; rt.vals = b.sv[0]; rt.vals_alt = b.sv[1];
+            rt.hist = b.hist; rt.status = b.rstatus;
+            radix_sort_pairs(ctx, rt, mm, pt, true, false);
+            table_build_kernel<<<tc_cdiv(mm, 256), 256, 0, s>>>(rt.keys, rt.vals, b.act[0][2], mm,
+                                                               b.t_idx, b.t_rank, b.act[0][3]);
+            TC_LAUNCH_CHECK(ctx);
+        }
+    }
+
+    // 6. prefix doubling on the tied suffixes
     int cur = 0;
     u64 h = cfg.h0;
-    const int rbits = ceil_log2_u64(N);
     while (m > 0) {
         if (st.rounds >= TC_MAX_ROUNDS) TC_FAIL(ctx, TC_ERR_INTERNAL, "suffix sort did not converge");
         u32 mm = (u32)m;
         u32 hh = h > N ? (u32)N : (u32)h;
-        u64 *k2 = b.k0, *k2alt = b.k1;  // round-0 keys are dead by now
-        key2_kernel<<<tc_cdiv(mm, 256), 256, 0, s>>>(b.act[cur][1], b.act[cur][2], b.isa, mm, hh,
-                                                    (u32)N, k2);
+        // dense: the round-0 key buffers are dead; sparse: they hold the sorted keys
+        u64 *k2 = dense ? b.k0 : b.sk[0], *k2alt = dense ? b.k1 : b.sk[1];
+        u32 *kv = dense ? b.v0 : b.sv[0], *kvalt = dense ? b.v2 : b.sv[1];
+        key2_kernel<<<tc_cdiv(mm, 256), 256, 0, s>>>(b.act[cur][1], b.act[cur][2], rl, mm, hh, k2);
         TC_LAUNCH_CHECK(ctx);
         RadixPlan p2;
         p2.add_range(0, rbits);
         p2.add_range(32, 32 + rbits);
         RadixBuffers r2;
-        r2.keys = k2; r2.keys_alt = k2alt;
-        r2.vals = b.act[cur][1]; r2.vals_alt = b.v0;
+        r2.keys = k2; r2.keys_alt = k2alt; r2.vals = kv; r2.vals_alt = kvalt;
         r2.hist = b.hist; r2.status = b.rstatus;
-        radix_sort_pairs(ctx, r2, mm, p2, false, false);
-        run_group(false, r2.keys, r2.vals, b.act[cur][0], mm, cur ^ 1);
+        radix_sort_pairs(ctx, r2, mm, p2, /*gen_idx=*/true, false);
+        GroupArgs gr = {};
+        gr.keys = r2.keys; gr.count = mm; gr.vals = r2.vals;
+        gr.in_slot = b.act[cur][0]; gr.in_idx = b.act[cur][1]; gr.in_tpos = b.act[cur][3];
+        gr.isa = dense ? b.isa : nullptr; gr.t_rank = dense ? nullptr : b.t_rank;
+        gr.out_slot = b.act[cur ^ 1][0]; gr.out_idx = b.act[cur ^ 1][1];
+        gr.out_grp = b.act[cur ^ 1][2]; gr.out_tpos = b.act[cur ^ 1][3];
+        run_group(false, gr);
         st.m[st.rounds] = m; st.key_bytes[st.rounds] = 8; st.passes[st.rounds] = (u32)p2.npass;
         st.h[st.rounds] = hh;
         st.rounds++;
-        // the sort may have left act[cur][1] pointing at v0: nothing to restore, the
-        // next set is rebuilt by the group kernel
-        m = ctx->h_scalars[1];
+        m = fetch_m();
         cur ^= 1;
         h *= 2;
     }
+    primary_kernel<<<1, 64, 0, s>>>(rl, ctx->d_scalars);
+    TC_LAUNCH_CHECK(ctx);
+    tc_d2h(ctx, ctx->h_scalars, ctx->d_scalars, sizeof(u64));
+    TC_HIP(ctx, hipStreamSynchronize(s));
     *primary = ctx->h_scalars[0];
     st.sigma = cfg.sigma_text + 1;
     st.radix_launches = 0;

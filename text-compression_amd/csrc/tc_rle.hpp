@@ -16,8 +16,8 @@
 #include "tc_common.hpp"
 #include "tc_mtf.hpp"
 
-#define RLE_NT 256
-#define RLE_ITEMS 16
+#define RLE_NT 512
+#define RLE_ITEMS 8
 #define RLE_TILE (RLE_NT * RLE_ITEMS)
 
 #ifdef __HIPCC__
@@ -32,6 +32,31 @@ struct RleArgs {
     u64 *scalars;  // [2] total pairs
     u32 *err;
 };
+
+// Flag ballots of one 64-position item: heads of Just runs, Just positions, own and
+// post emissions (see the rules at the top of this file).
+struct RleFlags {
+    u64 hb, jb, ob, pb;
+};
+__device__ __forceinline__ RleFlags rle_flags(int xi, int xp, int xn, u64 j, u64 N) {
+    const bool in = j < N;
+    const bool just = xi >= 0;
+    const bool head = in && just && (j == 0 || xp < 0 || xp != xi);
+    const bool own = in && !just && j >= 1;
+    bool post = false;
+    if (in) {
+        if (j == N - 1) post = true;
+        else if (xn < 0) post = true;
+        else if (!just) post = false;
+        else post = xi != xn;
+    }
+    RleFlags f;
+    f.hb = __ballot(head);
+    f.jb = __ballot(in && just);
+    f.ob = __ballot(own);
+    f.pb = __ballot(post);
+    return f;
+}
 
 template <class Acc, class SymT>
 __global__ __launch_bounds__(RLE_NT) void rle_encode_kernel(Acc acc, RleArgs a) {
@@ -52,57 +77,35 @@ __global__ __launch_bounds__(RLE_NT) void rle_encode_kernel(Acc acc, RleArgs a) 
         u64 j = base + k * 64 + l;
         x[k] = j < N ? acc(j) : -2;
     }
-    int xprev0 = -2, xnextT = -2;  // neighbours of the wave segment
+    int xprev0 = -2, xnextT = -2;  // neighbours of the wave segment (wave-uniform loads)
     if (base > 0 && base <= N) xprev0 = acc(base - 1);
-    {
-        u64 jn = base + (u64)64 * RLE_ITEMS;
-        if (jn < N) xnextT = acc(jn);
-    }
-    u32 hinc[RLE_ITEMS], jinc[RLE_ITEMS], eexc[RLE_ITEMS];
-    u8 fl[RLE_ITEMS];  // bit0 own, bit1 post
-    u32 ch = 0, cj = 0, cs = 0;
-    int carry_prev = xprev0;
-#pragma unroll
-    for (int k = 0; k < RLE_ITEMS; k++) {
-        u64 j = base + k * 64 + l;
-        bool in = j < N;
+    if (base + (u64)64 * RLE_ITEMS < N) xnextT = acc(base + (u64)64 * RLE_ITEMS);
+
+    auto item_flags = [&](int k) {
         int xi = x[k];
         int up = __shfl_up(xi, 1, 64);
-        int xp = (l == 0) ? carry_prev : up;
-        carry_prev = __shfl(xi, 63, 64);
         int dn = __shfl_down(xi, 1, 64);
-        int nx0 = xnextT;
-        if (k + 1 < RLE_ITEMS) nx0 = __shfl(x[(k + 1) % RLE_ITEMS], 0, 64);
-        int xn = (l < 63) ? dn : nx0;
-        bool just = xi >= 0;
-        bool head = in && just && (j == 0 || xp < 0 || xp != xi);
-        bool own = in && !just && j >= 1;
-        bool post = false;
-        if (in) {
-            if (j == N - 1) post = true;
-            else if (xn < 0) post = true;
-            else if (!just) post = false;
-            else post = xi != xn;
-        }
-        u32 hv = head ? (u32)(j + 1) : 0u;
-        u32 jv = (in && just) ? (u32)(j + 1) : 0u;
-        u32 hi = wave_incl_max(hv), ji = wave_incl_max(jv);
-        hi = hi > ch ? hi : ch;
-        ji = ji > cj ? ji : cj;
-        hinc[k] = hi;
-        jinc[k] = ji;
-        ch = __shfl(hi, 63, 64);
-        cj = __shfl(ji, 63, 64);
-        u32 ev = (own ? 1u : 0u) + (post ? 1u : 0u);
-        u32 ei = wave_incl_sum(ev);
-        eexc[k] = cs + ei - ev;
-        cs += __shfl(ei, 63, 64);
-        fl[k] = (u8)((own ? 1 : 0) | (post ? 2 : 0));
+        int p0 = (k == 0) ? xprev0 : __shfl(x[(k + RLE_ITEMS - 1) % RLE_ITEMS], 63, 64);
+        int n0 = (k == RLE_ITEMS - 1) ? xnextT : __shfl(x[(k + 1) % RLE_ITEMS], 0, 64);
+        int xp = (l == 0) ? p0 : up;
+        int xn = (l == 63) ? n0 : dn;
+        return rle_flags(xi, xp, xn, base + (u64)k * 64 + l, N);
+    };
+
+    // ---- phase 1: wave aggregates ----------------------------------------------------
+    u32 wh = 0, wj = 0, ws = 0;  // 1 + last head pos, 1 + last Just pos, emissions
+#pragma unroll
+    for (int k = 0; k < RLE_ITEMS; k++) {
+        RleFlags f = item_flags(k);
+        u64 jb0 = base + (u64)k * 64;
+        if (f.hb) wh = (u32)(jb0 + 63u - (u32)__builtin_clzll(f.hb)) + 1u;
+        if (f.jb) wj = (u32)(jb0 + 63u - (u32)__builtin_clzll(f.jb)) + 1u;
+        ws += (u32)__popcll(f.ob) + (u32)__popcll(f.pb);
     }
-    if (l == 63) {
-        s_wh[w] = ch;
-        s_wj[w] = cj;
-        s_ws[w] = cs;
+    if (l == 0) {
+        s_wh[w] = wh;
+        s_wj[w] = wj;
+        s_ws[w] = ws;
     }
     __syncthreads();
     u32 ph = 0, pj = 0, ps = 0, bh = 0, bj = 0, bs = 0;
@@ -129,31 +132,39 @@ __global__ __launch_bounds__(RLE_NT) void rle_encode_kernel(Acc acc, RleArgs a) 
     }
     __syncthreads();
     const u32 th = (u32)(s_pref[0] >> 31), tj = (u32)(s_pref[0] & 0x7fffffffu);
-    ph = ph > th ? ph : th;
-    pj = pj > tj ? pj : tj;
-    const u64 pe = s_pref[1] + ps;
+    u32 curH = ph > th ? ph : th, curJ = pj > tj ? pj : tj;
+    u64 curE = s_pref[1] + ps;
     SymT *syms = reinterpret_cast<SymT *>(a.syms);
+
+    // ---- phase 2: emit ---------------------------------------------------------------
 #pragma unroll
     for (int k = 0; k < RLE_ITEMS; k++) {
-        if (!fl[k]) continue;
-        u64 j = base + k * 64 + l;
-        u32 H = hinc[k] > ph ? hinc[k] : ph;
-        u32 J = jinc[k] > pj ? jinc[k] : pj;
-        u64 e = pe + eexc[k];
-        if (fl[k] & 1) {
+        const u64 jb0 = base + (u64)k * 64;
+        if (jb0 >= N) break;
+        RleFlags f = item_flags(k);
+        const u64 j = jb0 + l;
+        const u64 le = (2ull << l) - 1ull;
+        const u64 hm = f.hb & le, jm = f.jb & le;
+        const u32 H = hm ? (u32)(jb0 + 63u - (u32)__builtin_clzll(hm)) + 1u : curH;
+        const u32 J = jm ? (u32)(jb0 + 63u - (u32)__builtin_clzll(jm)) + 1u : curJ;
+        u64 e = curE + (u64)__popcll(f.ob & lanemask_lt()) + (u64)__popcll(f.pb & lanemask_lt());
+        if ((f.ob >> l) & 1ull) {
             if (e < a.cap) {
                 a.counts[e] = 1u;
                 syms[e] = (SymT)-1;
             }
             e++;
         }
-        if (fl[k] & 2) {
-            u32 cnt = x[k] >= 0 ? (u32)(j + 2 - H) : (J ? J - H + 1 : 1u);
+        if ((f.pb >> l) & 1ull) {
+            u32 cnt = x[k] >= 0 ? (u32)(j + 2 - H) : (J ? J - H + 1u : 1u);
             if (e < a.cap) {
                 a.counts[e] = cnt;
                 syms[e] = (SymT)x[k];
             }
         }
+        if (f.hb) curH = (u32)(jb0 + 63u - (u32)__builtin_clzll(f.hb)) + 1u;
+        if (f.jb) curJ = (u32)(jb0 + 63u - (u32)__builtin_clzll(f.jb)) + 1u;
+        curE += (u64)__popcll(f.ob) + (u64)__popcll(f.pb);
     }
 }
 

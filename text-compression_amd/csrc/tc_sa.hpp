@@ -129,128 +129,118 @@ __global__ __launch_bounds__(SA_NT) void keybuild_kernel(const u8 *__restrict__ 
 }
 
 // ---- group detection / re-ranking ---------------------------------------------
-// INIT (round 0): element k sits at SA position k; tie <=> equal key bits above the
-//   payload byte; writes L[k] from the key.
-// REFINE (round r): element k of the sorted active set goes to SA position
-//   slot[k]; tie <=> equal (group, rank[i+h]) key; writes SA, L (gathered).
-// Both: rank[idx] = position of the group's first member; members of groups of
-// size >= 2 are compacted into the next active set.
+// One kernel, three uses (all over elements in sorted order):
+//   INIT        element j sits at SA position j; tie <=> equal key bits above the
+//               payload byte; writes L[j] = key low byte; compacts the members of
+//               groups of size >= 2 into the first active set (slot, idx, group).
+//   INIT + isa_only   (dense mode, second pass) rank[sa[j]] = group start, for all j.
+//   REFINE      element kk of the sorted active set goes to SA position slot[kk]; tie
+//               <=> equal (group, rank[i+h]); writes SA, L (gathered), the new rank of
+//               every member (dense: isa[idx]; sparse: t_rank[tpos]) and the next set.
+// Flags are wave ballots, so every scan is bit arithmetic on wave-uniform 64-bit
+// masks with scalar carries; only the cross-wave / cross-tile prefixes use LDS and a
+// decoupled look-back (max of "last head", sum of actives).
+#define GRP_NT 512
+#define GRP_ITEMS 8
+#define GRP_TILE (GRP_NT * GRP_ITEMS)
+
 struct GroupArgs {
-    const u64 *keys;  // sorted keys
-    const u32 *idx;   // suffix start per element (INIT: the SA itself)
-    const u32 *slot;  // REFINE: SA position of the k-th active element (increasing)
+    const u64 *keys;    // sorted keys
     u32 count;
+    const u32 *vals;    // INIT: SA.  REFINE: for sorted position kk, index k0 into the in_* arrays
+    const u32 *in_slot; // REFINE: SA position of the kk-th active element (by sorted position)
+    const u32 *in_idx;  // REFINE: suffix start, by k0
+    const u32 *in_tpos; // REFINE sparse: rank-table position, by k0
     const u8 *text;
     u32 *sa;
-    u32 *isa;
+    u32 *isa;           // dense rank array or null
+    u32 *t_rank;        // sparse rank table or null
     u8 *L;
-    u32 *out_slot, *out_idx, *out_grp;  // next active set
-    u64 *status_max, *status_sum;       // look-back granules, [tiles] each
+    u32 *out_slot, *out_idx, *out_grp, *out_tpos;  // next active set
+    int isa_only;
+    u64 *status_max, *status_sum;  // look-back granules, [tiles] each
     u32 *ticket;
-    u64 *scalars;  // [0] primary, [1] active count
+    u64 *scalars;  // [1] active count
     u32 *err;
 };
 
 template <bool INIT>
-__global__ __launch_bounds__(SA_NT) void group_kernel(GroupArgs a) {
-    constexpr int NW = SA_NT / 64;
-    __shared__ u64 s_wmax[NW];
-    __shared__ u32 s_wsum[NW];
+__global__ __launch_bounds__(GRP_NT) void group_kernel(GroupArgs a) {
+    constexpr int NW = GRP_NT / 64;
+    __shared__ u32 s_wmax[NW], s_wsum[NW];
     __shared__ u64 s_pref[2];
     __shared__ u32 s_tile;
     const int tid = threadIdx.x, w = tid >> 6, l = tid & 63;
     if (tid == 0) s_tile = atomicAdd(a.ticket, 1u);
     __syncthreads();
     const u32 tile = s_tile;
-    const u64 base = (u64)tile * SA_TILE + (u64)w * 64 * SA_ITEMS;
+    const u64 base = (u64)tile * GRP_TILE + (u64)w * 64 * GRP_ITEMS;
     const u64 KMASK = INIT ? ~0xffull : ~0ull;
+    const u64 count = a.count;
 
-    u64 key[SA_ITEMS];
-    u32 idx[SA_ITEMS], pos[SA_ITEMS];
-    u8 lowb[SA_ITEMS];
-    int hb[SA_ITEMS];
+    // ---- phase 1: head ballots, packed low bytes, wave aggregates -----------------
+    u64 hb[GRP_ITEMS], ab[GRP_ITEMS];
+    u32 lowb[GRP_ITEMS / 4];
 #pragma unroll
-    for (int k = 0; k < SA_ITEMS; k++) {
+    for (int q = 0; q < GRP_ITEMS / 4; q++) lowb[q] = 0;
+    u64 carry = 0;
+    bool has_prev = false;
+    if (base > 0 && base < count) {
+        carry = a.keys[base - 1] & KMASK;
+        has_prev = true;
+    }
+#pragma unroll
+    for (int k = 0; k < GRP_ITEMS; k++) {
         u64 j = base + k * 64 + l;
-        bool in = j < a.count;
+        bool in = j < count;
         u64 raw = in ? a.keys[j] : 0;
-        lowb[k] = (u8)(raw & 0xff);
-        key[k] = raw & KMASK;
-        idx[k] = in ? a.idx[j] : 0;
-        pos[k] = INIT ? (u32)j : (in ? a.slot[j] : 0);
+        u64 key = raw & KMASK;
+        if (INIT) lowb[k >> 2] |= (u32)(raw & 0xff) << (8 * (k & 3));
+        u64 up = __shfl_up(key, 1, 64);
+        u64 pk = (l == 0) ? carry : up;
+        bool hp = (l == 0) ? has_prev : true;
+        hb[k] = __ballot(in && (!hp || pk != key));
+        carry = __shfl(key, 63, 64);
+        has_prev = true;
     }
-    // head flags: first element, or key differs from its predecessor
+    u64 tail_next = 1;  // head flag of the element just past this wave's segment
     {
-        u64 prevk = 0;
-        bool has_prev = false;
-        if (base > 0 && base < a.count) {
-            prevk = a.keys[base - 1] & KMASK;  // same address in every lane: broadcast
-            has_prev = true;
-        }
-#pragma unroll
-        for (int k = 0; k < SA_ITEMS; k++) {
-            u64 up = __shfl_up(key[k], 1, 64);
-            u64 pk = (l == 0) ? prevk : up;
-            bool hp = (l == 0) ? has_prev : true;
-            hb[k] = (!hp || pk != key[k]) ? 1 : 0;
-            prevk = __shfl(key[k], 63, 64);
-            has_prev = true;
-        }
+        u64 jn = base + (u64)64 * GRP_ITEMS;
+        if (jn < count) tail_next = ((a.keys[jn] & KMASK) != carry) ? 1 : 0;
     }
-    // next-head flags (a virtual head sits just past the end)
-    int nhb[SA_ITEMS];
-    {
-        int tail_next = 1;  // head flag of element base + 64*ITEMS
-        u64 jn = base + (u64)64 * SA_ITEMS;
-        if (jn < a.count) tail_next = ((a.keys[jn] & KMASK) != __shfl(key[SA_ITEMS - 1], 63, 64)) ? 1 : 0;
+    u32 wcnt = 0, wlast = 0;  // actives in this wave; 1 + value of the last head
 #pragma unroll
-        for (int k = 0; k < SA_ITEMS; k++) {
-            int dn = __shfl_down(hb[k], 1, 64);
-            int nx0 = tail_next;
-            if (k + 1 < SA_ITEMS) nx0 = __shfl(hb[(k + 1) % SA_ITEMS], 0, 64);
-            int nh = (l < 63) ? dn : nx0;
-            u64 j = base + k * 64 + l;
-            if (j + 1 >= a.count) nh = 1;
-            nhb[k] = nh;
+    for (int k = 0; k < GRP_ITEMS; k++) {
+        u64 jb = base + (u64)k * 64;
+        u64 inb = jb >= count ? 0ull : (count - jb >= 64 ? ~0ull : ((1ull << (count - jb)) - 1ull));
+        u64 nxt0 = (k + 1 < GRP_ITEMS) ? (hb[(k + 1) % GRP_ITEMS] & 1ull) : tail_next;
+        u64 nh = (hb[k] >> 1) | (nxt0 << 63);
+        // the element after the last valid one is a (virtual) head
+        u64 in_next = (inb >> 1) | ((jb + 64 < count ? 1ull : 0ull) << 63);
+        nh |= ~in_next;
+        ab[k] = inb & ~(hb[k] & nh);
+        wcnt += (u32)__popcll(ab[k]);
+        if (hb[k]) {
+            u32 hl = 63u - (u32)__builtin_clzll(hb[k]);
+            u64 jh = jb + hl;
+            wlast = INIT ? (u32)jh + 1u : a.in_slot[jh] + 1u;
         }
     }
-    // local scans in (wave, item, lane) order
-    u64 gmax[SA_ITEMS];
-    u32 aexc[SA_ITEMS];
-    bool act[SA_ITEMS];
-    u64 cmax = 0;
-    u32 csum = 0;
-#pragma unroll
-    for (int k = 0; k < SA_ITEMS; k++) {
-        u64 j = base + k * 64 + l;
-        bool in = j < a.count;
-        // group start encoded +1 so that 0 is the identity
-        u64 v = (in && hb[k]) ? (u64)pos[k] + 1 : 0;
-        u64 inc = wave_incl_max64(v);
-        inc = inc > cmax ? inc : cmax;
-        gmax[k] = inc;
-        cmax = __shfl(inc, 63, 64);
-        act[k] = in && !(hb[k] && nhb[k]);
-        u32 av = act[k] ? 1u : 0u;
-        u32 ai = wave_incl_sum(av);
-        aexc[k] = csum + ai - av;
-        csum += __shfl(ai, 63, 64);
-    }
-    if (l == 63) {
-        s_wmax[w] = cmax;
-        s_wsum[w] = csum;
+    if (l == 0) {
+        s_wmax[w] = wlast;
+        s_wsum[w] = wcnt;
     }
     __syncthreads();
-    u64 wpmax = 0, bmax = 0;
-    u32 wpsum = 0, bsum = 0;
+    u32 pmax = 0, psum = 0, bmax = 0, bsum = 0;
 #pragma unroll
     for (int i = 0; i < NW; i++) {
+        u32 m = s_wmax[i], c = s_wsum[i];
         if (i < w) {
-            wpmax = wpmax > s_wmax[i] ? wpmax : s_wmax[i];
-            wpsum += s_wsum[i];
+            pmax = pmax > m ? pmax : m;
+            psum += c;
         }
-        bmax = bmax > s_wmax[i] ? bmax : s_wmax[i];
-        bsum += s_wsum[i];
+        bmax = bmax > m ? bmax : m;
+        bsum += c;
     }
     if (w == 0) {
         u64 e = lb_exclusive<OpMax>(a.status_max, tile, bmax, a.err);
@@ -259,50 +249,152 @@ __global__ __launch_bounds__(SA_NT) void group_kernel(GroupArgs a) {
         u64 e = lb_exclusive<OpSum>(a.status_sum, tile, bsum, a.err);
         if (l == 0) {
             s_pref[1] = e;
-            if ((u64)(tile + 1) * SA_TILE >= a.count) a.scalars[1] = e + bsum;  // last tile
+            if ((u64)(tile + 1) * GRP_TILE >= count) a.scalars[1] = e + bsum;  // last tile
         }
     }
     __syncthreads();
-    const u64 tpmax = s_pref[0] > wpmax ? s_pref[0] : wpmax;
-    const u32 tpsum = (u32)s_pref[1] + wpsum;
+    u32 cur_head = (u32)s_pref[0] > pmax ? (u32)s_pref[0] : pmax;  // 1 + value
+    u32 cur_cnt = (u32)s_pref[1] + psum;
+
+    // ---- phase 2: ranks, outputs, compaction -------------------------------------
 #pragma unroll
-    for (int k = 0; k < SA_ITEMS; k++) {
-        u64 j = base + k * 64 + l;
-        if (j >= a.count) continue;
-        u64 g1 = gmax[k] > tpmax ? gmax[k] : tpmax;
-        u32 g = (u32)(g1 - 1);
-        u32 i = idx[k];
-        a.isa[i] = g;
-        if (INIT) {
-            a.L[j] = lowb[k];
-        } else {
-            a.sa[pos[k]] = i;
-            a.L[pos[k]] = i ? a.text[i - 1] : (u8)0;
+    for (int k = 0; k < GRP_ITEMS; k++) {
+        const u64 jb = base + (u64)k * 64;
+        if (jb >= count) break;
+        const u64 j = jb + l;
+        const bool in = j < count;
+        const bool act = (ab[k] >> l) & 1ull;
+        u32 k0 = 0, slot = 0;
+        if (!INIT && in) {
+            k0 = a.vals[j];
+            slot = a.in_slot[j];
         }
-        if (i == 0) a.scalars[0] = pos[k];
-        if (act[k]) {
-            u32 o = tpsum + aexc[k];
-            a.out_slot[o] = pos[k];
-            a.out_idx[o] = i;
-            a.out_grp[o] = g;
+        // group start for this lane: last head at or before it (every lane executes
+        // the shuffles; lanes without a head in range take the running scalar)
+        const u64 mle = hb[k] & ((2ull << l) - 1ull);
+        const u32 hl = mle ? 63u - (u32)__builtin_clzll(mle) : 0u;
+        const u32 sv = INIT ? 0u : (u32)__shfl((int)slot, (int)hl, 64);
+        const u32 g = mle ? (INIT ? (u32)(jb + hl) : sv) : cur_head - 1u;
+        if (hb[k]) {
+            u32 hlast = 63u - (u32)__builtin_clzll(hb[k]);
+            cur_head = (INIT ? (u32)(jb + hlast) : (u32)__shfl((int)slot, (int)hlast, 64)) + 1u;
+        }
+        const u32 o = cur_cnt + (u32)__popcll(ab[k] & lanemask_lt());
+        cur_cnt += (u32)__popcll(ab[k]);
+        if (!in) continue;
+        if (INIT) {
+            if (a.isa_only) {
+                a.isa[a.vals[j]] = g;
+            } else {
+                a.L[j] = (u8)(lowb[k >> 2] >> (8 * (k & 3)));
+                if (act) {
+                    a.out_slot[o] = (u32)j;
+                    a.out_idx[o] = a.vals[j];
+                    a.out_grp[o] = g;
+                }
+            }
+        } else {
+            const u32 i = a.in_idx[k0];
+            a.sa[slot] = i;
+            a.L[slot] = i ? a.text[i - 1] : (u8)0;
+            u32 tp = 0;
+            if (a.isa) a.isa[i] = g;
+            else {
+                tp = a.in_tpos[k0];
+                a.t_rank[tp] = g;
+            }
+            if (act) {
+                a.out_slot[o] = slot;
+                a.out_idx[o] = i;
+                a.out_grp[o] = g;
+                if (!a.isa) a.out_tpos[o] = tp;
+            }
         }
     }
+}
+
+// ---- rank of an arbitrary text position ----------------------------------------
+// dense: isa[p].  sparse: positions that were ever tied live in a table sorted by
+// position (t_idx -> t_rank); every other suffix was unique after round 0, so its
+// rank is the position of its round-0 key in the sorted key array.
+struct RankLookup {
+    const u32 *isa;      // dense, or null
+    const u32 *t_idx;    // sparse table
+    const u32 *t_rank;
+    u32 t_n;
+    const u64 *skeys;    // sorted round-0 keys (low byte = payload)
+    const u8 *text;
+    u32 n, N;
+    u32 B, w, s, P;
+    u16 lut[256];
+};
+
+__device__ __forceinline__ u32 rank_of(const RankLookup &r, const u16 *s_lut, u64 p) {
+    if (p >= r.N) return 0u;
+    if (r.isa) return r.isa[p];
+    {   // binary search in the table of ever-tied positions
+        u32 lo = 0, hi = r.t_n;
+        while (lo < hi) {
+            u32 mid = (lo + hi) >> 1;
+            if (r.t_idx[mid] < (u32)p) lo = mid + 1; else hi = mid;
+        }
+        if (lo < r.t_n && r.t_idx[lo] == (u32)p) return r.t_rank[lo];
+    }
+    // round-0 key of suffix p, straight from the text
+    u64 key = 0;
+    int sh = 64;
+    u64 q = p;
+    for (u32 f = 0; f < r.P; f++) {
+        u32 g = 0;
+        for (u32 t = 0; t < r.s; t++, q++) g = g * r.B + (q < r.n ? (u32)s_lut[r.text[q]] : 0u);
+        sh -= r.w;
+        key |= (u64)g << sh;
+    }
+    u64 lo = 0, hi = r.N;  // lower_bound over the key bits above the payload byte
+    while (lo < hi) {
+        u64 mid = (lo + hi) >> 1;
+        if ((r.skeys[mid] & ~0xffull) < key) lo = mid + 1; else hi = mid;
+    }
+    return (u32)lo;
 }
 
 // key2[k] = group << 32 | rank[idx + h]
 __global__ __launch_bounds__(256) void key2_kernel(const u32 *__restrict__ idx,
-                                                   const u32 *__restrict__ grp,
-                                                   const u32 *__restrict__ isa, u32 m, u32 h,
-                                                   u32 N, u64 *__restrict__ keys) {
+                                                   const u32 *__restrict__ grp, RankLookup r, u32 m,
+                                                   u32 h, u64 *__restrict__ keys) {
+    __shared__ u16 s_lut[256];
+    s_lut[threadIdx.x] = r.lut[threadIdx.x];
+    __syncthreads();
     u32 k = blockIdx.x * 256 + threadIdx.x;
     if (k >= m) return;
-    u64 p = (u64)idx[k] + h;
-    u32 r = p < N ? isa[p] : 0u;  // p <= n always holds for a tied suffix
-    keys[k] = ((u64)grp[k] << 32) | r;
+    keys[k] = ((u64)grp[k] << 32) | rank_of(r, s_lut, (u64)idx[k] + h);  // idx + h <= n for a tied suffix
 }
 
-__global__ __launch_bounds__(256) void copy_u32_kernel(const u32 *__restrict__ a,
-                                                       u32 *__restrict__ b, u32 m) {
+// primary = rank of suffix 0 (its SA position once everything is resolved)
+__global__ void primary_kernel(RankLookup r, u64 *scalars) {
+    __shared__ u16 s_lut[256];
+    for (int i = threadIdx.x; i < 256; i += blockDim.x) s_lut[i] = r.lut[i];
+    __syncthreads();
+    if (threadIdx.x == 0) scalars[0] = rank_of(r, s_lut, 0);
+}
+
+// sparse table build: after sorting (idx, k) by idx: t_idx[q] = idx, t_rank[q] = grp[k], tpos[k] = q
+__global__ __launch_bounds__(256) void table_build_kernel(const u64 *__restrict__ sorted_idx,
+                                                          const u32 *__restrict__ sorted_k,
+                                                          const u32 *__restrict__ grp, u32 m,
+                                                          u32 *__restrict__ t_idx,
+                                                          u32 *__restrict__ t_rank,
+                                                          u32 *__restrict__ tpos) {
+    u32 q = blockIdx.x * 256 + threadIdx.x;
+    if (q >= m) return;
+    u32 k = sorted_k[q];
+    t_idx[q] = (u32)sorted_idx[q];
+    t_rank[q] = grp[k];
+    tpos[k] = q;
+}
+
+__global__ __launch_bounds__(256) void widen_u32_kernel(const u32 *__restrict__ a,
+                                                        u64 *__restrict__ b, u32 m) {
     u32 k = blockIdx.x * 256 + threadIdx.x;
     if (k < m) b[k] = a[k];
 }
