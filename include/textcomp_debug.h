@@ -1,0 +1,23 @@
+/*
+ * textcomp_debug.h -- measurement hooks of libtextcomp.so (not part of the drop-in
+ * boundary): calibration micro-kernels used to put the pipeline's kernels next to what
+ * the memory system delivers on this device for the same access width.
+ */
+#ifndef TEXTCOMP_DEBUG_H
+#define TEXTCOMP_DEBUG_H
+#include "textcomp.h"
+#ifdef __cplusplus
+extern "C" {
+#endif
+/* Streams `bytes` from one workspace buffer to another `iters` times and returns the
+ * mean copy rate in GB/s (read + write bytes / time).  width: bytes per lane per access
+ * (1, 2, 4, 8, 16).  mode 0: copy, 1: read-only (sum), 2: write-only (fill). */
+int tc_dbg_stream_bench(tc_ctx *ctx, uint64_t bytes, int width, int mode, int iters, double *gbps);
+/* Sorts n random (u64 key, u32 value) pairs by the top `key_bits` key bits with the
+ * device radix sort and returns the mean duration of one pass in ms (HIP events).
+ * check != 0: verify the result is sorted and stable (returns TC_ERR_INTERNAL if not). */
+int tc_dbg_sort_bench(tc_ctx *ctx, uint64_t n, int key_bits, int iters, int check, double *ms_per_pass);
+#ifdef __cplusplus
+}
+#endif
+#endif

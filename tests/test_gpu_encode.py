@@ -161,3 +161,19 @@ def test_dense_and_sparse_rank_modes_agree(ctx, monkeypatch):
     assert ctx.suffix_array(t).tolist() == exp
     monkeypatch.delenv("TC_SA_FIELDS")
     assert ctx.suffix_array(t).tolist() == exp
+
+
+def test_finish_and_full_paths_agree(ctx, monkeypatch):
+    """Round 0 has a fast path (partial global sort + wave-local finish) and a full path
+    (all passes + group kernel); oversize buckets must fall back transparently."""
+    t = O.gen_acgtn(3, 200000).tobytes()
+    exp = O.suffix_array(t).tolist()
+    for passes in ("1", "2", "3"):                # few global passes: bigger buckets, more ties
+        monkeypatch.setenv("TC_SA_GLOBAL_PASSES", passes)
+        assert ctx.suffix_array(t).tolist() == exp, passes
+    monkeypatch.delenv("TC_SA_GLOBAL_PASSES")
+    monkeypatch.setenv("TC_SA_FINISH", "0")       # full path only
+    assert ctx.suffix_array(t).tolist() == exp
+    monkeypatch.delenv("TC_SA_FINISH")
+    rep = b"ACGT" * 50000 + t[:1000]              # long repeats: oversize buckets -> fallback
+    assert ctx.suffix_array(rep).tolist() == O.suffix_array(rep).tolist()

@@ -33,6 +33,7 @@ struct tc_ctx {
     hipEvent_t ev[8] = {};
     hipEvent_t pev[2 * 16] = {};  // per-pass event pairs (profile mode)
     int profile = 0;
+    int num_cus = 0;
     int pev_used = 0;
     std::string err;
     tc_stats stats = {};
@@ -80,6 +81,18 @@ struct Arena {
 };
 
 void tc_ws_reserve(tc_ctx *ctx, size_t bytes);
+// co-resident grid for persistent kernels: CUs x blocks_per_cu (TC_GRID_SCALE_PCT env scales it)
+u32 tc_persistent_grid(tc_ctx *ctx, int blocks_per_cu);
+// same, capped by what the occupancy query admits for this kernel/block size
+template <class K>
+static inline u32 tc_persistent_grid_for(tc_ctx *ctx, K kernel, int threads, int want_per_cu) {
+    int occ = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, kernel, threads, 0) != hipSuccess || occ < 1) {
+        (void)hipGetLastError();
+        occ = 1;
+    }
+    return tc_persistent_grid(ctx, occ < want_per_cu ? occ : want_per_cu);
+}
 void tc_sync_check(tc_ctx *ctx);  // stream sync + device error word check
 
 static inline u32 tc_cdiv(u64 a, u64 b) { return (u32)((a + b - 1) / b); }

@@ -129,6 +129,7 @@ static void sa_choose_config(tc_ctx *ctx, const u32 *counts, u64 n, SaConfig &c)
     if (P > pmax) P = pmax;
     c.P = P;
     c.h0 = P * c.s;
+    c.entropy = H;
 }
 
 // Builds SA (d_sa, N entries), last column (d_L, N bytes) and primary for the
@@ -159,45 +160,25 @@ static void sa_build(tc_ctx *ctx, Arena &A, const u8 *d_text, u64 n, u32 *d_sa, 
     SaConfig cfg;
     sa_choose_config(ctx, counts, n, cfg);
 
-    // 2. round-0 keys + digit histograms
-    RadixPlan plan;
-    plan.add_range(64 - (int)(cfg.P * cfg.w), 64);
-    KeyBuildParams kp;
-    kp.B = cfg.B; kp.w = cfg.w; kp.s = cfg.s; kp.P = cfg.P;
-    memcpy(kp.lut, cfg.lut, sizeof kp.lut);
-    kp.plan.npass = plan.npass;
-    for (int p = 0; p < plan.npass; p++) {
-        kp.plan.shift[p] = plan.shift[p];
-        kp.plan.mask[p] = plan.mask[p];
-    }
-    tc_memset_async(ctx, b.hist, 0, sizeof(u32) * RDX_MAX_PASSES * RDX_BINS);
-    keybuild_kernel<<<tc_cdiv(N, SA_TILE), SA_NT, 0, s>>>(d_text, (u32)n, kp, b.k0, b.hist);
-    TC_LAUNCH_CHECK(ctx);
-
-    // 3. radix sort; arrange the ping-pong so the SA lands in the wanted buffer
+    // 2. round-0 keys (+ digit histograms), radix sort, groups.
+    //    Fast path: sort only the top 8*G key bits globally, then finish_kernel orders the
+    //    (tiny, on high-entropy text) equal-prefix buckets by the remaining bits and emits
+    //    SA / L / the tied set.  Oversize buckets or a large tied set => the full path:
+    //    all P passes, group_kernel<INIT>, dense ISA if needed.
     u32 *va = d_sa ? d_sa : b.v1;
-    RadixBuffers rb;
-    rb.keys = b.k0; rb.keys_alt = b.k1;
-    if (plan.npass % 2 == 0) { rb.vals = va; rb.vals_alt = b.v0; }
-    else { rb.vals = b.v0; rb.vals_alt = va; }
-    rb.hist = b.hist;
-    rb.status = b.rstatus;
-    ctx->pev_used = 0;
-    radix_sort_pairs(ctx, rb, (u32)N, plan, /*gen_idx=*/true, /*hist_ready=*/true, /*timed=*/true);
-    u32 *sa = rb.vals;  // == va
-    u64 *skeys = rb.keys;
-
-    // 4. groups, last column, first active set
     const u32 gtiles = tc_cdiv(N, GRP_TILE);
-    auto run_group = [&](bool init, GroupArgs ga) {
+    auto run_group = [&](bool init, GroupArgs ga, u32 *sa_arr) {
         u32 tiles = tc_cdiv(ga.count, GRP_TILE);
         tc_memset_async(ctx, b.gstatus, 0, (2 * (size_t)gtiles + 4) * sizeof(u64));
-        ga.text = d_text; ga.sa = sa; ga.L = d_L;
+        ga.text = d_text; ga.sa = sa_arr; ga.L = d_L;
         ga.status_max = b.gstatus; ga.status_sum = b.gstatus + gtiles;
         ga.ticket = reinterpret_cast<u32 *>(b.gstatus + 2 * (size_t)gtiles);
         ga.scalars = ctx->d_scalars; ga.err = ctx->d_err;
-        if (init) group_kernel<true><<<tiles, GRP_NT, 0, s>>>(ga);
-        else group_kernel<false><<<tiles, GRP_NT, 0, s>>>(ga);
+        u32 grid = init ? tc_persistent_grid_for(ctx, group_kernel<true>, GRP_NT, 2)
+                        : tc_persistent_grid_for(ctx, group_kernel<false>, GRP_NT, 2);
+        if (grid > tiles) grid = tiles;
+        if (init) group_kernel<true><<<grid, GRP_NT, 0, s>>>(ga);
+        else group_kernel<false><<<grid, GRP_NT, 0, s>>>(ga);
         TC_LAUNCH_CHECK(ctx);
     };
     auto fetch_m = [&]() {
@@ -205,32 +186,121 @@ static void sa_build(tc_ctx *ctx, Arena &A, const u8 *d_text, u64 n, u32 *d_sa, 
         TC_HIP(ctx, hipStreamSynchronize(s));
         return ctx->h_scalars[1];
     };
-    tc_memset_async(ctx, ctx->d_scalars, 0, 8 * sizeof(u64));
-    GroupArgs g0 = {};
-    g0.keys = skeys; g0.count = (u32)N; g0.vals = sa;
-    g0.out_slot = b.act[0][0]; g0.out_idx = b.act[0][1]; g0.out_grp = b.act[0][2]; g0.out_tpos = b.act[0][3];
-    run_group(true, g0);
-    u64 m = fetch_m();
-    st.rounds = 1;
-    st.m[0] = N; st.key_bytes[0] = 8; st.passes[0] = (u32)plan.npass; st.h[0] = 0;
+    auto build_keys_and_sort = [&](const RadixPlan &plan, RadixBuffers &rb, bool sa_in_alt_at_end) {
+        KeyBuildParams kp;
+        kp.B = cfg.B; kp.w = cfg.w; kp.s = cfg.s; kp.P = cfg.P;
+        memcpy(kp.lut, cfg.lut, sizeof kp.lut);
+        kp.plan.npass = plan.npass;
+        for (int p = 0; p < plan.npass; p++) {
+            kp.plan.shift[p] = plan.shift[p];
+            kp.plan.mask[p] = plan.mask[p];
+        }
+        tc_memset_async(ctx, b.hist, 0, sizeof(u32) * RDX_MAX_PASSES * RDX_BINS);
+        keybuild_kernel<<<tc_cdiv(N, SA_TILE), SA_NT, 0, s>>>(d_text, (u32)n, kp, b.k0, b.hist);
+        TC_LAUNCH_CHECK(ctx);
+        // ping-pong arranged so that the sorted values land in `va` (or, when a finish
+        // pass follows, in the OTHER buffer so that the finish pass writes `va`)
+        rb.keys = b.k0; rb.keys_alt = b.k1;
+        const bool even = plan.npass % 2 == 0;
+        const bool start_in_va = sa_in_alt_at_end ? !even : even;
+        if (start_in_va) { rb.vals = va; rb.vals_alt = b.v0; }
+        else { rb.vals = b.v0; rb.vals_alt = va; }
+        rb.hist = b.hist;
+        rb.status = b.rstatus;
+        ctx->pev_used = 0;
+        radix_sort_pairs(ctx, rb, (u32)N, plan, /*gen_idx=*/true, /*hist_ready=*/true, /*timed=*/true);
+    };
+    const int rbits = ceil_log2_u64(N);
+    const int keybits = (int)(cfg.P * cfg.w);
+    u32 *sa = va;
+    const u64 *skeys = nullptr;
+    u64 m = 0;
+    bool have_groups = false;
+    tc_memset_async(ctx, ctx->d_scalars, 0, 16 * sizeof(u64));
+
+    if (env_int("TC_SA_FINISH", 1) != 0 && env_int("TC_SA_DENSE", 0) == 0) {
+        // global passes: enough top bits that an iid text of this entropy leaves ~4 suffixes
+        // per bucket, and few enough remaining bits for the finish pass (<= 32)
+        double e8 = cfg.w == 8 ? cfg.entropy * cfg.s : cfg.entropy * 8.0 / cfg.w;
+        int G = e8 > 1e-9 ? (int)ceil(((double)rbits - 2.0) / e8) : 64;
+        if (G < (keybits - 32 + 7) / 8) G = (keybits - 32 + 7) / 8;
+        if (G < 1) G = 1;
+        int forcedG = env_int("TC_SA_GLOBAL_PASSES", 0);
+        if (forcedG > 0) G = forcedG;
+        int topbits = 8 * G < keybits ? 8 * G : keybits;
+        if (keybits - topbits <= 32) {
+            RadixPlan plan;
+            plan.add_range(64 - topbits, 64);
+            RadixBuffers rb;
+            build_keys_and_sort(plan, rb, /*sa_in_alt_at_end=*/true);
+            u32 *counters = reinterpret_cast<u32 *>(ctx->d_scalars + 12);
+            FinishArgs fa;
+            fa.keys = rb.keys; fa.sa_in = rb.vals; fa.N = (u32)N; fa.tshift = 64 - topbits;
+            fa.sa_out = va; fa.L = d_L;
+            fa.out_slot = b.act[0][0]; fa.out_idx = b.act[0][1]; fa.out_grp = b.act[0][2];
+            fa.act_cap = (u32)N; fa.counters = counters;
+            const u32 waves = tc_cdiv(N, 64 * FIN_WPW);
+            finish_kernel<<<tc_cdiv(waves, FIN_NT / 64), FIN_NT, 0, s>>>(fa);
+            TC_LAUNCH_CHECK(ctx);
+            tc_d2h(ctx, &ctx->h_scalars[12], ctx->d_scalars + 12, sizeof(u64));
+            TC_HIP(ctx, hipStreamSynchronize(s));
+            const u32 fm = (u32)(ctx->h_scalars[12] & 0xffffffffu), over = (u32)(ctx->h_scalars[12] >> 32);
+            if (!over && fm <= b.sparse_cap - 1024) {
+                m = fm;
+                have_groups = true;
+                st.rounds = 1;
+                st.m[0] = N; st.key_bytes[0] = 8; st.passes[0] = (u32)plan.npass; st.h[0] = 0;
+                if (m > 0) {  // bring the tied set into SA order (refine relies on it)
+                    u32 mm = (u32)m;
+                    pack_active_kernel<<<tc_cdiv(mm, 256), 256, 0, s>>>(b.act[0][0], b.act[0][2], mm, b.sk[0]);
+                    TC_LAUNCH_CHECK(ctx);
+                    TC_HIP(ctx, hipMemcpyAsync(b.sv[0], b.act[0][1], mm * sizeof(u32), hipMemcpyDeviceToDevice, s));
+                    RadixPlan ps;
+                    ps.add_range(32, 32 + rbits);
+                    RadixBuffers rs;
+                    rs.keys = b.sk[0]; rs.keys_alt = b.sk[1]; rs.vals = b.sv[0]; rs.vals_alt = b.sv[1];
+                    rs.hist = b.hist; rs.status = b.rstatus;
+                    radix_sort_pairs(ctx, rs, mm, ps, false, false);
+                    unpack_active_kernel<<<tc_cdiv(mm, 256), 256, 0, s>>>(rs.keys, mm, b.act[0][0], b.act[0][2]);
+                    TC_LAUNCH_CHECK(ctx);
+                    TC_HIP(ctx, hipMemcpyAsync(b.act[0][1], rs.vals, mm * sizeof(u32), hipMemcpyDeviceToDevice, s));
+                }
+            }
+        }
+    }
+    if (!have_groups) {
+        RadixPlan plan;
+        plan.add_range(64 - keybits, 64);
+        RadixBuffers rb;
+        build_keys_and_sort(plan, rb, /*sa_in_alt_at_end=*/false);
+        skeys = rb.keys;
+        GroupArgs g0 = {};
+        g0.keys = skeys; g0.count = (u32)N; g0.vals = sa;
+        g0.out_slot = b.act[0][0]; g0.out_idx = b.act[0][1]; g0.out_grp = b.act[0][2]; g0.out_tpos = b.act[0][3];
+        run_group(true, g0, sa);
+        m = fetch_m();
+        st.rounds = 1;
+        st.m[0] = N; st.key_bytes[0] = 8; st.passes[0] = (u32)plan.npass; st.h[0] = 0;
+    }
 
     // 5. ranks: dense ISA when many suffixes are tied, else a sparse table of the tied
-    //    positions + binary search in the sorted round-0 keys for everything else
-    const int rbits = ceil_log2_u64(N);
+    //    positions + a search for everything else (sorted round-0 keys, or the SA itself)
     const bool dense = m > b.sparse_cap - 1024 || env_int("TC_SA_DENSE", 0) != 0;
     RankLookup rl = {};
     rl.text = d_text; rl.n = (u32)n; rl.N = (u32)N;
-    rl.B = cfg.B; rl.w = cfg.w; rl.s = cfg.s; rl.P = cfg.P;
+    rl.B = cfg.B; rl.w = cfg.w; rl.s = cfg.s; rl.P = cfg.P; rl.h0 = cfg.h0;
     memcpy(rl.lut, cfg.lut, sizeof rl.lut);
+    if (dense && !skeys) TC_FAIL(ctx, TC_ERR_INTERNAL, "dense mode needs the sorted keys");
     if (dense) {
         if (m > 0) {
-            GroupArgs gi = g0;
+            GroupArgs gi = {};
+            gi.keys = skeys; gi.count = (u32)N; gi.vals = sa;
             gi.isa = b.isa; gi.isa_only = 1;
-            run_group(true, gi);
+            run_group(true, gi, sa);
         }
         rl.isa = b.isa;
     } else {
-        rl.skeys = skeys; rl.t_idx = b.t_idx; rl.t_rank = b.t_rank; rl.t_n = (u32)m;
+        rl.skeys = skeys; rl.sa = sa; rl.t_idx = b.t_idx; rl.t_rank = b.t_rank; rl.t_n = (u32)m;
         if (m > 0) {
             u32 mm = (u32)m;
             widen_u32_kernel<<<tc_cdiv(mm, 256), 256, 0, s>>>(b.act[0][1], b.sk[0], mm);
@@ -272,7 +342,7 @@ static void sa_build(tc_ctx *ctx, Arena &A, const u8 *d_text, u64 n, u32 *d_sa, 
         gr.isa = dense ? b.isa : nullptr; gr.t_rank = dense ? nullptr : b.t_rank;
         gr.out_slot = b.act[cur ^ 1][0]; gr.out_idx = b.act[cur ^ 1][1];
         gr.out_grp = b.act[cur ^ 1][2]; gr.out_tpos = b.act[cur ^ 1][3];
-        run_group(false, gr);
+        run_group(false, gr, sa);
         st.m[st.rounds] = m; st.key_bytes[st.rounds] = 8; st.passes[st.rounds] = (u32)p2.npass;
         st.h[st.rounds] = hh;
         st.rounds++;
@@ -400,7 +470,9 @@ static void rle_encode_device(tc_ctx *ctx, Arena &A, Acc acc, u64 N, u32 *d_coun
     a.status_pair = status; a.status_sum = status + tiles;
     a.ticket = reinterpret_cast<u32 *>(status + 2 * (size_t)tiles);
     a.scalars = ctx->d_scalars; a.err = ctx->d_err;
-    rle_encode_kernel<Acc, SymT><<<tiles, RLE_NT, 0, ctx->stream>>>(acc, a);
+    u32 grid = tc_persistent_grid_for(ctx, rle_encode_kernel<Acc, SymT>, RLE_NT, 2);
+    if (grid > tiles) grid = tiles;
+    rle_encode_kernel<Acc, SymT><<<grid, RLE_NT, 0, ctx->stream>>>(acc, a);
     TC_LAUNCH_CHECK(ctx);
     tc_d2h(ctx, &ctx->h_scalars[2], ctx->d_scalars + 2, sizeof(u64));
     TC_HIP(ctx, hipStreamSynchronize(ctx->stream));

@@ -9,22 +9,38 @@
 // Replaces (together with tc_sa.hip) `DS.unstableSortOn snd` over the suffixes,
 // reference BWT/Internal.hs:130.
 #pragma once
+#include <stdlib.h>
+
 #include "tc_common.hpp"
 
 #define RDX_BITS 8
 #define RDX_BINS 256
-#define RDX_MAX_PASSES 12
+#define RDX_MAX_PASSES 16
+#ifndef RDX_NT
 #define RDX_NT 512
+#endif
+#ifndef RDX_ITEMS
 #define RDX_ITEMS 8
+#endif
 #define RDX_TILE (RDX_NT * RDX_ITEMS)
+#ifndef RDX_MINW
+#define RDX_MINW 6
+#endif
+#define RDX_LB_WAVES(persist) ((persist) ? 4 : RDX_MINW)
 
 struct RadixPlan {
     int npass = 0;
     int shift[RDX_MAX_PASSES];
     u32 mask[RDX_MAX_PASSES];
+    static int digit_bits() {  // TC_RADIX_DIGIT_BITS: fan-out experiment knob (default 8)
+        const char *e = getenv("TC_RADIX_DIGIT_BITS");
+        int v = e && *e ? atoi(e) : RDX_BITS;
+        return v < 1 ? 1 : (v > RDX_BITS ? RDX_BITS : v);
+    }
     void add_range(int lo_bit, int hi_bit) {  // passes over bits [lo_bit, hi_bit), LSD order
-        for (int b = lo_bit; b < hi_bit; b += RDX_BITS) {
-            int w = hi_bit - b < RDX_BITS ? hi_bit - b : RDX_BITS;
+        const int db = digit_bits();
+        for (int b = lo_bit; b < hi_bit; b += db) {
+            int w = hi_bit - b < db ? hi_bit - b : db;
             shift[npass] = b;
             mask[npass] = (1u << w) - 1u;
             npass++;
@@ -69,124 +85,292 @@ __global__ __launch_bounds__(256) void radix_scan_hist_kernel(u32 *hist) {
 }
 
 // ---- one pass ---------------------------------------------------------------
-template <bool GEN_IDX>
-__global__ __launch_bounds__(RDX_NT) void radix_pass_kernel(
+// PERSIST = false: one tile per block, tile id from an atomic ticket (a tile only
+//   ever waits on tiles whose blocks are already running).
+// PERSIST = true: each block draws ONE ticket k and processes tiles k, k+G, k+2G, ..
+//   (G = gridDim.x co-resident blocks), prefetching the next tile into registers.
+// LBB: status words fetched per look-back round trip.
+// SPLIT = true: no look-back at all -- per-tile digit offsets come from a scanned
+//   [tile][digit] matrix written by radix_tile_hist_kernel (classic 3-kernel pass).
+template <bool GEN_IDX, bool PERSIST, int LBB, bool SPLIT>
+__global__ __launch_bounds__(RDX_NT, RDX_LB_WAVES(PERSIST)) void radix_pass_kernel(
     const u64 *__restrict__ kin, const u32 *__restrict__ vin, u64 *__restrict__ kout,
     u32 *__restrict__ vout, u32 n, int shift, u32 mask, const u32 *__restrict__ bucket_base,
-    u64 *status, u32 *ticket, u32 *err) {
+    u64 *status, u32 *ticket, u32 *err, const u32 *__restrict__ tile_offs) {
     constexpr int NW = RDX_NT / 64;
-    __shared__ u64 s_keys[RDX_TILE];
-    __shared__ u32 s_vals[RDX_TILE];
-    __shared__ u32 s_hist[NW * RDX_BINS];
+    const int shift_raw = shift;
+    shift &= 0xff;
+    (void)shift_raw;
+    // staging area for the sorted tile; the per-wave histograms overlay its head (they
+    // are dead once every item's local position sits in a register): 48 KB + 2 KB => 3
+    // blocks per CU
+    __shared__ __attribute__((aligned(16))) unsigned char s_raw[RDX_TILE * 12];
+    u64 *s_keys = reinterpret_cast<u64 *>(s_raw);
+    u32 *s_vals = reinterpret_cast<u32 *>(s_raw + RDX_TILE * 8);
+    u32 *s_hist = reinterpret_cast<u32 *>(s_raw);
+    static_assert(NW * RDX_BINS * 4 <= RDX_TILE * 8, "histograms must fit under the key staging");
     __shared__ u32 s_dbase[RDX_BINS];
     __shared__ u32 s_gbase[RDX_BINS];
-    __shared__ u32 s_scan[8];
+    __shared__ u32 s_scan[RDX_NT / 64 + 1];
     __shared__ u32 s_tile;
 
     const int tid = threadIdx.x, w = tid >> 6, l = tid & 63;
-    if (tid == 0) s_tile = atomicAdd(ticket, 1u);
-    for (int i = tid; i < NW * RDX_BINS; i += RDX_NT) s_hist[i] = 0;
+    if (SPLIT) {
+        if (tid == 0) s_tile = blockIdx.x;
+    } else {
+        if (tid == 0) s_tile = atomicAdd(ticket, 1u);
+    }
     __syncthreads();
-    const u32 tile = s_tile;
-    const u64 base = (u64)tile * RDX_TILE;
-    const u32 valid = (n - base) < (u64)RDX_TILE ? (u32)(n - base) : (u32)RDX_TILE;
-
-    u64 key[RDX_ITEMS];
-    u32 val[RDX_ITEMS];
-    u32 rnk[RDX_ITEMS];
+    const u32 first = s_tile, G = PERSIST ? gridDim.x : 0x7fffffffu;
+    const u32 ntiles = (u32)(((u64)n + RDX_TILE - 1) / RDX_TILE);
     const u32 wofs = w * 64 * RDX_ITEMS;
-#pragma unroll
-    for (int k = 0; k < RDX_ITEMS; k++) {
-        u32 p = wofs + k * 64 + l;
-        if (p < valid) {
-            key[k] = kin[base + p];
-            val[k] = GEN_IDX ? (u32)(base + p) : vin[base + p];
-        } else {
-            key[k] = ~0ull;
-            val[k] = 0;
-        }
-    }
-    // stable ranking inside the wave, item by item
     u32 *wh = s_hist + w * RDX_BINS;
+
+    u64 key[RDX_ITEMS], nkey[RDX_ITEMS];
+    u32 val[RDX_ITEMS], nval[RDX_ITEMS];
+    auto load_tile = [&](u32 tile, u64 *kk, u32 *vv) {
+        const u64 base = (u64)tile * RDX_TILE;
 #pragma unroll
-    for (int k = 0; k < RDX_ITEMS; k++) {
-        u32 p = wofs + k * 64 + l;
-        u32 d = p < valid ? (u32)((key[k] >> shift) & mask) : 255u;  // pads: last digit, last
-        u64 m = ~0ull;
-#pragma unroll
-        for (int b = 0; b < RDX_BITS; b++) {
-            u64 bal = __ballot((d >> b) & 1u);
-            m &= ((d >> b) & 1u) ? bal : ~bal;
-        }
-        u32 old = wh[d];
-        u32 prior = __popcll(m & lanemask_lt());
-        __builtin_amdgcn_wave_barrier();
-        if (prior == 0) wh[d] = old + __popcll(m);
-        __builtin_amdgcn_wave_barrier();
-        rnk[k] = old + prior;
-    }
-    __syncthreads();
-    // digit totals, exclusive over waves; one owner thread per digit
-    u32 tot = 0;
-    if (tid < RDX_BINS) {
-#pragma unroll
-        for (int i = 0; i < NW; i++) {
-            u32 c = s_hist[i * RDX_BINS + tid];
-            s_hist[i * RDX_BINS + tid] = tot;
-            tot += c;
-        }
-    }
-    u32 tot_real = tot;
-    if (tid == 255) tot_real = tot - (RDX_TILE - valid);
-    u64 *st = status + (u64)tile * RDX_BINS + tid;
-    if (tid < RDX_BINS) lb_store(st, (tile == 0 ? LB_FLAG_INC : LB_FLAG_AGG) | (u64)tot_real);
-    u32 dtot;
-    u32 dbase = block_excl_sum<RDX_NT>(tid < RDX_BINS ? tot : 0u, s_scan, &dtot);
-    if (tid < RDX_BINS) {
-        u32 excl = 0;
-        if (tile > 0) {
-            i64 t = (i64)tile - 1;
-            u32 spins = 0;
-            while (true) {
-                u64 s = lb_load(status + (u64)t * RDX_BINS + tid);
-                u32 f = (u32)(s >> 62);
-                if (f == 0) {
-                    if (++spins > LB_SPIN_LIMIT) {
-                        atomicOr(err, 2u);
-                        break;
-                    }
-                    __builtin_amdgcn_s_sleep(1);
-                    continue;
-                }
-                excl += (u32)LB_VALUE(s);
-                if (f == 2) break;
-                t--;
+        for (int k = 0; k < RDX_ITEMS; k++) {
+            u64 g = base + wofs + k * 64 + l;
+            if (shift_raw & 0x800) {  // DIAGNOSTIC bit3: no global loads
+                kk[k] = (g * 0x9E3779B97F4A7C15ull) | 1ull;
+                vv[k] = (u32)g;
+            } else if (tile < ntiles && g < n) {
+                kk[k] = kin[g];
+                vv[k] = GEN_IDX ? (u32)g : vin[g];
+            } else {
+                kk[k] = ~0ull;
+                vv[k] = 0;
             }
-            lb_store(st, LB_FLAG_INC | (u64)(excl + tot_real));
         }
-        s_dbase[tid] = dbase;
-        s_gbase[tid] = bucket_base[tid] + excl - dbase;
+    };
+    load_tile(first, key, val);
+
+    for (u32 tile = first; tile < ntiles; tile += G) {
+        const u64 base = (u64)tile * RDX_TILE;
+        const u32 valid = (n - base) < (u64)RDX_TILE ? (u32)(n - base) : (u32)RDX_TILE;
+        if (PERSIST) load_tile(tile + G, nkey, nval);  // prefetch; consumed next iteration
+        for (int i = tid; i < NW * RDX_BINS; i += RDX_NT) s_hist[i] = 0;
+        __syncthreads();
+        // stable ranking inside the wave, item by item
+        u32 rnk[RDX_ITEMS];
+#pragma unroll
+        for (int k = 0; k < RDX_ITEMS; k++) {
+            u32 p = wofs + k * 64 + l;
+            u32 d = p < valid ? (u32)((key[k] >> shift) & mask) : 255u;  // pads: last digit, last
+            u64 m = ~0ull;
+            if (shift_raw & 0x100) {  // DIAGNOSTIC bit0 (timing only, wrong output): skip the match-any
+                m = 1ull << l;
+            } else {
+#pragma unroll
+                for (int b = 0; b < RDX_BITS; b++) {
+                    u64 bal = __ballot((d >> b) & 1u);
+                    m &= ((d >> b) & 1u) ? bal : ~bal;
+                }
+            }
+            u32 old = wh[d];
+            u32 prior = __popcll(m & lanemask_lt());
+            __builtin_amdgcn_wave_barrier();
+            if (prior == 0) wh[d] = old + __popcll(m);
+            __builtin_amdgcn_wave_barrier();
+            rnk[k] = old + prior;
+        }
+        __syncthreads();
+        // digit totals, exclusive over waves; one owner thread per digit
+        u32 tot = 0;
+        if (tid < RDX_BINS) {
+#pragma unroll
+            for (int i = 0; i < NW; i++) {
+                u32 c = s_hist[i * RDX_BINS + tid];
+                s_hist[i * RDX_BINS + tid] = tot;
+                tot += c;
+            }
+        }
+        u32 tot_real = tot;
+        if (tid == 255) tot_real = tot - (RDX_TILE - valid);
+        u64 *st = status + (u64)tile * RDX_BINS + tid;
+        if (!SPLIT && tid < RDX_BINS)
+            lb_store(st, (tile == 0 ? LB_FLAG_INC : LB_FLAG_AGG) | (u64)tot_real);
+        u32 dtot;
+        u32 dbase = block_excl_sum<RDX_NT>(tid < RDX_BINS ? tot : 0u, s_scan, &dtot);
+        if (tid < RDX_BINS) s_dbase[tid] = dbase;
+        __syncthreads();
+        // local sorted position of every item
+        u32 pos[RDX_ITEMS];
+#pragma unroll
+        for (int k = 0; k < RDX_ITEMS; k++) {
+            u32 p = wofs + k * 64 + l;
+            u32 d = p < valid ? (u32)((key[k] >> shift) & mask) : 255u;
+            pos[k] = s_dbase[d] + wh[d] + rnk[k];
+        }
+        if (tid < RDX_BINS) {
+            u32 excl = 0;
+            if (SPLIT) {
+                excl = tile_offs[(u64)tile * RDX_BINS + tid];  // already includes bucket base
+                s_gbase[tid] = excl - dbase;
+            } else {
+                if (tile > 0) {
+                    i64 t = (i64)tile - 1;
+                    u32 spins = 0;
+                    bool done = false;
+                    while (!done) {
+                        u64 sv[LBB];
+#pragma unroll
+                        for (int i = 0; i < LBB; i++) {
+                            i64 ti = t - i;
+                            sv[i] = ti >= 0 ? lb_load(status + (u64)ti * RDX_BINS + tid) : LB_FLAG_INC;
+                        }
+                        int consumed = LBB;
+#pragma unroll
+                        for (int i = 0; i < LBB; i++) {
+                            if (done || consumed != LBB) continue;
+                            u32 f = (u32)(sv[i] >> 62);
+                            if (f == 0) {  // not published yet: resume the walk from this tile
+                                consumed = i;
+                                if (++spins > LB_SPIN_LIMIT) {
+                                    atomicOr(err, 2u);
+                                    done = true;
+                                }
+                                continue;
+                            }
+                            excl += (u32)LB_VALUE(sv[i]);
+                            if (f == 2) done = true;
+                        }
+                        t -= consumed;
+                        if (consumed == 0) __builtin_amdgcn_s_sleep(1);
+                    }
+                    lb_store(st, LB_FLAG_INC | (u64)(excl + tot_real));
+                }
+                s_gbase[tid] = bucket_base[tid] + excl - dbase;
+            }
+        }
+        __syncthreads();
+        if (shift_raw & 0x200) {  // DIAGNOSTIC bit1: no LDS staging, plain coalesced copy-out
+#pragma unroll
+            for (int k = 0; k < RDX_ITEMS; k++) {
+                u32 p = wofs + k * 64 + l;
+                if (p < valid && (pos[k] != 0xffffffffu)) {
+                    kout[base + p] = key[k];
+                    vout[base + p] = val[k];
+                }
+            }
+        } else {
+#pragma unroll
+        for (int k = 0; k < RDX_ITEMS; k++) {
+            s_keys[pos[k]] = key[k];
+            s_vals[pos[k]] = val[k];
+        }
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < RDX_ITEMS; k++) {
+            u32 p = tid + k * RDX_NT;
+            if (p < valid) {
+                u64 kk = s_keys[p];
+                u32 d = (u32)((kk >> shift) & mask);
+                u32 g = s_gbase[d] + p;
+                if (!(shift_raw & 0x400) || kk == 0x123456789abcdefull) {  // DIAGNOSTIC bit2: no stores
+                    kout[g] = kk;
+                    vout[g] = s_vals[p];
+                }
+            }
+        }
+        }
+        if (PERSIST) {
+#pragma unroll
+            for (int k = 0; k < RDX_ITEMS; k++) {
+                key[k] = nkey[k];
+                val[k] = nval[k];
+            }
+            __syncthreads();
+        }
+    }
+}
+
+// SPLIT variant, kernel 1: per-tile digit counts -> matrix[digit][tile] (digit-major so
+// that one exclusive scan over the flat matrix yields every tile's bucket offset).
+__global__ __launch_bounds__(256) void radix_tile_hist_kernel(const u64 *__restrict__ keys, u32 n,
+                                                              int shift, u32 mask, u32 ntiles,
+                                                              u32 *__restrict__ matrix) {
+    __shared__ u32 s_h[4][RDX_BINS];
+    for (int i = threadIdx.x; i < 4 * RDX_BINS; i += 256) (&s_h[0][0])[i] = 0;
+    __syncthreads();
+    const u32 tile = blockIdx.x;
+    const u64 base = (u64)tile * RDX_TILE;
+    u32 *h = s_h[threadIdx.x >> 6];
+#pragma unroll 4
+    for (int k = 0; k < RDX_TILE / 256; k++) {
+        u64 g = base + k * 256 + threadIdx.x;
+        if (g < n) atomicAdd(&h[(u32)((keys[g] >> shift) & mask)], 1u);
     }
     __syncthreads();
-#pragma unroll
-    for (int k = 0; k < RDX_ITEMS; k++) {
-        u32 p = wofs + k * 64 + l;
-        u32 d = p < valid ? (u32)((key[k] >> shift) & mask) : 255u;
-        u32 pos = s_dbase[d] + wh[d] + rnk[k];
-        s_keys[pos] = key[k];
-        s_vals[pos] = val[k];
+    u32 c = s_h[0][threadIdx.x] + s_h[1][threadIdx.x] + s_h[2][threadIdx.x] + s_h[3][threadIdx.x];
+    matrix[(u64)threadIdx.x * ntiles + tile] = c;
+}
+// kernel 2a/2b/2c: exclusive scan of the flat u32 matrix (len = 256 * ntiles)
+__global__ __launch_bounds__(256) void scan32_reduce_kernel(const u32 *__restrict__ in, u64 len,
+                                                            u32 *__restrict__ part) {
+    __shared__ u32 s[4];
+    u64 base = (u64)blockIdx.x * 4096;
+    u32 v = 0;
+    for (int k = 0; k < 16; k++) {
+        u64 i = base + k * 256 + threadIdx.x;
+        if (i < len) v += in[i];
+    }
+    v = wave_sum(v);
+    if ((threadIdx.x & 63) == 0) s[threadIdx.x >> 6] = v;
+    __syncthreads();
+    if (threadIdx.x == 0) part[blockIdx.x] = s[0] + s[1] + s[2] + s[3];
+}
+__global__ __launch_bounds__(1024) void scan32_spine_kernel(u32 *part, u32 nparts) {
+    __shared__ u32 s_p[1024];
+    u32 per = (nparts + 1023) / 1024;
+    u32 lo = threadIdx.x * per, hi = lo + per < nparts ? lo + per : nparts;
+    u32 v = 0;
+    for (u32 t = lo; t < hi; t++) v += part[t];
+    s_p[threadIdx.x] = v;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        u32 run = 0;
+        for (int i = 0; i < 1024; i++) {
+            u32 c = s_p[i];
+            s_p[i] = run;
+            run += c;
+        }
     }
     __syncthreads();
-#pragma unroll
-    for (int k = 0; k < RDX_ITEMS; k++) {
-        u32 p = tid + k * RDX_NT;
-        if (p < valid) {
-            u64 kk = s_keys[p];
-            u32 d = (u32)((kk >> shift) & mask);
-            u32 g = s_gbase[d] + p;
-            kout[g] = kk;
-            vout[g] = s_vals[p];
+    u32 run = s_p[threadIdx.x];
+    for (u32 t = lo; t < hi; t++) {
+        u32 c = part[t];
+        part[t] = run;
+        run += c;
+    }
+}
+// matrix (digit-major) -> tile_offs[tile][digit] = exclusive prefix (global position)
+__global__ __launch_bounds__(256) void scan32_down_kernel(const u32 *__restrict__ in, u64 len,
+                                                          const u32 *__restrict__ part,
+                                                          u32 ntiles, u32 *__restrict__ tile_offs) {
+    __shared__ u32 s[4];
+    u64 base = (u64)blockIdx.x * 4096 + (u64)threadIdx.x * 16;
+    u32 v[16], tot = 0;
+    for (int k = 0; k < 16; k++) {
+        u64 i = base + k;
+        v[k] = i < len ? in[i] : 0;
+        tot += v[k];
+    }
+    u32 inc = wave_incl_sum(tot);
+    if ((threadIdx.x & 63) == 63) s[threadIdx.x >> 6] = inc;
+    __syncthreads();
+    u32 pre = part[blockIdx.x];
+    for (int i = 0; i < (int)(threadIdx.x >> 6); i++) pre += s[i];
+    u32 run = pre + inc - tot;
+    for (int k = 0; k < 16; k++) {
+        u64 i = base + k;
+        if (i < len) {
+            u32 digit = (u32)(i / ntiles), tile = (u32)(i % ntiles);
+            tile_offs[(u64)tile * RDX_BINS + digit] = run;
         }
+        run += v[k];
     }
 }
 
@@ -203,7 +387,10 @@ struct RadixBuffers {
     u32 *hist;    // [RDX_MAX_PASSES][256]
     u64 *status;  // [tiles*256 + 2]
 };
-static inline size_t radix_status_words(u64 n) { return (size_t)tc_cdiv(n, RDX_TILE) * RDX_BINS + 2; }
+static inline size_t radix_status_words(u64 n) {
+    size_t t = tc_cdiv(n, RDX_TILE);
+    return t * RDX_BINS + t / 8 + 64;  // look-back granules, or (split variant) matrix + offsets + partials
+}
 
 void radix_sort_pairs(tc_ctx *ctx, RadixBuffers &b, u32 n, const RadixPlan &plan, bool gen_idx,
                       bool hist_ready, bool timed = false);

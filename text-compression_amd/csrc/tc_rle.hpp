@@ -59,7 +59,7 @@ __device__ __forceinline__ RleFlags rle_flags(int xi, int xp, int xn, u64 j, u64
 }
 
 template <class Acc, class SymT>
-__global__ __launch_bounds__(RLE_NT) void rle_encode_kernel(Acc acc, RleArgs a) {
+__global__ __launch_bounds__(RLE_NT, 4) void rle_encode_kernel(Acc acc, RleArgs a) {
     constexpr int NW = RLE_NT / 64;
     __shared__ u32 s_wh[NW], s_wj[NW], s_ws[NW];
     __shared__ u64 s_pref[2];
@@ -67,9 +67,12 @@ __global__ __launch_bounds__(RLE_NT) void rle_encode_kernel(Acc acc, RleArgs a) 
     const int tid = threadIdx.x, w = tid >> 6, l = tid & 63;
     if (tid == 0) s_tile = atomicAdd(a.ticket, 1u);
     __syncthreads();
-    const u32 tile = s_tile;
-    const u64 base = (u64)tile * RLE_TILE + (u64)w * 64 * RLE_ITEMS;
     const u64 N = a.N;
+    const u32 ntiles = (u32)((N + RLE_TILE - 1) / RLE_TILE);
+    SymT *syms = reinterpret_cast<SymT *>(a.syms);
+    // persistent: one ticket per block, tiles strided by the (co-resident) grid
+    for (u32 tile = s_tile; tile < ntiles; tile += gridDim.x) {
+    const u64 base = (u64)tile * RLE_TILE + (u64)w * 64 * RLE_ITEMS;
 
     int x[RLE_ITEMS];
 #pragma unroll
@@ -134,7 +137,6 @@ __global__ __launch_bounds__(RLE_NT) void rle_encode_kernel(Acc acc, RleArgs a) 
     const u32 th = (u32)(s_pref[0] >> 31), tj = (u32)(s_pref[0] & 0x7fffffffu);
     u32 curH = ph > th ? ph : th, curJ = pj > tj ? pj : tj;
     u64 curE = s_pref[1] + ps;
-    SymT *syms = reinterpret_cast<SymT *>(a.syms);
 
     // ---- phase 2: emit ---------------------------------------------------------------
 #pragma unroll
@@ -165,6 +167,8 @@ __global__ __launch_bounds__(RLE_NT) void rle_encode_kernel(Acc acc, RleArgs a) 
         if (f.hb) curH = (u32)(jb0 + 63u - (u32)__builtin_clzll(f.hb)) + 1u;
         if (f.jb) curJ = (u32)(jb0 + 63u - (u32)__builtin_clzll(f.jb)) + 1u;
         curE += (u64)__popcll(f.ob) + (u64)__popcll(f.pb);
+    }
+    __syncthreads();  // LDS prefix slots are reused by the next tile
     }
 }
 

@@ -27,6 +27,7 @@ struct SaConfig {
     u32 s;           // symbols per field
     u32 P;           // fields sorted in round 0
     u32 h0;          // P * s
+    double entropy;  // bits per symbol of the byte histogram
     u16 lut[256];    // byte -> code (1..sigma_text), 0 if absent
 };
 
@@ -165,7 +166,7 @@ struct GroupArgs {
 };
 
 template <bool INIT>
-__global__ __launch_bounds__(GRP_NT) void group_kernel(GroupArgs a) {
+__global__ __launch_bounds__(GRP_NT, 4) void group_kernel(GroupArgs a) {
     constexpr int NW = GRP_NT / 64;
     __shared__ u32 s_wmax[NW], s_wsum[NW];
     __shared__ u64 s_pref[2];
@@ -173,10 +174,12 @@ __global__ __launch_bounds__(GRP_NT) void group_kernel(GroupArgs a) {
     const int tid = threadIdx.x, w = tid >> 6, l = tid & 63;
     if (tid == 0) s_tile = atomicAdd(a.ticket, 1u);
     __syncthreads();
-    const u32 tile = s_tile;
-    const u64 base = (u64)tile * GRP_TILE + (u64)w * 64 * GRP_ITEMS;
     const u64 KMASK = INIT ? ~0xffull : ~0ull;
     const u64 count = a.count;
+    const u32 ntiles = (u32)((count + GRP_TILE - 1) / GRP_TILE);
+    // persistent: one ticket per block, tiles strided by the (co-resident) grid
+    for (u32 tile = s_tile; tile < ntiles; tile += gridDim.x) {
+    const u64 base = (u64)tile * GRP_TILE + (u64)w * 64 * GRP_ITEMS;
 
     // ---- phase 1: head ballots, packed low bytes, wave aggregates -----------------
     u64 hb[GRP_ITEMS], ab[GRP_ITEMS];
@@ -311,6 +314,186 @@ __global__ __launch_bounds__(GRP_NT) void group_kernel(GroupArgs a) {
             }
         }
     }
+    __syncthreads();  // LDS prefix slots are reused by the next tile
+    }
+}
+
+// ---- finish: order the small buckets left by a partial (top-bits) sort -----------
+// Input: pairs sorted (stably) by the key bits >= tshift only.  Elements that agree on
+// those bits form a bucket; on high-entropy text buckets are tiny (1 GiB ACGTN, 32 top
+// bits = 12 symbols: ~4 suffixes on average).  Each wave owns the buckets that START in
+// its 64-position windows, ranks every member inside its bucket by the remaining key
+// bits (all-pairs within the bucket, through a small per-wave LDS image), and writes
+// SA / last column at the final positions.  Members whose whole key ties go to the
+// active set (unordered; the host sorts it by slot).  A bucket that does not end within
+// the next 64 positions raises `oversize`: the host then redoes the sort the long way.
+#define FIN_WPW 4      // windows per wave
+#define FIN_NT 256
+
+struct FinishArgs {
+    const u64 *keys;
+    const u32 *sa_in;
+    u32 N;
+    int tshift;        // bucket id = key >> tshift
+    u32 *sa_out;
+    u8 *L;
+    u32 *out_slot, *out_idx, *out_grp;
+    u32 act_cap;
+    u32 *counters;     // [0] active count, [1] oversize flag
+};
+
+__global__ __launch_bounds__(FIN_NT) void finish_kernel(FinishArgs a) {
+    __shared__ u32 s_low[FIN_NT / 64][128];
+    const int w = threadIdx.x >> 6, l = threadIdx.x & 63;
+    u32 *low = s_low[w];
+    const u64 N = a.N;
+    const u64 wave = (u64)blockIdx.x * (FIN_NT / 64) + w;
+    const u64 ws0 = wave * 64 * FIN_WPW;
+    if (ws0 >= N) return;
+    const u64 lowmask = ((1ull << a.tshift) - 1ull) & ~0xffull;  // remaining key bits, payload excluded
+
+    // chunk loader
+    auto ld_key = [&](u64 pos) -> u64 { return pos < N ? a.keys[pos] : ~0ull; };
+    auto ld_sa = [&](u64 pos) -> u32 { return pos < N ? a.sa_in[pos] : 0u; };
+    u64 kA = ld_key(ws0 + l);
+    u32 vA = ld_sa(ws0 + l);
+    u64 tprev = ws0 > 0 ? (a.keys[ws0 - 1] >> a.tshift) : 0;  // wave-uniform
+    bool hasprev = ws0 > 0;
+
+    for (int win = 0; win < FIN_WPW; win++) {
+        const u64 ws = ws0 + (u64)win * 64;
+        if (ws >= N) break;
+        u64 kB = ld_key(ws + 64 + l);
+        u32 vB = ld_sa(ws + 64 + l);
+        const bool inA = ws + l < N, inB = ws + 64 + l < N;
+        const u64 tA = kA >> a.tshift, tB = kB >> a.tshift;
+        // head flags
+        u64 upA = __shfl_up(tA, 1, 64);
+        u64 lastA = __shfl(tA, 63, 64);
+        u64 upB = __shfl_up(tB, 1, 64);
+        bool hA = inA && ((l == 0) ? (!hasprev || tA != tprev) : (tA != upA));
+        bool hB = inB && ((l == 0) ? (tB != lastA) : (tB != upB));
+        const u64 hbA = __ballot(hA), hbB = __ballot(hB);
+        const u64 inbA = __ballot(inA), inbB = __ballot(inB);
+        // ownership: A-lanes at or after the first head of A; B-lanes before the first head of B
+        // (they continue A's last bucket) -- provided A has a head at all
+        const int a0 = hbA ? __builtin_ctzll(hbA) : 64;
+        const int b0 = hbB ? __builtin_ctzll(hbB) : 64;
+        // the bucket running out of A must end inside B (a head in B, or the array ends there)
+        if (hbA && !hbB && (~inbB) == 0ull) {
+            // no head in a full B: the last bucket of A is longer than this kernel handles
+            if (l == 0) atomicOr(&a.counters[1], 1u);
+        }
+        const bool ownA = inA && l >= a0;
+        const bool ownB = inB && hbA && l < b0;
+        // bucket [s, t) in combined coordinates c = 0..127
+        u64 mleA = hbA & ((2ull << l) - 1ull);
+        int sA = mleA ? 63 - __builtin_clzll(mleA) : 0;            // start of my bucket (A lanes)
+        u64 mgtA = (l == 63) ? 0ull : (hbA & ~((2ull << l) - 1ull)); // heads after me in A
+        int endA_in_A = mgtA ? __builtin_ctzll(mgtA) : -1;
+        int lastHeadA = hbA ? 63 - __builtin_clzll(hbA) : 0;
+        // end of A's last bucket: first head of B, else the end of the array (valid
+        // positions are a prefix of the 128)
+        int endB = b0 < 64 ? 64 + b0 : (int)(__popcll(inbA) + __popcll(inbB));
+        int tAend = endA_in_A >= 0 ? endA_in_A : endB;
+        // A lanes: bucket [sA, tAend); B lanes (owned): bucket [lastHeadA, endB)
+        const u32 lowA = (u32)((kA & lowmask) >> 8), lowB = (u32)((kB & lowmask) >> 8);
+        low[l] = lowA;
+        low[64 + l] = lowB;
+        __builtin_amdgcn_wave_barrier();
+        int lenA = ownA ? tAend - sA : 0, lenB = ownB ? endB - lastHeadA : 0;
+        int maxlen = lenA > lenB ? lenA : lenB;
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) {
+            int o = __shfl_xor(maxlen, d, 64);
+            maxlen = maxlen > o ? maxlen : o;
+        }
+        // all-pairs ranking inside the bucket
+        u32 rankA = 0, ltA = 0, eqA = 0, rankB = 0, ltB = 0, eqB = 0;
+        const int cA = l, cB = 64 + l;
+        const int sB = lastHeadA, tBend = endB;
+        for (int d = 1; d < maxlen; d++) {
+            if (ownA) {
+                if (cA + d < tAend) {
+                    u32 y = low[cA + d];
+                    rankA += y < lowA; ltA += y < lowA; eqA += y == lowA;
+                }
+                if (cA - d >= sA) {
+                    u32 y = low[cA - d];
+                    rankA += y <= lowA; ltA += y < lowA; eqA += y == lowA;
+                }
+            }
+            if (ownB) {
+                if (cB + d < tBend) {
+                    u32 y = low[cB + d];
+                    rankB += y < lowB; ltB += y < lowB; eqB += y == lowB;
+                }
+                if (cB - d >= sB) {
+                    u32 y = low[cB - d];
+                    rankB += y <= lowB; ltB += y < lowB; eqB += y == lowB;
+                }
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+        // outputs
+        const bool actA = ownA && eqA > 0, actB = ownB && eqB > 0;
+        const u64 abA = __ballot(actA), abB = __ballot(actB);
+        const u32 nact = (u32)__popcll(abA) + (u32)__popcll(abB);
+        u32 abase = 0;
+        if (nact) {
+            if (l == 0) abase = atomicAdd(&a.counters[0], nact);
+            abase = __shfl(abase, 0, 64);
+        }
+        if (ownA) {
+            u32 j = (u32)(ws + sA) + rankA;
+            a.sa_out[j] = vA;
+            a.L[j] = (u8)(kA & 0xff);
+            if (actA) {
+                u32 o = abase + (u32)__popcll(abA & lanemask_lt());
+                if (o < a.act_cap) {
+                    a.out_slot[o] = j;
+                    a.out_idx[o] = vA;
+                    a.out_grp[o] = (u32)(ws + sA) + ltA;
+                }
+            }
+        }
+        if (ownB) {
+            u32 j = (u32)(ws + sB) + rankB;
+            a.sa_out[j] = vB;
+            a.L[j] = (u8)(kB & 0xff);
+            if (actB) {
+                u32 o = abase + (u32)__popcll(abA) + (u32)__popcll(abB & lanemask_lt());
+                if (o < a.act_cap) {
+                    a.out_slot[o] = j;
+                    a.out_idx[o] = vB;
+                    a.out_grp[o] = (u32)(ws + sB) + ltB;
+                }
+            }
+        }
+        // slide: B becomes the next window's A
+        tprev = lastA;
+        hasprev = true;
+        kA = kB;
+        vA = vB;
+    }
+}
+
+// active set arrives unordered from finish_kernel; refine needs it in SA order:
+// key = slot << 32 | grp, value = idx, sorted by the slot bits
+__global__ __launch_bounds__(256) void pack_active_kernel(const u32 *__restrict__ slot,
+                                                          const u32 *__restrict__ grp, u32 m,
+                                                          u64 *__restrict__ keys) {
+    u32 k = blockIdx.x * 256 + threadIdx.x;
+    if (k < m) keys[k] = ((u64)slot[k] << 32) | grp[k];
+}
+__global__ __launch_bounds__(256) void unpack_active_kernel(const u64 *__restrict__ keys, u32 m,
+                                                            u32 *__restrict__ slot,
+                                                            u32 *__restrict__ grp) {
+    u32 k = blockIdx.x * 256 + threadIdx.x;
+    if (k < m) {
+        slot[k] = (u32)(keys[k] >> 32);
+        grp[k] = (u32)keys[k];
+    }
 }
 
 // ---- rank of an arbitrary text position ----------------------------------------
@@ -322,12 +505,24 @@ struct RankLookup {
     const u32 *t_idx;    // sparse table
     const u32 *t_rank;
     u32 t_n;
-    const u64 *skeys;    // sorted round-0 keys (low byte = payload)
+    const u64 *skeys;    // sorted round-0 keys (low byte = payload), or null
+    const u32 *sa;       // the suffix array after round 0 (used when skeys is null)
     const u8 *text;
     u32 n, N;
     u32 B, w, s, P;
+    u32 h0;              // symbols covered by the round-0 key
     u16 lut[256];
 };
+
+// -1 / 0 / +1: first `h` symbols of suffix x vs suffix y (end of text sorts first)
+__device__ __forceinline__ int suffix_cmp(const u8 *text, u32 n, u64 x, u64 y, u32 h) {
+    for (u32 t = 0; t < h; t++, x++, y++) {
+        int cx = x < n ? (int)text[x] : -1, cy = y < n ? (int)text[y] : -1;
+        if (cx != cy) return cx < cy ? -1 : 1;
+        if (cx < 0) return 0;
+    }
+    return 0;
+}
 
 __device__ __forceinline__ u32 rank_of(const RankLookup &r, const u16 *s_lut, u64 p) {
     if (p >= r.N) return 0u;
@@ -339,6 +534,16 @@ __device__ __forceinline__ u32 rank_of(const RankLookup &r, const u16 *s_lut, u6
             if (r.t_idx[mid] < (u32)p) lo = mid + 1; else hi = mid;
         }
         if (lo < r.t_n && r.t_idx[lo] == (u32)p) return r.t_rank[lo];
+    }
+    if (!r.skeys) {
+        // suffix p was unique after round 0: its rank is its position in the SA, found by
+        // comparing the first h0 symbols against the suffixes the SA points at
+        u64 lo = 0, hi = r.N;
+        while (lo < hi) {
+            u64 mid = (lo + hi) >> 1;
+            if (suffix_cmp(r.text, r.n, r.sa[mid], p, r.h0) < 0) lo = mid + 1; else hi = mid;
+        }
+        return (u32)lo;
     }
     // round-0 key of suffix p, straight from the text
     u64 key = 0;

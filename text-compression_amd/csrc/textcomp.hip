@@ -4,6 +4,7 @@
 #include "tc_encode_host.hpp"
 #include "tc_decode_host.hpp"
 #include "tc_fm_host.hpp"
+#include "textcomp_debug.h"
 
 // ================================================================== context
 void tc_ws_reserve(tc_ctx *ctx, size_t bytes) {
@@ -25,6 +26,12 @@ void tc_ws_reserve(tc_ctx *ctx, size_t bytes) {
         TC_FAIL(ctx, TC_ERR_OOM, "workspace of %zu bytes: %s", bytes, hipGetErrorString(e));
     }
     ctx->ws_cap = want;
+}
+
+u32 tc_persistent_grid(tc_ctx *ctx, int blocks_per_cu) {
+    int pct = env_int("TC_GRID_SCALE_PCT", 100);
+    u64 g = (u64)ctx->num_cus * (u64)blocks_per_cu * (u64)pct / 100;
+    return g < 1 ? 1u : (u32)g;
 }
 
 void tc_sync_check(tc_ctx *ctx) {
@@ -210,6 +217,65 @@ static void rle_decode_host(tc_ctx *ctx, const u32 *counts, const SymT *syms, u6
     tc_sync_check(ctx);
 }
 
+// ------------------------------------------------------------ calibration kernels
+template <class T>
+__global__ __launch_bounds__(256) void dbg_stream_kernel(const T *__restrict__ in, T *__restrict__ out,
+                                                         u64 count, int mode, u32 *sink) {
+    u64 i = (u64)blockIdx.x * 256 + threadIdx.x;
+    const u64 stride = (u64)gridDim.x * 256;
+    if (mode == 0) {
+        for (; i < count; i += stride) out[i] = in[i];
+    } else if (mode == 1) {
+        u32 acc = 0;
+        for (; i < count; i += stride) {
+            T v = in[i];
+            const unsigned char *p = reinterpret_cast<const unsigned char *>(&v);
+            acc += p[0];
+        }
+        if (acc == 0x12345678u) *sink = acc;
+    } else {
+        T v;
+        memset(&v, 7, sizeof(T));
+        for (; i < count; i += stride) out[i] = v;
+    }
+}
+template <class T>
+static double dbg_stream_run(tc_ctx *ctx, char *a, char *b, u64 bytes, int mode, int iters) {
+    const u64 count = bytes / sizeof(T);
+    u32 grid = tc_cdiv(count, 256 * 8);
+    if (grid > 256u * 16u * 4u) grid = 256u * 16u * 4u;
+    hipStream_t s = ctx->stream;
+    dbg_stream_kernel<T><<<grid, 256, 0, s>>>((const T *)a, (T *)b, count, mode, ctx->d_err + 8);
+    TC_LAUNCH_CHECK(ctx);
+    TC_HIP(ctx, hipEventRecord(ctx->ev[6], s));
+    for (int i = 0; i < iters; i++)
+        dbg_stream_kernel<T><<<grid, 256, 0, s>>>((const T *)a, (T *)b, count, mode, ctx->d_err + 8);
+    TC_HIP(ctx, hipEventRecord(ctx->ev[7], s));
+    TC_HIP(ctx, hipStreamSynchronize(s));
+    float ms = 0;
+    TC_HIP(ctx, hipEventElapsedTime(&ms, ctx->ev[6], ctx->ev[7]));
+    double moved = (double)count * sizeof(T) * (mode == 0 ? 2.0 : 1.0) * iters;
+    return moved / (ms * 1e-3) / 1e9;
+}
+
+__global__ __launch_bounds__(256) void dbg_random_keys_kernel(u64 *keys, u64 n, u64 seed, int key_bits) {
+    for (u64 i = (u64)blockIdx.x * 256 + threadIdx.x; i < n; i += (u64)gridDim.x * 256) {
+        u64 z = seed + (i + 1) * 0x9E3779B97F4A7C15ull;
+        z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+        z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+        z = z ^ (z >> 31);
+        keys[i] = (z << (64 - key_bits)) | (i & 0xff);
+    }
+}
+// sorted by the top bits, and stable: equal keys keep increasing values
+__global__ __launch_bounds__(256) void dbg_check_sorted_kernel(const u64 *keys, const u32 *vals, u64 n,
+                                                               int key_bits, u32 *bad) {
+    for (u64 i = (u64)blockIdx.x * 256 + threadIdx.x; i + 1 < n; i += (u64)gridDim.x * 256) {
+        u64 a = keys[i] >> (64 - key_bits), b = keys[i + 1] >> (64 - key_bits);
+        if (a > b || (a == b && vals[i] >= vals[i + 1])) atomicAdd(bad, 1u);
+    }
+}
+
 extern "C" {
 
 const char *tc_version(void) { return "textcomp-amd 0.1 (gfx950)"; }
@@ -227,6 +293,11 @@ int tc_ctx_create(int device, tc_ctx **out) {
     ctx->device = device;
     try {
         TC_HIP(ctx, hipSetDevice(device));
+        {
+            hipDeviceProp_t prop;
+            TC_HIP(ctx, hipGetDeviceProperties(&prop, device));
+            ctx->num_cus = prop.multiProcessorCount;
+        }
         TC_HIP(ctx, hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking));
         TC_HIP(ctx, hipMalloc((void **)&ctx->d_err, 256));
         TC_HIP(ctx, hipMalloc((void **)&ctx->d_scalars, 64 * sizeof(u64)));
@@ -686,6 +757,82 @@ int tc_fm_info(const tc_fm *fm, uint64_t *N, uint32_t *sigma, int16_t *c_sym, ui
     }
     if (sigma) *sigma = sg;
     return TC_OK;
+}
+
+
+int tc_dbg_stream_bench(tc_ctx *ctx, uint64_t bytes, int width, int mode, int iters, double *gbps) {
+    TC_API_BEGIN(ctx)
+    if (!gbps || bytes < 4096 || iters < 1 || mode < 0 || mode > 2) TC_FAIL(ctx, TC_ERR_ARG, "bad argument");
+    tc_ws_reserve(ctx, 2 * bytes + 512);
+    char *a = ctx->ws, *b = ctx->ws + ((bytes + 255) & ~(u64)255);
+    tc_memset_async(ctx, a, 1, bytes);
+    switch (width) {
+        case 1: *gbps = dbg_stream_run<u8>(ctx, a, b, bytes, mode, iters); break;
+        case 2: *gbps = dbg_stream_run<u16>(ctx, a, b, bytes, mode, iters); break;
+        case 4: *gbps = dbg_stream_run<u32>(ctx, a, b, bytes, mode, iters); break;
+        case 8: *gbps = dbg_stream_run<u64>(ctx, a, b, bytes, mode, iters); break;
+        case 16: *gbps = dbg_stream_run<uint4>(ctx, a, b, bytes, mode, iters); break;
+        default: TC_FAIL(ctx, TC_ERR_ARG, "width must be 1, 2, 4, 8 or 16");
+    }
+    TC_API_END(ctx)
+}
+
+
+int tc_dbg_sort_bench(tc_ctx *ctx, uint64_t n, int key_bits, int iters, int check, double *ms_per_pass) {
+    TC_API_BEGIN(ctx)
+    if (!ms_per_pass || n < 2 || n > TC_MAX_N || key_bits < 1 || key_bits > 56 || iters < 1)
+        TC_FAIL(ctx, TC_ERR_ARG, "bad argument");
+    RadixBuffers b;
+    u64 *src = nullptr;
+    u32 *bad = nullptr;
+    auto carve = [&](Arena &A) {
+        src = A.get<u64>(n);
+        b.keys = A.get<u64>(n); b.keys_alt = A.get<u64>(n);
+        b.vals = A.get<u32>(n); b.vals_alt = A.get<u32>(n);
+        b.hist = A.get<u32>(RDX_MAX_PASSES * RDX_BINS);
+        b.status = A.get<u64>(radix_status_words(n));
+        bad = A.get<u32>(64);
+    };
+    Arena dry(nullptr);
+    carve(dry);
+    tc_ws_reserve(ctx, dry.off);
+    Arena A(ctx->ws);
+    carve(A);
+    hipStream_t s = ctx->stream;
+    dbg_random_keys_kernel<<<4096, 256, 0, s>>>(src, n, 0x5EEDull, key_bits);
+    TC_LAUNCH_CHECK(ctx);
+    RadixPlan plan;
+    plan.add_range(64 - key_bits, 64);
+    double total = 0;
+    int launches = 0;
+    const int saved = ctx->profile;
+    ctx->profile = 1;
+    for (int it = 0; it < iters + 1; it++) {
+        RadixBuffers r = b;
+        TC_HIP(ctx, hipMemcpyAsync(r.keys, src, n * sizeof(u64), hipMemcpyDeviceToDevice, s));
+        ctx->pev_used = 0;
+        radix_sort_pairs(ctx, r, (u32)n, plan, true, false, true);
+        TC_HIP(ctx, hipStreamSynchronize(s));
+        if (it > 0)
+            for (int i = 0; i < ctx->pev_used; i++) {
+                float ms = 0;
+                TC_HIP(ctx, hipEventElapsedTime(&ms, ctx->pev[2 * i], ctx->pev[2 * i + 1]));
+                total += ms;
+                launches++;
+            }
+        if (check && it == iters) {
+            tc_memset_async(ctx, bad, 0, 256);
+            dbg_check_sorted_kernel<<<4096, 256, 0, s>>>(r.keys, r.vals, n, key_bits, bad);
+            TC_LAUNCH_CHECK(ctx);
+            tc_d2h(ctx, &ctx->h_scalars[10], bad, sizeof(u32));
+            TC_HIP(ctx, hipStreamSynchronize(s));
+            if ((u32)ctx->h_scalars[10]) { ctx->profile = saved; TC_FAIL(ctx, TC_ERR_INTERNAL, "sort check: %u inversions", (u32)ctx->h_scalars[10]); }
+        }
+    }
+    ctx->profile = saved;
+    *ms_per_pass = launches ? total / launches : 0;
+    tc_sync_check(ctx);
+    TC_API_END(ctx)
 }
 
 }  // extern "C"
