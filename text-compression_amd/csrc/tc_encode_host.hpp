@@ -222,7 +222,7 @@ static void sa_build(tc_ctx *ctx, Arena &A, const u8 *d_text, u64 n, u32 *d_sa, 
         // global passes: enough top bits that an iid text of this entropy leaves ~4 suffixes
         // per bucket, and few enough remaining bits for the finish pass (<= 32)
         double e8 = cfg.w == 8 ? cfg.entropy * cfg.s : cfg.entropy * 8.0 / cfg.w;
-        int G = e8 > 1e-9 ? (int)ceil(((double)rbits - 2.0) / e8) : 64;
+        int G = e8 > 1e-9 ? (int)ceil((log2((double)N) - 4.0) / e8) : 64;  // ~16 suffixes per bucket at most
         if (G < (keybits - 32 + 7) / 8) G = (keybits - 32 + 7) / 8;
         if (G < 1) G = 1;
         int forcedG = env_int("TC_SA_GLOBAL_PASSES", 0);
@@ -236,6 +236,7 @@ static void sa_build(tc_ctx *ctx, Arena &A, const u8 *d_text, u64 n, u32 *d_sa, 
             u32 *counters = reinterpret_cast<u32 *>(ctx->d_scalars + 12);
             FinishArgs fa;
             fa.keys = rb.keys; fa.sa_in = rb.vals; fa.N = (u32)N; fa.tshift = 64 - topbits;
+            fa.lshift = 64 - keybits; fa.lbits = keybits - topbits;
             fa.sa_out = va; fa.L = d_L;
             fa.out_slot = b.act[0][0]; fa.out_idx = b.act[0][1]; fa.out_grp = b.act[0][2];
             fa.act_cap = (u32)N; fa.counters = counters;

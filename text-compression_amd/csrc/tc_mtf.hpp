@@ -32,6 +32,11 @@ struct U16Acc {  // plain integers (MTF index stream); never Nothing
     const u16 *v;
     __device__ __forceinline__ int operator()(u64 j) const { return (int)v[j]; }
 };
+// value of a staged int16 slot as the accessor would have returned it
+template <class Acc>
+__device__ __forceinline__ int staged_value(i16 raw) { return (int)raw; }
+template <>
+__device__ __forceinline__ int staged_value<U16Acc>(i16 raw) { return (int)(u16)raw; }
 
 #define MTF_NT 256
 #define MTF_CH 64                       // symbols per lane chunk (nibble path)
@@ -44,6 +49,60 @@ struct Lut16 { u16 v[260]; };
 struct SymTab { i16 v[260]; };  // code -> sym
 
 #ifdef __HIPCC__
+
+// Stage COUNT symbols starting at position `base` into LDS as int16 (-1 = Nothing, -2 =
+// past the end) with the widest loads the source allows (narrow per-lane loads run at a
+// fraction of the HBM rate on gfx950: 1 B/lane ~1.2 TB/s, 2 B ~2.2, 8-16 B ~5.5).
+template <int COUNT, int NT>
+__device__ __forceinline__ void stage_syms(const BwtAcc &acc, u64 base, u64 N, i16 *dst) {
+    const u8 *src = acc.L + base;
+    if ((((uintptr_t)src) & 15) == 0) {
+        for (int c = threadIdx.x; c < COUNT / 16; c += NT) {
+            u64 p = base + (u64)c * 16;
+            if (p + 16 <= N) {
+                uint4 v = *reinterpret_cast<const uint4 *>(src + (u64)c * 16);
+                u32 x[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+                for (int q = 0; q < 16; q++) dst[c * 16 + q] = (i16)((x[q >> 2] >> (8 * (q & 3))) & 0xff);
+            } else {
+                for (int q = 0; q < 16; q++) dst[c * 16 + q] = (p + q < N) ? (i16)src[(u64)c * 16 + q] : (i16)-2;
+            }
+        }
+    } else {
+        for (int c = threadIdx.x; c < COUNT; c += NT) dst[c] = (base + c < N) ? (i16)src[c] : (i16)-2;
+    }
+    __syncthreads();
+    if (acc.primary >= (i64)base && acc.primary < (i64)(base + COUNT) && threadIdx.x == 0)
+        dst[acc.primary - (i64)base] = -1;
+    __syncthreads();
+}
+template <int COUNT, int NT, class T16>
+__device__ __forceinline__ void stage_syms16(const T16 *srcbase, u64 base, u64 N, i16 *dst) {
+    const T16 *src = srcbase + base;
+    if ((((uintptr_t)src) & 15) == 0) {
+        for (int c = threadIdx.x; c < COUNT / 8; c += NT) {
+            u64 p = base + (u64)c * 8;
+            if (p + 8 <= N) {
+                uint4 v = *reinterpret_cast<const uint4 *>(src + (u64)c * 8);
+                *reinterpret_cast<uint4 *>(dst + c * 8) = v;
+            } else {
+                for (int q = 0; q < 8; q++) dst[c * 8 + q] = (p + q < N) ? (i16)src[(u64)c * 8 + q] : (i16)-2;
+            }
+        }
+    } else {
+        for (int c = threadIdx.x; c < COUNT; c += NT) dst[c] = (base + c < N) ? (i16)src[c] : (i16)-2;
+    }
+    __syncthreads();
+}
+template <int COUNT, int NT>
+__device__ __forceinline__ void stage_syms(const SymAcc &acc, u64 base, u64 N, i16 *dst) {
+    stage_syms16<COUNT, NT, i16>(acc.s, base, N, dst);
+}
+template <int COUNT, int NT>
+__device__ __forceinline__ void stage_syms(const U16Acc &acc, u64 base, u64 N, i16 *dst) {
+    // raw 16-bit image; read back through staged_value<U16Acc> (unsigned)
+    stage_syms16<COUNT, NT, u16>(acc.v, base, N, dst);
+}
 
 // presence histogram over an accessor (standalone MTF / RLE / FM entry points)
 template <class Acc>
@@ -95,12 +154,12 @@ __device__ __forceinline__ NibSumm nib_shfl_up(NibSumm v, int d) {
 // Stage one tile of codes into LDS (chunk-major, padded) and return this lane's
 // chunk summary (from the identity list).  0xFF marks padding past N.
 template <class Acc>
-__device__ __forceinline__ void nib_stage(Acc acc, u64 N, u64 base, const u8 *s_lut, u8 *s_code) {
+__device__ __forceinline__ void nib_stage(Acc acc, u64 N, u64 base, const u8 *s_lut, u8 *s_code,
+                                          i16 *s_sym) {
+    stage_syms<MTF_TILE, MTF_NT>(acc, base, N, s_sym);
     for (u32 p = threadIdx.x; p < MTF_TILE; p += MTF_NT) {
-        u64 j = base + p;
-        u8 c = 0xFF;
-        if (j < N) c = s_lut[acc(j) + 1];
-        s_code[(p / MTF_CH) * MTF_STRIDE + (p % MTF_CH)] = c;
+        int v = s_sym[p];
+        s_code[(p / MTF_CH) * MTF_STRIDE + (p % MTF_CH)] = v == -2 ? (u8)0xFF : s_lut[v + 1];
     }
 }
 
@@ -151,11 +210,12 @@ __global__ __launch_bounds__(MTF_NT) void mtf_nib_summary_kernel(Acc acc, u64 N,
                                                                   u64 *__restrict__ t_perm,
                                                                   u32 *__restrict__ t_mask) {
     __shared__ u8 s_code[MTF_NT * MTF_STRIDE];
+    __shared__ __attribute__((aligned(16))) i16 s_sym[MTF_TILE];
     __shared__ u8 s_lut[260];
     __shared__ NibSumm s_w[MTF_NT / 64];
     for (int i = threadIdx.x; i < 257; i += MTF_NT) s_lut[i] = lut.v[i];
     __syncthreads();
-    nib_stage(acc, N, (u64)blockIdx.x * MTF_TILE, s_lut, s_code);
+    nib_stage(acc, N, (u64)blockIdx.x * MTF_TILE, s_lut, s_code, s_sym);
     __syncthreads();
     NibSumm mine = nib_chunk_summary(s_code);
     NibSumm agg;
@@ -194,12 +254,13 @@ __global__ __launch_bounds__(MTF_NT) void mtf_nib_apply_kernel(Acc acc, u64 N,
                                                                 const u64 *__restrict__ t_perm,
                                                                 u16 *__restrict__ idx) {
     __shared__ u8 s_code[MTF_NT * MTF_STRIDE];
+    __shared__ __attribute__((aligned(16))) i16 s_sym[MTF_TILE];
     __shared__ u8 s_lut[260];
     __shared__ NibSumm s_w[MTF_NT / 64];
     for (int i = threadIdx.x; i < 257; i += MTF_NT) s_lut[i] = lut.v[i];
     __syncthreads();
     const u64 base = (u64)blockIdx.x * MTF_TILE;
-    nib_stage(acc, N, base, s_lut, s_code);
+    nib_stage(acc, N, base, s_lut, s_code, s_sym);
     __syncthreads();
     NibSumm mine = nib_chunk_summary(s_code);
     NibSumm agg;
@@ -225,9 +286,18 @@ __global__ __launch_bounds__(MTF_NT) void mtf_nib_apply_kernel(Acc acc, u64 N,
         cw[q] = ov;  // indices overwrite the codes in place
     }
     __syncthreads();
-    for (u32 p = threadIdx.x; p < MTF_TILE; p += MTF_NT) {
-        u64 j = base + p;
-        if (j < N) idx[j] = (u16)s_code[(p / MTF_CH) * MTF_STRIDE + (p % MTF_CH)];
+    for (u32 p = threadIdx.x; p < MTF_TILE; p += MTF_NT)
+        s_sym[p] = (i16)s_code[(p / MTF_CH) * MTF_STRIDE + (p % MTF_CH)];
+    __syncthreads();
+    if ((((uintptr_t)(idx + base)) & 15) == 0) {
+        for (u32 c = threadIdx.x; c < MTF_TILE / 8; c += MTF_NT) {
+            u64 j = base + (u64)c * 8;
+            if (j + 8 <= N) *reinterpret_cast<uint4 *>(idx + j) = *reinterpret_cast<const uint4 *>(s_sym + c * 8);
+            else for (int q = 0; q < 8; q++) if (j + q < N) idx[j + q] = (u16)s_sym[c * 8 + q];
+        }
+    } else {
+        for (u32 p = threadIdx.x; p < MTF_TILE; p += MTF_NT)
+            if (base + p < N) idx[base + p] = (u16)s_sym[p];
     }
 }
 

@@ -64,6 +64,7 @@ __global__ __launch_bounds__(RLE_NT, 4) void rle_encode_kernel(Acc acc, RleArgs 
     __shared__ u32 s_wh[NW], s_wj[NW], s_ws[NW];
     __shared__ u64 s_pref[2];
     __shared__ u32 s_tile;
+    __shared__ __attribute__((aligned(16))) i16 s_x[RLE_TILE];
     const int tid = threadIdx.x, w = tid >> 6, l = tid & 63;
     if (tid == 0) s_tile = atomicAdd(a.ticket, 1u);
     __syncthreads();
@@ -74,12 +75,10 @@ __global__ __launch_bounds__(RLE_NT, 4) void rle_encode_kernel(Acc acc, RleArgs 
     for (u32 tile = s_tile; tile < ntiles; tile += gridDim.x) {
     const u64 base = (u64)tile * RLE_TILE + (u64)w * 64 * RLE_ITEMS;
 
+    stage_syms<RLE_TILE, RLE_NT>(acc, (u64)tile * RLE_TILE, N, s_x);
     int x[RLE_ITEMS];
 #pragma unroll
-    for (int k = 0; k < RLE_ITEMS; k++) {
-        u64 j = base + k * 64 + l;
-        x[k] = j < N ? acc(j) : -2;
-    }
+    for (int k = 0; k < RLE_ITEMS; k++) x[k] = staged_value<Acc>(s_x[w * 64 * RLE_ITEMS + k * 64 + l]);
     int xprev0 = -2, xnextT = -2;  // neighbours of the wave segment (wave-uniform loads)
     if (base > 0 && base <= N) xprev0 = acc(base - 1);
     if (base + (u64)64 * RLE_ITEMS < N) xnextT = acc(base + (u64)64 * RLE_ITEMS);

@@ -335,6 +335,7 @@ struct FinishArgs {
     const u32 *sa_in;
     u32 N;
     int tshift;        // bucket id = key >> tshift
+    int lshift, lbits; // remaining key bits = (key >> lshift) & ((1 << lbits) - 1), lbits <= 32
     u32 *sa_out;
     u8 *L;
     u32 *out_slot, *out_idx, *out_grp;
@@ -350,7 +351,7 @@ __global__ __launch_bounds__(FIN_NT) void finish_kernel(FinishArgs a) {
     const u64 wave = (u64)blockIdx.x * (FIN_NT / 64) + w;
     const u64 ws0 = wave * 64 * FIN_WPW;
     if (ws0 >= N) return;
-    const u64 lowmask = ((1ull << a.tshift) - 1ull) & ~0xffull;  // remaining key bits, payload excluded
+    const u64 lowmask = a.lbits >= 64 ? ~0ull : ((1ull << a.lbits) - 1ull);  // remaining key bits
 
     // chunk loader
     auto ld_key = [&](u64 pos) -> u64 { return pos < N ? a.keys[pos] : ~0ull; };
@@ -397,7 +398,7 @@ __global__ __launch_bounds__(FIN_NT) void finish_kernel(FinishArgs a) {
         int endB = b0 < 64 ? 64 + b0 : (int)(__popcll(inbA) + __popcll(inbB));
         int tAend = endA_in_A >= 0 ? endA_in_A : endB;
         // A lanes: bucket [sA, tAend); B lanes (owned): bucket [lastHeadA, endB)
-        const u32 lowA = (u32)((kA & lowmask) >> 8), lowB = (u32)((kB & lowmask) >> 8);
+        const u32 lowA = (u32)((kA >> a.lshift) & lowmask), lowB = (u32)((kB >> a.lshift) & lowmask);
         low[l] = lowA;
         low[64 + l] = lowB;
         __builtin_amdgcn_wave_barrier();
