@@ -34,6 +34,7 @@ struct tc_ctx {
     hipEvent_t pev[2 * 16] = {};  // per-pass event pairs (profile mode)
     int profile = 0;
     int num_cus = 0;
+    int safe_tickets = 0;  // set after a look-back spin overflow: single ticket counter
     int pev_used = 0;
     std::string err;
     tc_stats stats = {};

@@ -135,12 +135,33 @@ static void sa_choose_config(tc_ctx *ctx, const u32 *counts, u64 n, SaConfig &c)
 // Builds SA (d_sa, N entries), last column (d_L, N bytes) and primary for the
 // device text.  d_sa may be null (workspace buffer used).  counts256_out (host,
 // optional) receives the byte histogram.
+static void sa_run(tc_ctx *ctx, SaBuffers &b, const u8 *d_text, u64 n, u32 *d_sa, u8 *d_L,
+                   u64 *primary, u32 *counts256_out);
+
 static void sa_build(tc_ctx *ctx, Arena &A, const u8 *d_text, u64 n, u32 *d_sa, u8 *d_L,
                      u64 *primary, u32 *counts256_out, bool dry) {
     const u64 N = n + 1;
     SaBuffers b;
     sa_carve(A, N, b, d_sa == nullptr);
     if (dry) return;
+    sa_run(ctx, b, d_text, n, d_sa, d_L, primary, counts256_out);
+    // The sharded tile tickets of the radix pass assume blocks start in roughly increasing
+    // blockIdx order; if a bounded look-back spin tripped, redo with the single counter.
+    if (!ctx->safe_tickets) {
+        TC_HIP(ctx, hipMemcpyAsync(&ctx->h_scalars[62], ctx->d_err, sizeof(u32), hipMemcpyDeviceToHost,
+                                   ctx->stream));
+        TC_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        if ((u32)ctx->h_scalars[62] & 2u) {
+            tc_memset_async(ctx, ctx->d_err, 0, sizeof(u32));
+            ctx->safe_tickets = 1;
+            sa_run(ctx, b, d_text, n, d_sa, d_L, primary, counts256_out);
+        }
+    }
+}
+
+static void sa_run(tc_ctx *ctx, SaBuffers &b, const u8 *d_text, u64 n, u32 *d_sa, u8 *d_L,
+                   u64 *primary, u32 *counts256_out) {
+    const u64 N = n + 1;
     hipStream_t s = ctx->stream;
     tc_stats &st = ctx->stats;
 
@@ -196,7 +217,17 @@ static void sa_build(tc_ctx *ctx, Arena &A, const u8 *d_text, u64 n, u32 *d_sa, 
             kp.plan.mask[p] = plan.mask[p];
         }
         tc_memset_async(ctx, b.hist, 0, sizeof(u32) * RDX_MAX_PASSES * RDX_BINS);
-        keybuild_kernel<<<tc_cdiv(N, SA_TILE), SA_NT, 0, s>>>(d_text, (u32)n, kp, b.k0, b.hist);
+        // one shared histogram when every pass is exactly one 8-bit field
+        bool onehist = cfg.w == 8 && plan.npass < RDX_MAX_PASSES && env_int("TC_KB_ONEHIST", 1) != 0;
+        for (int p = 0; p < plan.npass; p++)
+            if (plan.mask[p] != 255u || plan.shift[p] % 8 != 0) onehist = false;
+        if (onehist) {
+            keybuild_kernel<true><<<tc_cdiv(N, SA_TILE), SA_NT, 0, s>>>(d_text, (u32)n, kp, b.k0, b.hist);
+            TC_LAUNCH_CHECK(ctx);
+            keyhist_fix_kernel<<<1, 256, 0, s>>>(d_text, (u32)n, kp, b.hist);
+        } else {
+            keybuild_kernel<false><<<tc_cdiv(N, SA_TILE), SA_NT, 0, s>>>(d_text, (u32)n, kp, b.k0, b.hist);
+        }
         TC_LAUNCH_CHECK(ctx);
         // ping-pong arranged so that the sorted values land in `va` (or, when a finish
         // pass follows, in the OTHER buffer so that the finish pass writes `va`)

@@ -98,9 +98,12 @@ __global__ __launch_bounds__(RDX_NT, RDX_LB_WAVES(PERSIST)) void radix_pass_kern
     u32 *__restrict__ vout, u32 n, int shift, u32 mask, const u32 *__restrict__ bucket_base,
     u64 *status, u32 *ticket, u32 *err, const u32 *__restrict__ tile_offs) {
     constexpr int NW = RDX_NT / 64;
-    const int shift_raw = shift;
+#ifdef TC_RADIX_DIAG
+    const int shift_raw = shift;  // timing-only ablation bits ride in the high bits of `shift`
+#else
+    const int shift_raw = shift & 0x100000;
+#endif
     shift &= 0xff;
-    (void)shift_raw;
     // staging area for the sorted tile; the per-wave histograms overlay its head (they
     // are dead once every item's local position sits in a register): 48 KB + 2 KB => 3
     // blocks per CU
@@ -108,7 +111,8 @@ __global__ __launch_bounds__(RDX_NT, RDX_LB_WAVES(PERSIST)) void radix_pass_kern
     u64 *s_keys = reinterpret_cast<u64 *>(s_raw);
     u32 *s_vals = reinterpret_cast<u32 *>(s_raw + RDX_TILE * 8);
     u32 *s_hist = reinterpret_cast<u32 *>(s_raw);
-    static_assert(NW * RDX_BINS * 4 <= RDX_TILE * 8, "histograms must fit under the key staging");
+    u64 *s_mask = reinterpret_cast<u64 *>(s_raw + NW * RDX_BINS * 4);
+    static_assert(NW * RDX_BINS * 12 <= RDX_TILE * 12, "histograms + match masks must fit under the staging area");
     __shared__ u32 s_dbase[RDX_BINS];
     __shared__ u32 s_gbase[RDX_BINS];
     __shared__ u32 s_scan[RDX_NT / 64 + 1];
@@ -117,8 +121,19 @@ __global__ __launch_bounds__(RDX_NT, RDX_LB_WAVES(PERSIST)) void radix_pass_kern
     const int tid = threadIdx.x, w = tid >> 6, l = tid & 63;
     if (SPLIT) {
         if (tid == 0) s_tile = blockIdx.x;
+    } else if (PERSIST || (shift_raw & 0x100000)) {
+        if (tid == 0) s_tile = atomicAdd(ticket, 1u);  // one counter: always safe
     } else {
-        if (tid == 0) s_tile = atomicAdd(ticket, 1u);
+        // tile ids from 8 ticket counters (one word saturates at ~88 tickets/us): shard =
+        // blockIdx % 8, tile = 8 * ticket + shard.  Every shard receives the same number of
+        // blocks, so tile ids stay within one round of each other across shards as long as
+        // blocks start in roughly increasing blockIdx order; if the hardware ever starts
+        // them wildly out of order the bounded look-back spin trips and the host redoes the
+        // sort with the single counter.
+        if (tid == 0) {
+            u32 sh = blockIdx.x & 7u;
+            s_tile = atomicAdd(ticket + 32 * sh, 1u) * 8u + sh;
+        }
     }
     __syncthreads();
     const u32 first = s_tile, G = PERSIST ? gridDim.x : 0x7fffffffu;
@@ -130,15 +145,22 @@ __global__ __launch_bounds__(RDX_NT, RDX_LB_WAVES(PERSIST)) void radix_pass_kern
     u32 val[RDX_ITEMS], nval[RDX_ITEMS];
     auto load_tile = [&](u32 tile, u64 *kk, u32 *vv) {
         const u64 base = (u64)tile * RDX_TILE;
+        const u64 *kt = kin + base;  // uniform base + 32-bit lane offset
+        const u32 *vt = vin + base;
+        const u32 lim = tile < ntiles ? ((n - base) < (u64)RDX_TILE ? (u32)(n - base) : (u32)RDX_TILE) : 0u;
 #pragma unroll
         for (int k = 0; k < RDX_ITEMS; k++) {
-            u64 g = base + wofs + k * 64 + l;
+            const u32 o = wofs + k * 64 + l;
+#ifdef TC_RADIX_DIAG
             if (shift_raw & 0x800) {  // DIAGNOSTIC bit3: no global loads
-                kk[k] = (g * 0x9E3779B97F4A7C15ull) | 1ull;
-                vv[k] = (u32)g;
-            } else if (tile < ntiles && g < n) {
-                kk[k] = kin[g];
-                vv[k] = GEN_IDX ? (u32)g : vin[g];
+                kk[k] = ((base + o) * 0x9E3779B97F4A7C15ull) | 1ull;
+                vv[k] = (u32)(base + o);
+                continue;
+            }
+#endif
+            if (o < lim) {
+                kk[k] = kt[o];
+                vv[k] = GEN_IDX ? (u32)base + o : vt[o];
             } else {
                 kk[k] = ~0ull;
                 vv[k] = 0;
@@ -151,35 +173,40 @@ __global__ __launch_bounds__(RDX_NT, RDX_LB_WAVES(PERSIST)) void radix_pass_kern
         const u64 base = (u64)tile * RDX_TILE;
         const u32 valid = (n - base) < (u64)RDX_TILE ? (u32)(n - base) : (u32)RDX_TILE;
         if (PERSIST) load_tile(tile + G, nkey, nval);  // prefetch; consumed next iteration
-        for (int i = tid; i < NW * RDX_BINS; i += RDX_NT) s_hist[i] = 0;
+        if (!(shift_raw & 0x4000))
+            for (int i = tid; i < NW * RDX_BINS * 3; i += RDX_NT) s_hist[i] = 0;  // histograms + masks
         __syncthreads();
-        // stable ranking inside the wave, item by item
+        // stable ranking inside the wave, item by item.  match-any through LDS: every lane
+        // ORs its lane bit into a per-wave, per-digit 64-bit mask, then reads the mask of
+        // its own digit back (2 LDS ops instead of 8 ballots + ~50 VALU per item); the
+        // first lane of each digit group updates the wave histogram and clears the mask.
         u32 rnk[RDX_ITEMS];
+        u32 dig[RDX_ITEMS];
+        u64 *wm = s_mask + w * RDX_BINS;
+        const u64 mybit = 1ull << l;
 #pragma unroll
         for (int k = 0; k < RDX_ITEMS; k++) {
             u32 p = wofs + k * 64 + l;
             u32 d = p < valid ? (u32)((key[k] >> shift) & mask) : 255u;  // pads: last digit, last
-            u64 m = ~0ull;
-            if (shift_raw & 0x100) {  // DIAGNOSTIC bit0 (timing only, wrong output): skip the match-any
-                m = 1ull << l;
-            } else {
-#pragma unroll
-                for (int b = 0; b < RDX_BITS; b++) {
-                    u64 bal = __ballot((d >> b) & 1u);
-                    m &= ((d >> b) & 1u) ? bal : ~bal;
-                }
-            }
-            u32 old = wh[d];
-            u32 prior = __popcll(m & lanemask_lt());
+            dig[k] = d;
+            if (shift_raw & 0x1000) { rnk[k] = k; continue; }  // DIAGNOSTIC bit4
+            atomicOr((unsigned long long *)&wm[d], (unsigned long long)mybit);
             __builtin_amdgcn_wave_barrier();
-            if (prior == 0) wh[d] = old + __popcll(m);
+            u64 m = wm[d];
+            u32 old = wh[d];
+            u32 prior = __popcll(m & (mybit - 1ull));
+            __builtin_amdgcn_wave_barrier();
+            if (prior == 0) {
+                wh[d] = old + __popcll(m);
+                wm[d] = 0ull;
+            }
             __builtin_amdgcn_wave_barrier();
             rnk[k] = old + prior;
         }
         __syncthreads();
         // digit totals, exclusive over waves; one owner thread per digit
         u32 tot = 0;
-        if (tid < RDX_BINS) {
+        if (tid < RDX_BINS && !(shift_raw & 0x2000)) {  // DIAGNOSTIC bit5 skips
 #pragma unroll
             for (int i = 0; i < NW; i++) {
                 u32 c = s_hist[i * RDX_BINS + tid];
@@ -199,11 +226,7 @@ __global__ __launch_bounds__(RDX_NT, RDX_LB_WAVES(PERSIST)) void radix_pass_kern
         // local sorted position of every item
         u32 pos[RDX_ITEMS];
 #pragma unroll
-        for (int k = 0; k < RDX_ITEMS; k++) {
-            u32 p = wofs + k * 64 + l;
-            u32 d = p < valid ? (u32)((key[k] >> shift) & mask) : 255u;
-            pos[k] = s_dbase[d] + wh[d] + rnk[k];
-        }
+        for (int k = 0; k < RDX_ITEMS; k++) pos[k] = s_dbase[dig[k]] + wh[dig[k]] + rnk[k];
         if (tid < RDX_BINS) {
             u32 excl = 0;
             if (SPLIT) {
@@ -389,7 +412,7 @@ struct RadixBuffers {
 };
 static inline size_t radix_status_words(u64 n) {
     size_t t = tc_cdiv(n, RDX_TILE);
-    return t * RDX_BINS + t / 8 + 64;  // look-back granules, or (split variant) matrix + offsets + partials
+    return t * RDX_BINS + t / 8 + 256;  // look-back granules, or (split variant) matrix + offsets + partials
 }
 
 void radix_sort_pairs(tc_ctx *ctx, RadixBuffers &b, u32 n, const RadixPlan &plan, bool gen_idx,

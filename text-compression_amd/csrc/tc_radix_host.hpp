@@ -10,14 +10,15 @@
 //   4 ticket per tile, look-back 4
 static int radix_variant() {
     const char *e = getenv("TC_RADIX_VARIANT");
-    return e && *e ? atoi(e) : 1;
+    return e && *e ? atoi(e) : 0;
 }
 
 template <bool GEN>
 static void radix_launch_pass(tc_ctx *ctx, int variant, RadixBuffers &b, u32 n, int shift, u32 mask,
                               const u32 *bucket_base, u32 tiles, u32 *ticket) {
     hipStream_t s = ctx->stream;
-    if (const char *dg = getenv("TC_DIAG")) shift |= (atoi(dg) & 0xff) << 8;  // timing-only diagnostics, wrong output
+    if (const char *dg = getenv("TC_DIAG")) shift |= (atoi(dg) & 0xfff) << 8;
+    if (ctx->safe_tickets || !getenv("TC_SHARDED_TICKETS")) shift |= 0x100000;  // single counter (sharding measured no gain)  // timing-only diagnostics, wrong output
     if (variant == 3) {
         u32 *matrix = reinterpret_cast<u32 *>(b.status);
         u32 *tile_offs = matrix + (size_t)tiles * RDX_BINS;
@@ -80,7 +81,7 @@ void radix_sort_pairs(tc_ctx *ctx, RadixBuffers &b, u32 n, const RadixPlan &plan
         TC_LAUNCH_CHECK(ctx);
     }
     const u32 tiles = tc_cdiv(n, RDX_TILE);
-    const size_t words = (size_t)tiles * RDX_BINS + 2;
+    const size_t words = (size_t)tiles * RDX_BINS + 130;  // granules + 8 ticket counters, 128 B apart
     for (int p = 0; p < plan.npass; p++) {
         u32 *ticket = reinterpret_cast<u32 *>(b.status + (size_t)tiles * RDX_BINS);
         if (variant != 3) TC_HIP(ctx, hipMemsetAsync(b.status, 0, words * sizeof(u64), s));

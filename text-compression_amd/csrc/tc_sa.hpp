@@ -68,64 +68,135 @@ struct KeyBuildParams {
 
 // ---- round-0 keys ---------------------------------------------------------------
 // key(i) = fields G(i), G(i+s), ..  (G(p) = s symbols from p, base B) from bit 63
-// down, w bits each; low byte = text[i-1] (0 for i == 0).  Also accumulates the
-// digit histograms of every sort pass (saves one read of the keys).
+// down, w bits each; low byte = text[i-1] (0 for i == 0).  Text comes in through
+// 16-byte loads into an LDS image of codes; G is built once per position.
+// Digit histograms for the sort passes (saves one read of the keys):
+//   ONEHIST (w == 8, every pass = one whole field): every pass sees the same multiset of
+//   G values up to boundary terms, so ONE histogram H[v] = #{j < N : G(j) = v} is taken
+//   here and keyhist_fix_kernel derives each pass's counts from it;
+//   otherwise one LDS histogram per pass.
+#define KB_PRE 16  // LDS slot 0 = text position base - KB_PRE (keeps 16-byte units aligned)
+#define KB_SLOTS (SA_TILE + KB_PRE + KB_HALO + 8)
+
+template <bool ONEHIST>
 __global__ __launch_bounds__(SA_NT) void keybuild_kernel(const u8 *__restrict__ text, u32 n,
                                                          KeyBuildParams kp,
                                                          u64 *__restrict__ keys,
                                                          u32 *__restrict__ hist) {
-    __shared__ u16 s_c[SA_TILE + KB_HALO + 8];  // codes, slot 0 = position base-1
-    __shared__ u16 s_g[SA_TILE + KB_HALO + 8];
-    __shared__ u8 s_raw[SA_TILE + 8];            // raw bytes, slot 0 = position base-1
-    __shared__ u32 s_h[RDX_MAX_PASSES * RDX_BINS];
+    __shared__ __attribute__((aligned(16))) u16 s_c[KB_SLOTS];  // codes
+    __shared__ __attribute__((aligned(16))) u16 s_g[KB_SLOTS];  // G values
+    __shared__ __attribute__((aligned(16))) u8 s_raw[KB_SLOTS]; // raw bytes
+    __shared__ u32 s_h[ONEHIST ? RDX_BINS : RDX_MAX_PASSES * RDX_BINS];
     __shared__ u16 s_lut[256];
     const int tid = threadIdx.x;
     const u32 N = n + 1;
     const u64 base = (u64)blockIdx.x * SA_TILE;
-    for (int i = tid; i < kp.plan.npass * RDX_BINS; i += SA_NT) s_h[i] = 0;
+    const int nh = ONEHIST ? RDX_BINS : kp.plan.npass * RDX_BINS;
+    for (int i = tid; i < nh; i += SA_NT) s_h[i] = 0;
     s_lut[tid] = kp.lut[tid];
     __syncthreads();
-    const u32 span = SA_TILE + kp.P * kp.s + kp.s;  // symbols needed from `base`
-    for (u32 p = tid; p < span + 1; p += SA_NT) {
-        i64 pos = (i64)base + (i64)p - 1;
-        u16 c = 0;
-        u8 raw = 0;
-        if (pos >= 0 && pos < (i64)n) {
-            raw = text[pos];
-            c = s_lut[raw];
+    // phase A: text -> codes + raw, 16 bytes per thread per step
+    const u32 span = SA_TILE + kp.P * kp.s + kp.s;            // symbols needed from `base`
+    const u32 units = (KB_PRE + span + 15) / 16;
+    const bool aligned = (((uintptr_t)text) & 15) == 0;
+    for (u32 u = tid; u < units; u += SA_NT) {
+        const i64 p0 = (i64)base - KB_PRE + (i64)u * 16;       // text position of the unit's first byte
+        u8 raw[16];
+        if (aligned && p0 >= 0 && p0 + 16 <= (i64)n) {
+            uint4 v = *reinterpret_cast<const uint4 *>(text + p0);
+            u32 x[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+            for (int q = 0; q < 16; q++) raw[q] = (u8)(x[q >> 2] >> (8 * (q & 3)));
+        } else {
+#pragma unroll
+            for (int q = 0; q < 16; q++) {
+                i64 p = p0 + q;
+                raw[q] = (p >= 0 && p < (i64)n) ? text[p] : (u8)0;
+            }
         }
-        s_c[p] = c;
-        if (p <= SA_TILE) s_raw[p] = raw;
+        u16 code[16];
+#pragma unroll
+        for (int q = 0; q < 16; q++) {
+            i64 p = p0 + q;
+            code[q] = (p >= 0 && p < (i64)n) ? s_lut[raw[q]] : (u16)0;
+        }
+        uint4 *dc = reinterpret_cast<uint4 *>(s_c + u * 16);
+        dc[0] = make_uint4(code[0] | (code[1] << 16), code[2] | (code[3] << 16), code[4] | (code[5] << 16), code[6] | (code[7] << 16));
+        dc[1] = make_uint4(code[8] | (code[9] << 16), code[10] | (code[11] << 16), code[12] | (code[13] << 16), code[14] | (code[15] << 16));
+        *reinterpret_cast<uint4 *>(s_raw + u * 16) =
+            make_uint4(raw[0] | (raw[1] << 8) | (raw[2] << 16) | ((u32)raw[3] << 24),
+                       raw[4] | (raw[5] << 8) | (raw[6] << 16) | ((u32)raw[7] << 24),
+                       raw[8] | (raw[9] << 8) | (raw[10] << 16) | ((u32)raw[11] << 24),
+                       raw[12] | (raw[13] << 8) | (raw[14] << 16) | ((u32)raw[15] << 24));
     }
     __syncthreads();
-    for (u32 p = tid; p < SA_TILE + kp.P * kp.s; p += SA_NT) {
+    // phase B: G(p) for every slot that a key of this tile can touch
+    const u32 gslots = KB_PRE + SA_TILE + kp.P * kp.s;
+    for (u32 q = tid; q < gslots; q += SA_NT) {
         u32 g = 0;
-        for (u32 j = 0; j < kp.s; j++) g = g * kp.B + s_c[p + 1 + j];
-        s_g[p] = (u16)g;
+        for (u32 j = 0; j < kp.s; j++) g = g * kp.B + s_c[q + j];
+        s_g[q] = (u16)g;
     }
     __syncthreads();
+    // phase C: keys (striped => coalesced 8-byte stores) + histogram(s)
 #pragma unroll 4
     for (int k = 0; k < SA_ITEMS; k++) {
-        u32 p = tid + k * SA_NT;
-        u64 i = base + p;
+        const u32 p = tid + k * SA_NT;
+        const u64 i = base + p;
         if (i < N) {
+            const u32 q = KB_PRE + p;
             u64 key = 0;
             int sh = 64;
             for (u32 f = 0; f < kp.P; f++) {
                 sh -= kp.w;
-                key |= (u64)s_g[p + f * kp.s] << sh;
+                key |= (u64)s_g[q + f * kp.s] << sh;
             }
-            key |= (u64)s_raw[p];
+            key |= (u64)s_raw[q - 1];
             keys[i] = key;
-            for (int q = 0; q < kp.plan.npass; q++)
-                atomicAdd(&s_h[q * RDX_BINS + (u32)((key >> kp.plan.shift[q]) & kp.plan.mask[q])],
-                          1u);
+            if (ONEHIST) {
+                atomicAdd(&s_h[s_g[q]], 1u);
+            } else {
+                for (int pq = 0; pq < kp.plan.npass; pq++)
+                    atomicAdd(&s_h[pq * RDX_BINS + (u32)((key >> kp.plan.shift[pq]) & kp.plan.mask[pq])], 1u);
+            }
         }
     }
     __syncthreads();
-    for (int i = tid; i < kp.plan.npass * RDX_BINS; i += SA_NT) {
+    for (int i = tid; i < nh; i += SA_NT) {
         u32 c = s_h[i];
-        if (c) atomicAdd(&hist[i], c);
+        if (c) atomicAdd(&hist[ONEHIST ? (RDX_MAX_PASSES - 1) * RDX_BINS + i : i], c);
+    }
+}
+
+// ONEHIST fix-up (one block): H sits in the LAST histogram row; pass q sorts field f_q,
+// whose digit for suffix i is G(i + f_q*s), so
+//   hist_q[v] = H[v] - #{j < f_q*s : G(j) = v} + #{N <= j < N + f_q*s : G(j) = v}.
+__global__ __launch_bounds__(256) void keyhist_fix_kernel(const u8 *__restrict__ text, u32 n,
+                                                          KeyBuildParams kp, u32 *hist) {
+    __shared__ u32 s_g[128];
+    const u32 N = n + 1;
+    const int tid = threadIdx.x;
+    // G at the head [0, maxoff) and just past the end [N, N + maxoff)
+    if (tid < 128) {
+        u32 j = tid < 64 ? (u32)tid : N + (u32)(tid - 64);
+        u32 g = 0;
+        for (u32 t = 0; t < kp.s; t++) {
+            u64 p = (u64)j + t;
+            g = g * kp.B + (p < n ? (u32)kp.lut[text[p]] : 0u);
+        }
+        s_g[tid] = g;
+    }
+    __syncthreads();
+    const u32 H = hist[(RDX_MAX_PASSES - 1) * RDX_BINS + tid];
+    for (int q = 0; q < kp.plan.npass; q++) {
+        const u32 f = (u32)((64 - kp.plan.shift[q]) / 8 - 1);  // field sorted by pass q
+        const u32 off = f * kp.s;
+        u32 sub = 0, add = 0;
+        for (u32 j = 0; j < off && j < 64; j++) {
+            sub += s_g[j] == (u32)tid;
+            add += s_g[64 + j] == (u32)tid;
+        }
+        hist[q * RDX_BINS + tid] = H - sub + add;
     }
 }
 
@@ -353,19 +424,24 @@ __global__ __launch_bounds__(FIN_NT) void finish_kernel(FinishArgs a) {
     if (ws0 >= N) return;
     const u64 lowmask = a.lbits >= 64 ? ~0ull : ((1ull << a.lbits) - 1ull);  // remaining key bits
 
-    // chunk loader
-    auto ld_key = [&](u64 pos) -> u64 { return pos < N ? a.keys[pos] : ~0ull; };
-    auto ld_sa = [&](u64 pos) -> u32 { return pos < N ? a.sa_in[pos] : 0u; };
-    u64 kA = ld_key(ws0 + l);
-    u32 vA = ld_sa(ws0 + l);
+    // all chunks of this wave are requested up front (one round trip instead of one per window)
+    u64 kk[FIN_WPW + 1];
+    u32 vv[FIN_WPW + 1];
+#pragma unroll
+    for (int c = 0; c <= FIN_WPW; c++) {
+        const u64 pos = ws0 + (u64)c * 64 + l;
+        kk[c] = pos < N ? a.keys[pos] : ~0ull;
+        vv[c] = pos < N ? a.sa_in[pos] : 0u;
+    }
     u64 tprev = ws0 > 0 ? (a.keys[ws0 - 1] >> a.tshift) : 0;  // wave-uniform
     bool hasprev = ws0 > 0;
 
+#pragma unroll
     for (int win = 0; win < FIN_WPW; win++) {
         const u64 ws = ws0 + (u64)win * 64;
         if (ws >= N) break;
-        u64 kB = ld_key(ws + 64 + l);
-        u32 vB = ld_sa(ws + 64 + l);
+        const u64 kA = kk[win], kB = kk[win + 1];
+        const u32 vA = vv[win], vB = vv[win + 1];
         const bool inA = ws + l < N, inB = ws + 64 + l < N;
         const u64 tA = kA >> a.tshift, tB = kB >> a.tshift;
         // head flags
@@ -402,39 +478,39 @@ __global__ __launch_bounds__(FIN_NT) void finish_kernel(FinishArgs a) {
         low[l] = lowA;
         low[64 + l] = lowB;
         __builtin_amdgcn_wave_barrier();
-        int lenA = ownA ? tAend - sA : 0, lenB = ownB ? endB - lastHeadA : 0;
-        int maxlen = lenA > lenB ? lenA : lenB;
+        // rank inside the bucket: walk the bucket's members once (stable: ties broken by
+        // position).  A-lanes walk their own bucket; the B-lanes that continue A's last
+        // bucket all share ONE bucket and are handled by a second, usually short, walk.
+        const int cA = l, cB = 64 + l;
+        const int sB = lastHeadA, tBend = endB;
+        int lenA = ownA ? tAend - sA : 0;
+        int maxlen = lenA;
 #pragma unroll
         for (int d = 32; d >= 1; d >>= 1) {
             int o = __shfl_xor(maxlen, d, 64);
             maxlen = maxlen > o ? maxlen : o;
         }
-        // all-pairs ranking inside the bucket
-        u32 rankA = 0, ltA = 0, eqA = 0, rankB = 0, ltB = 0, eqB = 0;
-        const int cA = l, cB = 64 + l;
-        const int sB = lastHeadA, tBend = endB;
-        for (int d = 1; d < maxlen; d++) {
-            if (ownA) {
-                if (cA + d < tAend) {
-                    u32 y = low[cA + d];
-                    rankA += y < lowA; ltA += y < lowA; eqA += y == lowA;
-                }
-                if (cA - d >= sA) {
-                    u32 y = low[cA - d];
-                    rankA += y <= lowA; ltA += y < lowA; eqA += y == lowA;
-                }
-            }
-            if (ownB) {
-                if (cB + d < tBend) {
-                    u32 y = low[cB + d];
-                    rankB += y < lowB; ltB += y < lowB; eqB += y == lowB;
-                }
-                if (cB - d >= sB) {
-                    u32 y = low[cB - d];
-                    rankB += y <= lowB; ltB += y < lowB; eqB += y == lowB;
-                }
+        u32 rankA = 0, ltA = 0, leA = 0;
+        for (int t = 0; t < maxlen; t++) {
+            const int u = sA + t;
+            if (ownA && u < tAend) {
+                const u32 y = low[u];
+                ltA += y < lowA;
+                leA += y <= lowA;
+                rankA += (y < lowA) | ((y == lowA) & (u < cA));
             }
         }
+        const u32 eqA = ownA ? leA - ltA - 1u : 0u;  // other members with the same remaining bits
+        u32 rankB = 0, ltB = 0, leB = 0;
+        if (hbA && b0 > 0) {  // wave-uniform: some B-lanes continue A's last bucket
+            for (int u = sB; u < tBend; u++) {
+                const u32 y = low[u];
+                ltB += y < lowB;
+                leB += y <= lowB;
+                rankB += (y < lowB) | ((y == lowB) & (u < cB));
+            }
+        }
+        const u32 eqB = ownB ? leB - ltB - 1u : 0u;
         __builtin_amdgcn_wave_barrier();
         // outputs
         const bool actA = ownA && eqA > 0, actB = ownB && eqB > 0;
@@ -471,11 +547,8 @@ __global__ __launch_bounds__(FIN_NT) void finish_kernel(FinishArgs a) {
                 }
             }
         }
-        // slide: B becomes the next window's A
         tprev = lastA;
         hasprev = true;
-        kA = kB;
-        vA = vB;
     }
 }
 
