@@ -161,6 +161,21 @@ int tc_encode_dev(tc_ctx *ctx, const uint8_t *d_text, uint64_t n, tc_block *out)
 int tc_decode(tc_ctx *ctx, const tc_block *blk, uint8_t *text);
 int tc_decode_dev(tc_ctx *ctx, const tc_block *blk, uint8_t *d_text);
 
+/* ---- encoded-block wire format (used by the multi-GPU gather) ----- */
+/* The reference has no on-disk / wire format.  Packed form of a tc_block's runs:
+ *   byte k (k < nruns) = value | (min(count, 15) << 4)      when sigma <= 16
+ *   (sigma > 16: two bytes per run: value low byte | count-escape byte)
+ * count >= 15 ("escape") additionally appends the pair (run index, count) as two
+ * uint32 words to the escape list that follows the bytes at the next 8-byte boundary.
+ * `packed` needs tc_block_packed_bound(nruns, sigma) bytes; *packed_bytes returns the
+ * bytes used and *nesc the number of escapes.  All pointers are DEVICE pointers. */
+uint64_t tc_block_packed_bound(uint64_t nruns, uint32_t sigma);
+int tc_block_pack_dev(tc_ctx *ctx, const tc_block *blk, uint8_t *d_packed, uint64_t *packed_bytes,
+                      uint64_t *nesc);
+/* Inverse: fills blk->run_count / blk->run_value (device, capacity blk->nruns >= nruns). */
+int tc_block_unpack_dev(tc_ctx *ctx, const uint8_t *d_packed, uint64_t nruns, uint32_t sigma,
+                        uint64_t nesc, tc_block *blk);
+
 /* ---- Data.FMIndex -------------------------------------------------------- */
 /* bytestringToBWTToFMIndexB (FMIndex.hs:108-111,162-183): C[c] (seqToCc,
  * FMIndex/Internal.hs:275-316), Occ (seqToOccCK :195-259, kept as rank

@@ -177,3 +177,35 @@ def test_finish_and_full_paths_agree(ctx, monkeypatch):
     monkeypatch.delenv("TC_SA_FINISH")
     rep = b"ACGT" * 50000 + t[:1000]              # long repeats: oversize buckets -> fallback
     assert ctx.suffix_array(rep).tolist() == O.suffix_array(rep).tolist()
+
+
+def test_block_pack_unpack_roundtrip(ctx):
+    """Packed wire format of the runs (used by the multi-GPU gather): exact inverse, incl. count
+    escapes and the two-byte form for sigma > 16."""
+    import ctypes as C
+    import torch
+    from textcomp import Block
+    lib = ctx.lib
+    rng = np.random.default_rng(12)
+    cases = [(6, rng.integers(1, 4, 50000), rng.integers(0, 6, 50000)),
+             (6, np.array([1, 14, 15, 16, 100000, 2]), np.array([0, 5, 3, 2, 1, 4])),       # escapes
+             (257, rng.integers(1, 300, 20000), rng.integers(0, 257, 20000)),               # 2 bytes / run
+             (16, np.array([2 ** 31]), np.array([15]))]
+    for sigma, counts, vals in cases:
+        k = len(counts)
+        d_c = torch.from_numpy(counts.astype(np.uint32).view(np.int32)).cuda()
+        d_v = torch.from_numpy(vals.astype(np.uint16).view(np.int16)).cuda()
+        blk = Block(); blk.nruns = k; blk.sigma = sigma
+        blk.run_count = d_c.data_ptr(); blk.run_value = d_v.data_ptr()
+        bound = lib.tc_block_packed_bound(k, sigma)
+        buf = torch.zeros(bound, dtype=torch.uint8, device="cuda")
+        nb, ne = C.c_uint64(), C.c_uint64()
+        assert lib.tc_block_pack_dev(ctx.handle, C.byref(blk), C.c_void_p(buf.data_ptr()), C.byref(nb), C.byref(ne)) == 0
+        assert nb.value <= bound
+        esc_thr = 15 if sigma <= 16 else 127
+        assert ne.value == int((counts >= esc_thr).sum())
+        o_c = torch.zeros(k, dtype=torch.int32, device="cuda"); o_v = torch.zeros(k, dtype=torch.int16, device="cuda")
+        out = Block(); out.nruns = k; out.run_count = o_c.data_ptr(); out.run_value = o_v.data_ptr()
+        assert lib.tc_block_unpack_dev(ctx.handle, C.c_void_p(buf.data_ptr()), k, sigma, ne.value, C.byref(out)) == 0
+        assert np.array_equal(o_c.cpu().numpy().view(np.uint32), counts.astype(np.uint32))
+        assert np.array_equal(o_v.cpu().numpy().view(np.uint16), vals.astype(np.uint16))

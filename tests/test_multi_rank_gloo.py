@@ -18,11 +18,11 @@ def _free_port():
     return p
 
 
-def _block_for(rank, n):
-    rng = np.random.default_rng(1000 + rank)
-    k = int(n * (0.5 + 0.1 * rank))
-    return (k, 17 + rank, 6, n, torch.from_numpy(rng.integers(1, 9, n + 2).astype(np.int32)),
-            torch.from_numpy(rng.integers(0, 6, n + 2).astype(np.int16)))
+def _block_for(rank, step, n):
+    rng = np.random.default_rng(1000 + 17 * rank + step)
+    k = int(n * (0.5 + 0.1 * rank)) + step
+    hdr = [k, k - 3, 0, 17 + rank, 6, n]
+    return hdr, torch.from_numpy(rng.integers(0, 256, n + 64).astype(np.uint8))
 
 
 def _worker(rank, world, port, n, q):
@@ -30,19 +30,23 @@ def _worker(rank, world, port, n, q):
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
         from textcomp.gather import BlockGather, shard_patterns
-        k, prim, sig, nn, cnt, val = _block_for(rank, n)
-        g = BlockGather(n + 2, torch.device("cpu"))
+        g = BlockGather(n + 64, torch.device("cpu"), depth=2)
         ok = True
-        for _ in range(2):  # buffers are reused across steps
-            res = g.gather(k, prim, sig, nn, cnt, val)
-            if rank == 0:
+        steps = 5
+        bufs = [None, None]
+        for st in range(steps):     # pipelined: submit only posts; buffers are double-buffered
+            hdr, payload = _block_for(rank, st, n)
+            bufs[st % 2] = payload
+            g.submit(hdr, payload)
+        g.drain()
+        if rank == 0:
+            got = g.completed[-2:]          # the last two records are still retained
+            for st, res in zip(range(steps - 2, steps), got):
                 for r in range(world):
-                    ek, eprim, esig, en, ecnt, eval_ = _block_for(r, n)
-                    hdr, c, v = res[r]
-                    ok &= hdr == (ek, eprim, esig, en)
-                    ok &= torch.equal(c, ecnt[:ek]) and torch.equal(v, eval_[:ek])
-            else:
-                ok &= res is None
+                    ehdr, epay = _block_for(r, st, n)
+                    hdr, data = res[r]
+                    ok &= list(hdr) == ehdr
+                    ok &= torch.equal(data, epay[:ehdr[0]])
         lo, hi = shard_patterns(11, world, rank)
         part = torch.arange(lo, hi, dtype=torch.int64)
         parts = [torch.empty(6, dtype=torch.int64) for _ in range(world)]

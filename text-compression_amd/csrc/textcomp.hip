@@ -276,6 +276,55 @@ __global__ __launch_bounds__(256) void dbg_check_sorted_kernel(const u64 *keys, 
     }
 }
 
+// ------------------------------------------------------------ packed run format
+// bytes per run: 1 (sigma <= 16) or 2 (value byte, count byte with 255 = escape; the
+// ninth value bit of sigma = 257 rides in the count byte's top bit -> counts escape at 127)
+static inline int pack_bpr(u32 sigma) { return sigma <= 16 ? 1 : 2; }
+
+__global__ __launch_bounds__(256) void pack_runs_kernel(const u32 *__restrict__ cnt,
+                                                        const u16 *__restrict__ val, u64 nruns,
+                                                        int bpr, u8 *__restrict__ out,
+                                                        u32 *__restrict__ esc, u32 *nesc, u64 esc_cap) {
+    for (u64 k = (u64)blockIdx.x * 256 + threadIdx.x; k < nruns; k += (u64)gridDim.x * 256) {
+        const u32 c = cnt[k], v = val[k];
+        bool e;
+        if (bpr == 1) {
+            e = c >= 15;
+            out[k] = (u8)((v & 15u) | ((e ? 15u : c) << 4));
+        } else {
+            e = c >= 127;
+            out[2 * k] = (u8)v;
+            out[2 * k + 1] = (u8)((e ? 127u : c) | ((v >> 8) << 7));
+        }
+        if (e) {
+            u32 slot = atomicAdd(nesc, 1u);
+            if (slot < esc_cap) {
+                esc[2 * (u64)slot] = (u32)k;
+                esc[2 * (u64)slot + 1] = c;
+            }
+        }
+    }
+}
+__global__ __launch_bounds__(256) void unpack_runs_kernel(const u8 *__restrict__ in, u64 nruns, int bpr,
+                                                          u32 *__restrict__ cnt, u16 *__restrict__ val) {
+    for (u64 k = (u64)blockIdx.x * 256 + threadIdx.x; k < nruns; k += (u64)gridDim.x * 256) {
+        if (bpr == 1) {
+            u8 b = in[k];
+            val[k] = (u16)(b & 15);
+            cnt[k] = (u32)(b >> 4);
+        } else {
+            u8 lo = in[2 * k], hi = in[2 * k + 1];
+            val[k] = (u16)(lo | ((hi >> 7) << 8));
+            cnt[k] = (u32)(hi & 127);
+        }
+    }
+}
+__global__ __launch_bounds__(256) void unpack_esc_kernel(const u32 *__restrict__ esc, u64 nesc,
+                                                         u64 nruns, u32 *__restrict__ cnt) {
+    u64 i = (u64)blockIdx.x * 256 + threadIdx.x;
+    if (i < nesc && esc[2 * i] < nruns) cnt[esc[2 * i]] = esc[2 * i + 1];
+}
+
 extern "C" {
 
 const char *tc_version(void) { return "textcomp-amd 0.1 (gfx950)"; }
@@ -609,6 +658,60 @@ int tc_decode(tc_ctx *ctx, const tc_block *blk, uint8_t *text) {
     if (d_count) (void)hipFree(d_count);
     if (d_value) (void)hipFree(d_value);
     if (rc != TC_OK) throw TcFail{rc};
+    TC_API_END(ctx)
+}
+
+// ====================================================== encoded-block wire format
+uint64_t tc_block_packed_bound(uint64_t nruns, uint32_t sigma) {
+    // bytes + 8-byte alignment + worst-case escape list (every run escapes)
+    return (((u64)pack_bpr(sigma) * nruns + 7) & ~7ull) + 8 * nruns + 8;
+}
+
+int tc_block_pack_dev(tc_ctx *ctx, const tc_block *blk, uint8_t *d_packed, uint64_t *packed_bytes,
+                      uint64_t *nesc) {
+    TC_API_BEGIN(ctx)
+    if (!blk || !packed_bytes || !nesc) TC_FAIL(ctx, TC_ERR_ARG, "bad argument");
+    const u64 nruns = blk->nruns;
+    *packed_bytes = 0; *nesc = 0;
+    if (nruns == 0) return TC_OK;
+    if (!d_packed || !blk->run_count || !blk->run_value) TC_FAIL(ctx, TC_ERR_ARG, "null buffer");
+    const int bpr = pack_bpr(blk->sigma);
+    const u64 body = ((u64)bpr * nruns + 7) & ~7ull;
+    u32 *esc = reinterpret_cast<u32 *>(d_packed + body);
+    u32 *d_nesc = reinterpret_cast<u32 *>(ctx->d_scalars + 14);
+    tc_memset_async(ctx, d_nesc, 0, sizeof(u64));
+    u32 grid = tc_cdiv(nruns, 256 * 8);
+    if (grid > 8192) grid = 8192;
+    pack_runs_kernel<<<grid, 256, 0, ctx->stream>>>(blk->run_count, blk->run_value, nruns, bpr, d_packed,
+                                                   esc, d_nesc, nruns);
+    TC_LAUNCH_CHECK(ctx);
+    tc_d2h(ctx, &ctx->h_scalars[14], ctx->d_scalars + 14, sizeof(u64));
+    TC_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    *nesc = (u32)ctx->h_scalars[14];
+    *packed_bytes = body + 8 * *nesc;
+    TC_API_END(ctx)
+}
+
+int tc_block_unpack_dev(tc_ctx *ctx, const uint8_t *d_packed, uint64_t nruns, uint32_t sigma,
+                        uint64_t nesc, tc_block *blk) {
+    TC_API_BEGIN(ctx)
+    if (!blk || blk->nruns < nruns) TC_FAIL(ctx, TC_ERR_ARG, "bad argument");
+    if (nruns == 0) { blk->nruns = 0; return TC_OK; }
+    if (!d_packed || !blk->run_count || !blk->run_value) TC_FAIL(ctx, TC_ERR_ARG, "null buffer");
+    const int bpr = pack_bpr(sigma);
+    const u64 body = ((u64)bpr * nruns + 7) & ~7ull;
+    u32 grid = tc_cdiv(nruns, 256 * 8);
+    if (grid > 8192) grid = 8192;
+    unpack_runs_kernel<<<grid, 256, 0, ctx->stream>>>(d_packed, nruns, bpr, blk->run_count, blk->run_value);
+    TC_LAUNCH_CHECK(ctx);
+    if (nesc) {
+        unpack_esc_kernel<<<tc_cdiv(nesc, 256), 256, 0, ctx->stream>>>(
+            reinterpret_cast<const u32 *>(d_packed + body), nesc, nruns, blk->run_count);
+        TC_LAUNCH_CHECK(ctx);
+    }
+    TC_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    blk->nruns = nruns;
+    blk->sigma = sigma;
     TC_API_END(ctx)
 }
 

@@ -1,61 +1,98 @@
 """Multi-GPU leg of the path: independent records, one per rank, no data-path
-collective during the encode; ONE exchange at the end -- the variable-size gather of
-the encoded blocks on rank 0.
+collective during the encode; ONE exchange per record at the end -- the variable-size
+gather of the encoded blocks on rank 0.
 
-Headers (nruns, primary, sigma, n) travel by all_gather (tiny); the run arrays by
-point-to-point sends posted together, so rank 0 receives from all peers at once:
-xGMI is point-to-point, a root gather ingests on every link concurrently whereas a
-ring would be bound by one link.  torch.distributed is plumbing (backend "nccl" is
-RCCL on ROCm; "gloo" in the CPU tests)."""
+Design for xGMI (point-to-point links, no switch): a root gather posted as one batch
+of sends/receives lets rank 0 ingest on all of its links at once, where a ring would be
+bound by a single link.  Two further measures keep the exchange off the critical path:
+  * the payload is the PACKED run format of include/textcomp.h (1 byte per run for
+    sigma <= 16 instead of 6), and
+  * the exchange is pipelined: `submit()` only posts the transfers (double-buffered),
+    so the gather of record k overlaps the encode of record k+1; `drain()` completes
+    everything still in flight.
+Headers travel on their own process group (its own RCCL communicator) so that the small
+synchronous header all-gather never queues behind a payload still in flight.
+
+torch.distributed is plumbing here (backend "nccl" is RCCL on ROCm; "gloo" in the CPU
+tests)."""
 import torch
 import torch.distributed as dist
 
+HDR_WORDS = 6  # nbytes, nruns, nesc, primary, sigma, n
+
 
 class BlockGather:
-    def __init__(self, cap, device, group=None):
+    def __init__(self, cap_bytes, device, depth=2, group=None):
         self.group = group
         self.world = dist.get_world_size(group)
         self.rank = dist.get_rank(group)
         self.device = device
-        self.cap = cap
-        self._recv_cnt = None
-        self._recv_val = None
+        self.cap = int(cap_bytes)
+        self.depth = depth
+        self.hdr_group = dist.new_group(ranks=list(range(self.world))) if self.world > 1 else None
+        self._recv = None     # rank 0: [slot][peer] uint8 buffers
+        self._inflight = [None] * depth   # per slot: (works, result)
+        self._step = 0
+        self.completed = []   # rank 0: finished gathers, oldest first (bounded)
 
     def _alloc(self):
-        if self._recv_cnt is None:
-            self._recv_cnt = [None] + [torch.empty(self.cap, dtype=torch.int32, device=self.device)
-                                       for _ in range(1, self.world)]
-            self._recv_val = [None] + [torch.empty(self.cap, dtype=torch.int16, device=self.device)
-                                       for _ in range(1, self.world)]
+        if self._recv is None:
+            self._recv = [[None] + [torch.empty(self.cap, dtype=torch.uint8, device=self.device)
+                                    for _ in range(1, self.world)] for _ in range(self.depth)]
 
-    def gather(self, nruns, primary, sigma, n, run_count, run_value):
-        """run_count int32[>=nruns], run_value int16[>=nruns] on self.device.
-        Rank 0 returns [(header tuple, counts view, values view)] per rank; others None."""
-        hdr = torch.tensor([nruns, primary, sigma, n], dtype=torch.int64, device=self.device)
-        hdrs = torch.empty(self.world * 4, dtype=torch.int64, device=self.device)
-        dist.all_gather_into_tensor(hdrs, hdr, group=self.group)
+    def _finish_slot(self, slot):
+        entry = self._inflight[slot]
+        if entry is None:
+            return
+        works, result = entry
+        for w in works:
+            w.wait()
+        self._inflight[slot] = None
+        if result is not None:
+            self.completed.append(result)
+            if len(self.completed) > 2 * self.depth:
+                self.completed.pop(0)
+
+    def submit(self, header, payload):
+        """header: 6 ints (nbytes, nruns, nesc, primary, sigma, n); payload: uint8 tensor holding
+        at least header[0] bytes, which the caller must not overwrite before the next-but-one
+        submit (double buffering) or drain().  Returns immediately after posting."""
+        slot = self._step % self.depth
+        self._step += 1
+        self._finish_slot(slot)
+        nbytes = int(header[0])
+        if nbytes > self.cap:
+            raise ValueError("packed block of %d bytes exceeds the gather capacity %d" % (nbytes, self.cap))
         if self.world == 1:
-            return [((nruns, primary, sigma, n), run_count[:nruns], run_value[:nruns])]
-        ops = []
+            self.completed.append([(tuple(int(v) for v in header), payload[:nbytes])])
+            if len(self.completed) > 2 * self.depth:
+                self.completed.pop(0)
+            return
+        hdr = torch.tensor([int(v) for v in header], dtype=torch.int64, device=self.device)
+        hdrs = torch.empty(self.world * HDR_WORDS, dtype=torch.int64, device=self.device)
+        dist.all_gather_into_tensor(hdrs, hdr, group=self.hdr_group)
+        ops, result = [], None
         if self.rank == 0:
             self._alloc()
-            H = hdrs.view(self.world, 4).tolist()
+            H = hdrs.view(self.world, HDR_WORDS).tolist()
+            result = [(tuple(int(v) for v in H[0]), payload[:nbytes])]
             for r in range(1, self.world):
                 k = int(H[r][0])
-                ops.append(dist.P2POp(dist.irecv, self._recv_cnt[r][:k], r, group=self.group))
-                ops.append(dist.P2POp(dist.irecv, self._recv_val[r][:k], r, group=self.group))
-        else:
-            ops.append(dist.P2POp(dist.isend, run_count[:nruns], 0, group=self.group))
-            ops.append(dist.P2POp(dist.isend, run_value[:nruns], 0, group=self.group))
-        for w in dist.batch_isend_irecv(ops):
-            w.wait()
-        if self.rank != 0:
-            return None
-        out = [(tuple(int(v) for v in H[0]), run_count[:nruns], run_value[:nruns])]
-        for r in range(1, self.world):
-            k = int(H[r][0])
-            out.append((tuple(int(v) for v in H[r]), self._recv_cnt[r][:k], self._recv_val[r][:k]))
-        return out
+                if k > self.cap:
+                    raise ValueError("rank %d sends %d bytes, capacity %d" % (r, k, self.cap))
+                buf = self._recv[slot][r][:k]
+                result.append((tuple(int(v) for v in H[r]), buf))
+                if k:
+                    ops.append(dist.P2POp(dist.irecv, buf, r, group=self.group))
+        elif nbytes:
+            ops.append(dist.P2POp(dist.isend, payload[:nbytes], 0, group=self.group))
+        works = dist.batch_isend_irecv(ops) if ops else []
+        self._inflight[slot] = (works, result)
+
+    def drain(self):
+        """Complete every transfer still in flight (oldest first)."""
+        for i in range(self.depth):
+            self._finish_slot((self._step + i) % self.depth)
 
 
 def shard_patterns(npat, world, rank):
