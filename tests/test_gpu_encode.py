@@ -209,3 +209,23 @@ def test_block_pack_unpack_roundtrip(ctx):
         assert lib.tc_block_unpack_dev(ctx.handle, C.c_void_p(buf.data_ptr()), k, sigma, ne.value, C.byref(out)) == 0
         assert np.array_equal(o_c.cpu().numpy().view(np.uint32), counts.astype(np.uint32))
         assert np.array_equal(o_v.cpu().numpy().view(np.uint16), vals.astype(np.uint16))
+
+
+def test_mtf_slow_and_fast_incoming_list_paths(ctx, monkeypatch):
+    """sigma <= 16: tiles recover their incoming list by a backward scan (fast) or by the
+    summary/scan launches (slow; also the fallback when the scan is ambiguous)."""
+    rng = np.random.default_rng(31)
+    late = b"A" * 40000 + bytes(rng.choice(list(b"ACGT"), 30000).astype(np.uint8)) + b"N" * 5 + b"T" * 20000
+    for t in (O.gen_acgtn(9, 100000).tobytes(), late, b"AB" * 30000):
+        L = O.bwt_encode_arr(t)
+        prim = int(np.nonzero(L < 0)[0][0])
+        Lb = np.where(L < 0, 0, L).astype(np.uint8)
+        eidx, efl = O.mtf_encode_arr(L)
+        for flag in ("1", "0"):
+            monkeypatch.setenv("TC_MTF_FASTIN", flag)
+            idx, fl = ctx.mtf_encode(Lb, prim)
+            assert idx.tolist() == eidx.tolist() and fl.tolist() == efl.tolist(), flag
+        # the raw text as an MTF input: symbols that only appear late make the scan ambiguous
+        idx, fl = ctx.mtf_encode(np.frombuffer(t, np.uint8), None)
+        e2, f2 = O.mtf_encode_arr(np.frombuffer(t, np.uint8).astype(np.int16))
+        assert idx.tolist() == e2.tolist() and fl.tolist() == f2.tolist()

@@ -4,6 +4,8 @@
 #include <math.h>
 #include <stdlib.h>
 
+#include <type_traits>
+
 #include "tc_mtf.hpp"
 #include "tc_radix_host.hpp"
 #include "tc_rle.hpp"
@@ -465,14 +467,30 @@ static void mtf_encode_device(tc_ctx *ctx, Arena &A, Acc acc, u64 N, const u32 *
     if (al.sigma <= 16 && !force_general) {
         Lut8 lut;
         for (int v = 0; v < 257; v++) lut.v[v] = (u8)al.code_of_sym[v];
-        mtf_nib_summary_kernel<Acc><<<tiles, MTF_NT, 0, s>>>(acc, N, lut, t_perm, t_mask);
-        TC_LAUNCH_CHECK(ctx);
-        mtf_nib_scan_kernel<<<1, MTF_NT, 0, s>>>(t_perm, t_mask, tiles);
-        TC_LAUNCH_CHECK(ctx);
-        mtf_nib_apply_kernel<Acc><<<tiles, MTF_NT, 0, s>>>(acc, N, lut, t_perm, d_idx);
-        TC_LAUNCH_CHECK(ctx);
-        tc_d2h(ctx, &ctx->h_scalars[8], t_perm + tiles, sizeof(u64));
-        TC_HIP(ctx, hipStreamSynchronize(s));
+        // fast path: every tile recovers its incoming list by a short backward scan
+        bool fast_ok = false;
+        if (env_int("TC_MTF_FASTIN", 1) != 0) {
+            u32 *flag = reinterpret_cast<u32 *>(ctx->d_scalars + 15);
+            tc_memset_async(ctx, flag, 0, sizeof(u64));
+            mtf_nib_apply_kernel<Acc, true><<<tiles, MTF_NT, 0, s>>>(acc, N, lut, t_perm, d_idx, al.sigma, flag);
+            TC_LAUNCH_CHECK(ctx);
+            mtf_nib_final_kernel<Acc><<<1, 64, 0, s>>>(acc, N, lut, al.sigma, t_perm + tiles, flag);
+            TC_LAUNCH_CHECK(ctx);
+            tc_d2h(ctx, &ctx->h_scalars[15], ctx->d_scalars + 15, sizeof(u64));
+            tc_d2h(ctx, &ctx->h_scalars[8], t_perm + tiles, sizeof(u64));
+            TC_HIP(ctx, hipStreamSynchronize(s));
+            fast_ok = ((u32)ctx->h_scalars[15]) == 0;
+        }
+        if (!fast_ok) {
+            mtf_nib_summary_kernel<Acc><<<tiles, MTF_NT, 0, s>>>(acc, N, lut, t_perm, t_mask);
+            TC_LAUNCH_CHECK(ctx);
+            mtf_nib_scan_kernel<<<1, MTF_NT, 0, s>>>(t_perm, t_mask, tiles);
+            TC_LAUNCH_CHECK(ctx);
+            mtf_nib_apply_kernel<Acc, false><<<tiles, MTF_NT, 0, s>>>(acc, N, lut, t_perm, d_idx, al.sigma, nullptr);
+            TC_LAUNCH_CHECK(ctx);
+            tc_d2h(ctx, &ctx->h_scalars[8], t_perm + tiles, sizeof(u64));
+            TC_HIP(ctx, hipStreamSynchronize(s));
+        }
         u64 perm = ctx->h_scalars[8];
         for (u32 i = 0; i < al.sigma; i++) final_list[i] = al.sym_of_code[(perm >> (4 * i)) & 15];
     } else {
@@ -493,7 +511,8 @@ static void mtf_encode_device(tc_ctx *ctx, Arena &A, Acc acc, u64 N, const u32 *
 template <class Acc, class SymT>
 static void rle_encode_device(tc_ctx *ctx, Arena &A, Acc acc, u64 N, u32 *d_counts, SymT *d_syms,
                               u64 cap, u64 *total, bool dry) {
-    const u32 tiles = tc_cdiv(N, RLE_TILE);
+    const bool idx_stream = std::is_same<Acc, U16Acc>::value;
+    const u32 tiles = tc_cdiv(N, idx_stream ? RLE16_TILE : RLE_TILE);
     u64 *status = A.get<u64>(2 * (size_t)tiles + 4);
     if (dry) return;
     tc_memset_async(ctx, status, 0, (2 * (size_t)tiles + 4) * sizeof(u64));
@@ -502,9 +521,15 @@ static void rle_encode_device(tc_ctx *ctx, Arena &A, Acc acc, u64 N, u32 *d_coun
     a.status_pair = status; a.status_sum = status + tiles;
     a.ticket = reinterpret_cast<u32 *>(status + 2 * (size_t)tiles);
     a.scalars = ctx->d_scalars; a.err = ctx->d_err;
-    u32 grid = tc_persistent_grid_for(ctx, rle_encode_kernel<Acc, SymT>, RLE_NT, 2);
-    if (grid > tiles) grid = tiles;
-    rle_encode_kernel<Acc, SymT><<<grid, RLE_NT, 0, ctx->stream>>>(acc, a);
+    if constexpr (std::is_same<Acc, U16Acc>::value) {
+        u32 grid = tc_persistent_grid_for(ctx, rle_encode_u16_kernel, RLE_NT, 2);
+        if (grid > tiles) grid = tiles;
+        rle_encode_u16_kernel<<<grid, RLE_NT, 0, ctx->stream>>>(acc, a);
+    } else {
+        u32 grid = tc_persistent_grid_for(ctx, rle_encode_kernel<Acc, SymT>, RLE_NT, 2);
+        if (grid > tiles) grid = tiles;
+        rle_encode_kernel<Acc, SymT><<<grid, RLE_NT, 0, ctx->stream>>>(acc, a);
+    }
     TC_LAUNCH_CHECK(ctx);
     tc_d2h(ctx, &ctx->h_scalars[2], ctx->d_scalars + 2, sizeof(u64));
     TC_HIP(ctx, hipStreamSynchronize(ctx->stream));

@@ -204,6 +204,59 @@ __device__ __forceinline__ NibSumm nib_block_excl(NibSumm mine, NibSumm *s_w, Ni
     return nib_combine(pre, exc);
 }
 
+
+// MTF list (codes, front = low nibble) just before position `pos`, recovered by scanning
+// BACKWARDS: the list is "symbols by last occurrence, most recent first, then the
+// never-seen ones in alphabet order".  One wave walks back 64 positions at a time until
+// at most one of the sigma codes is still unseen (its place is then forced: last).  On
+// high-entropy text that is one or two steps.  Returns false (every lane) if the window
+// of MTF_BACK_MAX positions did not settle it -- the caller then flags the slow path.
+#define MTF_BACK_MAX 8192
+template <class Acc>
+__device__ __forceinline__ bool nib_list_before(Acc acc, u64 pos, u32 sigma, const u8 *s_lut, u64 *out) {
+    u32 seen = 0;          // bit c set: code c already placed
+    u64 list = 0;          // placed codes, most recent first
+    u32 placed = 0;
+    u64 p = pos;
+    const u32 all = (sigma >= 32 ? 0xffffffffu : ((1u << sigma) - 1u));
+    for (u32 step = 0; step < MTF_BACK_MAX / 64 && p > 0 && __popc(all & ~seen) > 1; step++) {
+        const u64 lo = p >= 64 ? p - 64 : 0;                 // chunk [lo, p)
+        const u64 j = lo + lane_id();
+        const u32 c = j < p ? (u32)s_lut[acc(j) + 1] : 0xffu;
+        // walk this chunk from its most recent position down: take the unseen code with the
+        // highest position, repeat (at most sigma times)
+        u32 todo = all & ~seen;
+        while (todo) {
+            u64 best = 0;   // ballot of lanes holding a not-yet-placed code
+            best = __ballot(c < 16u && ((todo >> c) & 1u));
+            if (!best) break;
+            const int hl = 63 - __builtin_clzll(best);
+            const u32 cc = (u32)__shfl((int)c, hl, 64);
+            list |= (u64)cc << (4 * placed);
+            placed++;
+            seen |= 1u << cc;
+            todo &= ~(1u << cc);
+        }
+        p = lo;
+    }
+    u32 rest = all & ~seen;
+    if (__popc(rest) > 1 && p > 0) return false;   // window exhausted, still ambiguous
+    // never-seen codes follow in alphabet order (exactly right when p == 0 was reached)
+    while (rest) {
+        u32 cc = (u32)__builtin_ctz(rest);
+        list |= (u64)cc << (4 * placed);
+        placed++;
+        rest &= rest - 1;
+    }
+    // codes >= sigma are not part of the alphabet: park them behind (identity order)
+    for (u32 cc = sigma; cc < 16; cc++) {
+        list |= (u64)cc << (4 * placed);
+        placed++;
+    }
+    *out = list;
+    return true;
+}
+
 template <class Acc>
 __global__ __launch_bounds__(MTF_NT) void mtf_nib_summary_kernel(Acc acc, u64 N,
                                                                   Lut8 lut,
@@ -248,11 +301,14 @@ __global__ __launch_bounds__(MTF_NT) void mtf_nib_scan_kernel(u64 *t_perm, u32 *
     }
 }
 
-template <class Acc>
+// FASTIN: the tile's incoming list is recovered in-kernel by nib_list_before (no summary /
+// scan launches); `flag` is raised when that fails and the host reruns the 3-kernel path.
+template <class Acc, bool FASTIN>
 __global__ __launch_bounds__(MTF_NT) void mtf_nib_apply_kernel(Acc acc, u64 N,
                                                                 Lut8 lut,
                                                                 const u64 *__restrict__ t_perm,
-                                                                u16 *__restrict__ idx) {
+                                                                u16 *__restrict__ idx, u32 sigma,
+                                                                u32 *flag) {
     __shared__ u8 s_code[MTF_NT * MTF_STRIDE];
     __shared__ __attribute__((aligned(16))) i16 s_sym[MTF_TILE];
     __shared__ u8 s_lut[260];
@@ -267,7 +323,19 @@ __global__ __launch_bounds__(MTF_NT) void mtf_nib_apply_kernel(Acc acc, u64 N,
     NibSumm exc = nib_block_excl(mine, s_w, &agg);
     // true incoming list of this lane's chunk: tile's incoming list, then the
     // block-local prefix applied to it
-    NibSumm in = nib_combine(NibSumm{t_perm[blockIdx.x], 0u}, exc);
+    __shared__ u64 s_in;
+    if (FASTIN) {
+        if (threadIdx.x < 64) {
+            u64 l0 = NIB_IDENT;
+            bool ok = nib_list_before(acc, base, sigma, s_lut, &l0);
+            if (threadIdx.x == 0) {
+                s_in = l0;
+                if (!ok) atomicOr(flag, 1u);
+            }
+        }
+        __syncthreads();
+    }
+    NibSumm in = nib_combine(NibSumm{FASTIN ? s_in : t_perm[blockIdx.x], 0u}, exc);
     u64 list = in.perm;
     u32 *cw = reinterpret_cast<u32 *>(s_code + threadIdx.x * MTF_STRIDE);
 #pragma unroll 4
@@ -298,6 +366,21 @@ __global__ __launch_bounds__(MTF_NT) void mtf_nib_apply_kernel(Acc acc, u64 N,
     } else {
         for (u32 p = threadIdx.x; p < MTF_TILE; p += MTF_NT)
             if (base + p < N) idx[base + p] = (u16)s_sym[p];
+    }
+}
+
+// list after the last symbol (the MTF result's second component), FASTIN path
+template <class Acc>
+__global__ __launch_bounds__(64) void mtf_nib_final_kernel(Acc acc, u64 N, Lut8 lut, u32 sigma,
+                                                           u64 *out, u32 *flag) {
+    __shared__ u8 s_lut[260];
+    for (int i = threadIdx.x; i < 257; i += 64) s_lut[i] = lut.v[i];
+    __syncthreads();
+    u64 l0 = NIB_IDENT;
+    bool ok = nib_list_before(acc, N, sigma, s_lut, &l0);
+    if (threadIdx.x == 0) {
+        *out = l0;
+        if (!ok) atomicOr(flag, 1u);
     }
 }
 

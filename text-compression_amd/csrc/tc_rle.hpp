@@ -19,6 +19,8 @@
 #define RLE_NT 512
 #define RLE_ITEMS 8
 #define RLE_TILE (RLE_NT * RLE_ITEMS)
+#define RLE16_ITEMS 8
+#define RLE16_TILE (RLE_NT * RLE16_ITEMS)
 
 #ifdef __HIPCC__
 
@@ -168,6 +170,94 @@ __global__ __launch_bounds__(RLE_NT, 4) void rle_encode_kernel(Acc acc, RleArgs 
         curE += (u64)__popcll(f.ob) + (u64)__popcll(f.pb);
     }
     __syncthreads();  // LDS prefix slots are reused by the next tile
+    }
+}
+
+// Same pass for a stream that cannot contain Nothing (the MTF index stream): only run
+// heads and run tails exist, so two ballots per item, kept as wave-uniform masks between
+// the aggregate phase and the emit phase.
+__global__ __launch_bounds__(RLE_NT, 4) void rle_encode_u16_kernel(U16Acc acc, RleArgs a) {
+    constexpr int NW = RLE_NT / 64;
+    __shared__ u32 s_wh[NW], s_ws[NW];
+    __shared__ u64 s_pref[2];
+    __shared__ u32 s_tile;
+    __shared__ __attribute__((aligned(16))) i16 s_x[RLE16_TILE];
+    const int tid = threadIdx.x, w = tid >> 6, l = tid & 63;
+    if (tid == 0) s_tile = atomicAdd(a.ticket, 1u);
+    __syncthreads();
+    const u64 N = a.N;
+    const u32 ntiles = (u32)((N + RLE16_TILE - 1) / RLE16_TILE);
+    u16 *vals = reinterpret_cast<u16 *>(a.syms);
+    for (u32 tile = s_tile; tile < ntiles; tile += gridDim.x) {
+        const u64 base = (u64)tile * RLE16_TILE + (u64)w * 64 * RLE16_ITEMS;
+        stage_syms<RLE16_TILE, RLE_NT>(acc, (u64)tile * RLE16_TILE, N, s_x);
+        u32 x[RLE16_ITEMS];
+#pragma unroll
+        for (int k = 0; k < RLE16_ITEMS; k++) x[k] = (u32)(u16)s_x[w * 64 * RLE16_ITEMS + k * 64 + l];
+        u32 xprev0 = 0x10000u, xnextT = 0x10000u;  // impossible values: force head / tail
+        if (base > 0 && base <= N) xprev0 = (u32)acc(base - 1);
+        if (base + (u64)64 * RLE16_ITEMS < N) xnextT = (u32)acc(base + (u64)64 * RLE16_ITEMS);
+        u64 hb[RLE16_ITEMS], pb[RLE16_ITEMS];
+        u32 wh = 0, ws = 0;
+#pragma unroll
+        for (int k = 0; k < RLE16_ITEMS; k++) {
+            const u64 jb0 = base + (u64)k * 64;
+            const u64 j = jb0 + l;
+            const bool in = j < N;
+            u32 up = (u32)__shfl_up((int)x[k], 1, 64), dn = (u32)__shfl_down((int)x[k], 1, 64);
+            u32 p0 = (k == 0) ? xprev0 : (u32)__shfl((int)x[(k + RLE16_ITEMS - 1) % RLE16_ITEMS], 63, 64);
+            u32 n0 = (k == RLE16_ITEMS - 1) ? xnextT : (u32)__shfl((int)x[(k + 1) % RLE16_ITEMS], 0, 64);
+            u32 xp = (l == 0) ? p0 : up, xn = (l == 63) ? n0 : dn;
+            hb[k] = __ballot(in && (j == 0 || xp != x[k]));
+            pb[k] = __ballot(in && (j == N - 1 || xn != x[k]));
+            if (hb[k]) wh = (u32)(jb0 + 63u - (u32)__builtin_clzll(hb[k])) + 1u;
+            ws += (u32)__popcll(pb[k]);
+        }
+        if (l == 0) {
+            s_wh[w] = wh;
+            s_ws[w] = ws;
+        }
+        __syncthreads();
+        u32 ph = 0, ps = 0, bh = 0, bs = 0;
+#pragma unroll
+        for (int i = 0; i < NW; i++) {
+            if (i < w) {
+                ph = ph > s_wh[i] ? ph : s_wh[i];
+                ps += s_ws[i];
+            }
+            bh = bh > s_wh[i] ? bh : s_wh[i];
+            bs += s_ws[i];
+        }
+        if (w == 0) {
+            u64 e = lb_exclusive<OpMax>(a.status_pair, tile, bh, a.err);
+            if (l == 0) s_pref[0] = e;
+        } else if (w == 1) {
+            u64 e = lb_exclusive<OpSum>(a.status_sum, tile, bs, a.err);
+            if (l == 0) {
+                s_pref[1] = e;
+                if ((u64)(tile + 1) * RLE16_TILE >= N) a.scalars[2] = e + bs;
+            }
+        }
+        __syncthreads();
+        u32 curH = ph > (u32)s_pref[0] ? ph : (u32)s_pref[0];
+        u64 curE = s_pref[1] + ps;
+#pragma unroll
+        for (int k = 0; k < RLE16_ITEMS; k++) {
+            const u64 jb0 = base + (u64)k * 64;
+            if (jb0 >= N) break;
+            if ((pb[k] >> l) & 1ull) {
+                const u64 hm = hb[k] & ((2ull << l) - 1ull);
+                const u32 H = hm ? (u32)(jb0 + 63u - (u32)__builtin_clzll(hm)) + 1u : curH;
+                const u64 e = curE + (u64)__popcll(pb[k] & lanemask_lt());
+                if (e < a.cap) {
+                    a.counts[e] = (u32)(jb0 + l + 2 - H);
+                    vals[e] = (u16)x[k];
+                }
+            }
+            if (hb[k]) curH = (u32)(jb0 + 63u - (u32)__builtin_clzll(hb[k])) + 1u;
+            curE += (u64)__popcll(pb[k]);
+        }
+        __syncthreads();
     }
 }
 
