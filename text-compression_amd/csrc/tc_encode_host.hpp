@@ -223,12 +223,28 @@ static void sa_run(tc_ctx *ctx, SaBuffers &b, const u8 *d_text, u64 n, u32 *d_sa
         bool onehist = cfg.w == 8 && plan.npass < RDX_MAX_PASSES && env_int("TC_KB_ONEHIST", 1) != 0;
         for (int p = 0; p < plan.npass; p++)
             if (plan.mask[p] != 255u || plan.shift[p] % 8 != 0) onehist = false;
-        if (onehist) {
-            keybuild_kernel<true><<<tc_cdiv(N, SA_TILE), SA_NT, 0, s>>>(d_text, (u32)n, kp, b.k0, b.hist);
+        const u32 kgrid = tc_cdiv(N, SA_TILE);
+        // fused first pass: keys are generated inside the first radix pass (no key array
+        // written + re-read); needs the shared-histogram configuration
+        const bool fuse = onehist && RDX_TILE == SA_TILE && env_int("TC_KEYGEN_FUSED", 1) != 0;
+        RadixKeyGen kg;
+        if (fuse) {
+            kg.n_text = (u32)n; kg.B = cfg.B; kg.w = cfg.w; kg.s = cfg.s; kg.P = cfg.P;
+            memcpy(kg.lut, cfg.lut, sizeof kg.lut);
+            u32 ggrid = tc_cdiv(N, 256 * 16 * 4);
+            if (ggrid > 2048) ggrid = 2048;
+            ghist_kernel<<<ggrid, 256, 0, s>>>(d_text, (u32)n, kp, b.hist);
+            TC_LAUNCH_CHECK(ctx);
+            keyhist_fix_kernel<<<1, 256, 0, s>>>(d_text, (u32)n, kp, b.hist);
+        } else if (onehist) {
+            // unrolled instances for the DNA-like configuration (3 symbols per field)
+            if (cfg.s == 3 && cfg.P == 6) keybuild_kernel<true, 3, 6><<<kgrid, SA_NT, 0, s>>>(d_text, (u32)n, kp, b.k0, b.hist);
+            else if (cfg.s == 3 && cfg.P == 5) keybuild_kernel<true, 3, 5><<<kgrid, SA_NT, 0, s>>>(d_text, (u32)n, kp, b.k0, b.hist);
+            else keybuild_kernel<true, 0, 0><<<kgrid, SA_NT, 0, s>>>(d_text, (u32)n, kp, b.k0, b.hist);
             TC_LAUNCH_CHECK(ctx);
             keyhist_fix_kernel<<<1, 256, 0, s>>>(d_text, (u32)n, kp, b.hist);
         } else {
-            keybuild_kernel<false><<<tc_cdiv(N, SA_TILE), SA_NT, 0, s>>>(d_text, (u32)n, kp, b.k0, b.hist);
+            keybuild_kernel<false, 0, 0><<<kgrid, SA_NT, 0, s>>>(d_text, (u32)n, kp, b.k0, b.hist);
         }
         TC_LAUNCH_CHECK(ctx);
         // ping-pong arranged so that the sorted values land in `va` (or, when a finish
@@ -241,12 +257,15 @@ static void sa_run(tc_ctx *ctx, SaBuffers &b, const u8 *d_text, u64 n, u32 *d_sa
         rb.hist = b.hist;
         rb.status = b.rstatus;
         ctx->pev_used = 0;
-        radix_sort_pairs(ctx, rb, (u32)N, plan, /*gen_idx=*/true, /*hist_ready=*/true, /*timed=*/true);
+        radix_sort_pairs(ctx, rb, (u32)N, plan, /*gen_idx=*/true, /*hist_ready=*/true, /*timed=*/true,
+                         d_text, fuse ? &kg : nullptr);
     };
     const int rbits = ceil_log2_u64(N);
     const int keybits = (int)(cfg.P * cfg.w);
     u32 *sa = va;
     const u64 *skeys = nullptr;
+    const u64 *tkeys = nullptr;
+    int tkeys_shift = 0;
     u64 m = 0;
     bool have_groups = false;
     tc_memset_async(ctx, ctx->d_scalars, 0, 16 * sizeof(u64));
@@ -282,6 +301,8 @@ static void sa_run(tc_ctx *ctx, SaBuffers &b, const u8 *d_text, u64 n, u32 *d_sa
             if (!over && fm <= b.sparse_cap - 1024) {
                 m = fm;
                 have_groups = true;
+                tkeys = rb.keys;
+                tkeys_shift = 64 - topbits;
                 st.rounds = 1;
                 st.m[0] = N; st.key_bytes[0] = 8; st.passes[0] = (u32)plan.npass; st.h[0] = 0;
                 if (m > 0) {  // bring the tied set into SA order (refine relies on it)
@@ -334,7 +355,7 @@ static void sa_run(tc_ctx *ctx, SaBuffers &b, const u8 *d_text, u64 n, u32 *d_sa
         }
         rl.isa = b.isa;
     } else {
-        rl.skeys = skeys; rl.sa = sa; rl.t_idx = b.t_idx; rl.t_rank = b.t_rank; rl.t_n = (u32)m;
+        rl.skeys = skeys; rl.tkeys = tkeys; rl.tshift = tkeys_shift; rl.sa = sa; rl.t_idx = b.t_idx; rl.t_rank = b.t_rank; rl.t_n = (u32)m;
         if (m > 0) {
             u32 mm = (u32)m;
             widen_u32_kernel<<<tc_cdiv(mm, 256), 256, 0, s>>>(b.act[0][1], b.sk[0], mm);

@@ -16,15 +16,17 @@
 #define RDX_BITS 8
 #define RDX_BINS 256
 #define RDX_MAX_PASSES 16
+// tile shape: 4096 pairs per tile; 256 threads x 16 items measured best on MI355X
+// (512x8 9.0, 1024x8 8.7, 512x16 8.6, 256x16 8.5 ms per 2^30-pair pass)
 #ifndef RDX_NT
-#define RDX_NT 512
+#define RDX_NT 256
 #endif
 #ifndef RDX_ITEMS
-#define RDX_ITEMS 8
+#define RDX_ITEMS 16
 #endif
 #define RDX_TILE (RDX_NT * RDX_ITEMS)
 #ifndef RDX_MINW
-#define RDX_MINW 6
+#define RDX_MINW 3
 #endif
 #define RDX_LB_WAVES(persist) ((persist) ? 4 : RDX_MINW)
 
@@ -46,6 +48,14 @@ struct RadixPlan {
             npass++;
         }
     }
+};
+
+// first pass of the suffix sort: keys are built from the text inside the pass (no key array
+// is ever written or read for it); see keybuild_kernel in tc_sa.hpp for the key layout
+struct RadixKeyGen {
+    u32 n_text;   // text length; pairs sorted = n_text + 1
+    u32 B, w, s, P;
+    u16 lut[256];
 };
 
 struct RadixPlanDev {
@@ -92,11 +102,12 @@ __global__ __launch_bounds__(256) void radix_scan_hist_kernel(u32 *hist) {
 // LBB: status words fetched per look-back round trip.
 // SPLIT = true: no look-back at all -- per-tile digit offsets come from a scanned
 //   [tile][digit] matrix written by radix_tile_hist_kernel (classic 3-kernel pass).
-template <bool GEN_IDX, bool PERSIST, int LBB, bool SPLIT>
+template <bool GEN_IDX, bool PERSIST, int LBB, bool SPLIT, bool KEYGEN>
 __global__ __launch_bounds__(RDX_NT, RDX_LB_WAVES(PERSIST)) void radix_pass_kernel(
     const u64 *__restrict__ kin, const u32 *__restrict__ vin, u64 *__restrict__ kout,
     u32 *__restrict__ vout, u32 n, int shift, u32 mask, const u32 *__restrict__ bucket_base,
-    u64 *status, u32 *ticket, u32 *err, const u32 *__restrict__ tile_offs) {
+    u64 *status, u32 *ticket, u32 *err, const u32 *__restrict__ tile_offs,
+    const u8 *__restrict__ text, RadixKeyGen kg) {
     constexpr int NW = RDX_NT / 64;
 #ifdef TC_RADIX_DIAG
     const int shift_raw = shift;  // timing-only ablation bits ride in the high bits of `shift`
@@ -115,10 +126,13 @@ __global__ __launch_bounds__(RDX_NT, RDX_LB_WAVES(PERSIST)) void radix_pass_kern
     static_assert(NW * RDX_BINS * 12 <= RDX_TILE * 12, "histograms + match masks must fit under the staging area");
     __shared__ u32 s_dbase[RDX_BINS];
     __shared__ u32 s_gbase[RDX_BINS];
+    __shared__ u16 s_klut[KEYGEN ? 256 : 1];
     __shared__ u32 s_scan[RDX_NT / 64 + 1];
     __shared__ u32 s_tile;
 
     const int tid = threadIdx.x, w = tid >> 6, l = tid & 63;
+    if (KEYGEN)
+        for (int i = tid; i < 256; i += RDX_NT) s_klut[i] = kg.lut[i];
     if (SPLIT) {
         if (tid == 0) s_tile = blockIdx.x;
     } else if (PERSIST || (shift_raw & 0x100000)) {
@@ -167,12 +181,84 @@ __global__ __launch_bounds__(RDX_NT, RDX_LB_WAVES(PERSIST)) void radix_pass_kern
             }
         }
     };
-    load_tile(first, key, val);
+    if (!KEYGEN) load_tile(first, key, val);
 
     for (u32 tile = first; tile < ntiles; tile += G) {
         const u64 base = (u64)tile * RDX_TILE;
         const u32 valid = (n - base) < (u64)RDX_TILE ? (u32)(n - base) : (u32)RDX_TILE;
         if (PERSIST) load_tile(tile + G, nkey, nval);  // prefetch; consumed next iteration
+        if (KEYGEN) {
+            // ---- keys of suffixes [base, base + TILE) straight from the text ---------------
+            // LDS image (codes, G values, raw bytes) lives at +16 KB of the staging area,
+            // clear of the histograms / match masks at its head
+            constexpr int KG_PRE = 16, KG_SLOTS = RDX_TILE + KG_PRE + 80;
+            u16 *k_c = reinterpret_cast<u16 *>(s_raw + 16384);
+            u16 *k_g = k_c + KG_SLOTS;
+            u8 *k_r = reinterpret_cast<u8 *>(k_g + KG_SLOTS);
+            static_assert(16384 + KG_SLOTS * 5 <= RDX_TILE * 12, "key-generation image must fit in the staging area");
+            const u32 nt = kg.n_text;
+            const u32 span = RDX_TILE + kg.P * kg.s + kg.s;
+            const u32 units = (KG_PRE + span + 15) / 16;
+            const bool aligned = (((uintptr_t)text) & 15) == 0;
+            for (u32 u = tid; u < units; u += RDX_NT) {
+                const i64 p0 = (i64)base - KG_PRE + (i64)u * 16;
+                u8 raw[16];
+                if (aligned && p0 >= 0 && p0 + 16 <= (i64)nt) {
+                    uint4 v = *reinterpret_cast<const uint4 *>(text + p0);
+                    u32 xx[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+                    for (int q = 0; q < 16; q++) raw[q] = (u8)(xx[q >> 2] >> (8 * (q & 3)));
+                } else {
+#pragma unroll
+                    for (int q = 0; q < 16; q++) {
+                        i64 pp = p0 + q;
+                        raw[q] = (pp >= 0 && pp < (i64)nt) ? text[pp] : (u8)0;
+                    }
+                }
+                u32 cw[8], rw[4];
+#pragma unroll
+                for (int q = 0; q < 16; q += 2) {
+                    i64 pa = p0 + q, pb = p0 + q + 1;
+                    u32 ca = (pa >= 0 && pa < (i64)nt) ? (u32)s_klut[raw[q]] : 0u;
+                    u32 cb = (pb >= 0 && pb < (i64)nt) ? (u32)s_klut[raw[q + 1]] : 0u;
+                    cw[q >> 1] = ca | (cb << 16);
+                }
+#pragma unroll
+                for (int q = 0; q < 4; q++)
+                    rw[q] = raw[4 * q] | (raw[4 * q + 1] << 8) | (raw[4 * q + 2] << 16) | ((u32)raw[4 * q + 3] << 24);
+                uint4 *dc = reinterpret_cast<uint4 *>(k_c + u * 16);
+                dc[0] = make_uint4(cw[0], cw[1], cw[2], cw[3]);
+                dc[1] = make_uint4(cw[4], cw[5], cw[6], cw[7]);
+                *reinterpret_cast<uint4 *>(k_r + u * 16) = make_uint4(rw[0], rw[1], rw[2], rw[3]);
+            }
+            __syncthreads();
+            const u32 gslots = KG_PRE + RDX_TILE + kg.P * kg.s;
+            for (u32 q = tid; q < gslots; q += RDX_NT) {
+                u32 g = 0;
+                for (u32 j = 0; j < kg.s; j++) g = g * kg.B + k_c[q + j];
+                k_g[q] = (u16)g;
+            }
+            __syncthreads();
+#pragma unroll
+            for (int k = 0; k < RDX_ITEMS; k++) {
+                const u32 p = wofs + k * 64 + l;
+                if (base + p < n) {
+                    const u32 q = KG_PRE + p;
+                    u64 kk = 0;
+                    int sh = 64;
+                    for (u32 f = 0; f < kg.P; f++) {
+                        sh -= kg.w;
+                        kk |= (u64)k_g[q + f * kg.s] << sh;
+                    }
+                    key[k] = kk | (u64)k_r[q - 1];
+                    val[k] = (u32)base + p;
+                } else {
+                    key[k] = ~0ull;
+                    val[k] = 0;
+                }
+            }
+            __syncthreads();
+        }
         if (!(shift_raw & 0x4000))
             for (int i = tid; i < NW * RDX_BINS * 3; i += RDX_NT) s_hist[i] = 0;  // histograms + masks
         __syncthreads();
@@ -416,4 +502,5 @@ static inline size_t radix_status_words(u64 n) {
 }
 
 void radix_sort_pairs(tc_ctx *ctx, RadixBuffers &b, u32 n, const RadixPlan &plan, bool gen_idx,
-                      bool hist_ready, bool timed = false);
+                      bool hist_ready, bool timed = false, const u8 *text = nullptr,
+                      const RadixKeyGen *keygen = nullptr);

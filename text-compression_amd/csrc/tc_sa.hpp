@@ -34,12 +34,14 @@ struct SaConfig {
 #ifdef __HIPCC__
 
 // ---- byte histogram -----------------------------------------------------------
+// One LDS counter per (byte value, lane): lanes never share an address, and the bank is
+// the lane id, so a 5-letter text does not serialise 64 ways on 5 hot counters.
 __global__ __launch_bounds__(256) void hist256_kernel(const u8 *__restrict__ text, u64 n,
                                                       u32 *__restrict__ counts) {
-    __shared__ u32 s_h[4][256];
-    for (int i = threadIdx.x; i < 1024; i += 256) (&s_h[0][0])[i] = 0;
+    __shared__ u32 s_h[256 * 64];
+    for (int i = threadIdx.x; i < 256 * 64; i += 256) s_h[i] = 0;
     __syncthreads();
-    u32 *h = s_h[threadIdx.x >> 6];
+    u32 *h = s_h + (threadIdx.x & 63);
     const u64 nvec = ((uintptr_t)text & 15) ? 0 : n / 16;
     const uint4 *tv = reinterpret_cast<const uint4 *>(text);
     for (u64 i = (u64)blockIdx.x * 256 + threadIdx.x; i < nvec; i += (u64)gridDim.x * 256) {
@@ -47,16 +49,17 @@ __global__ __launch_bounds__(256) void hist256_kernel(const u8 *__restrict__ tex
         u32 x[4] = {v.x, v.y, v.z, v.w};
 #pragma unroll
         for (int q = 0; q < 4; q++) {
-            atomicAdd(&h[x[q] & 255], 1u);
-            atomicAdd(&h[(x[q] >> 8) & 255], 1u);
-            atomicAdd(&h[(x[q] >> 16) & 255], 1u);
-            atomicAdd(&h[x[q] >> 24], 1u);
+            atomicAdd(&h[(x[q] & 255) * 64], 1u);
+            atomicAdd(&h[((x[q] >> 8) & 255) * 64], 1u);
+            atomicAdd(&h[((x[q] >> 16) & 255) * 64], 1u);
+            atomicAdd(&h[(x[q] >> 24) * 64], 1u);
         }
     }
     for (u64 i = nvec * 16 + (u64)blockIdx.x * 256 + threadIdx.x; i < n; i += (u64)gridDim.x * 256)
-        atomicAdd(&h[text[i]], 1u);
+        atomicAdd(&h[(u32)text[i] * 64], 1u);
     __syncthreads();
-    u32 c = s_h[0][threadIdx.x] + s_h[1][threadIdx.x] + s_h[2][threadIdx.x] + s_h[3][threadIdx.x];
+    u32 c = 0;
+    for (int l = 0; l < 64; l++) c += s_h[threadIdx.x * 64 + ((l + threadIdx.x) & 63)];
     if (c) atomicAdd(&counts[threadIdx.x], c);
 }
 
@@ -78,7 +81,7 @@ struct KeyBuildParams {
 #define KB_PRE 16  // LDS slot 0 = text position base - KB_PRE (keeps 16-byte units aligned)
 #define KB_SLOTS (SA_TILE + KB_PRE + KB_HALO + 8)
 
-template <bool ONEHIST>
+template <bool ONEHIST, int CS, int CP>  // CS/CP: compile-time s / P (0 = take them from kp)
 __global__ __launch_bounds__(SA_NT) void keybuild_kernel(const u8 *__restrict__ text, u32 n,
                                                          KeyBuildParams kp,
                                                          u64 *__restrict__ keys,
@@ -91,12 +94,13 @@ __global__ __launch_bounds__(SA_NT) void keybuild_kernel(const u8 *__restrict__ 
     const int tid = threadIdx.x;
     const u32 N = n + 1;
     const u64 base = (u64)blockIdx.x * SA_TILE;
+    const u32 KS = CS ? (u32)CS : kp.s, KP = CP ? (u32)CP : kp.P;
     const int nh = ONEHIST ? RDX_BINS : kp.plan.npass * RDX_BINS;
     for (int i = tid; i < nh; i += SA_NT) s_h[i] = 0;
     s_lut[tid] = kp.lut[tid];
     __syncthreads();
     // phase A: text -> codes + raw, 16 bytes per thread per step
-    const u32 span = SA_TILE + kp.P * kp.s + kp.s;            // symbols needed from `base`
+    const u32 span = SA_TILE + KP * KS + KS;                  // symbols needed from `base`
     const u32 units = (KB_PRE + span + 15) / 16;
     const bool aligned = (((uintptr_t)text) & 15) == 0;
     for (u32 u = tid; u < units; u += SA_NT) {
@@ -131,10 +135,11 @@ __global__ __launch_bounds__(SA_NT) void keybuild_kernel(const u8 *__restrict__ 
     }
     __syncthreads();
     // phase B: G(p) for every slot that a key of this tile can touch
-    const u32 gslots = KB_PRE + SA_TILE + kp.P * kp.s;
+    const u32 gslots = KB_PRE + SA_TILE + KP * KS;
     for (u32 q = tid; q < gslots; q += SA_NT) {
         u32 g = 0;
-        for (u32 j = 0; j < kp.s; j++) g = g * kp.B + s_c[q + j];
+#pragma unroll
+        for (u32 j = 0; j < KS; j++) g = g * kp.B + s_c[q + j];
         s_g[q] = (u16)g;
     }
     __syncthreads();
@@ -147,9 +152,10 @@ __global__ __launch_bounds__(SA_NT) void keybuild_kernel(const u8 *__restrict__ 
             const u32 q = KB_PRE + p;
             u64 key = 0;
             int sh = 64;
-            for (u32 f = 0; f < kp.P; f++) {
+#pragma unroll
+            for (u32 f = 0; f < KP; f++) {
                 sh -= kp.w;
-                key |= (u64)s_g[q + f * kp.s] << sh;
+                key |= (u64)s_g[q + f * KS] << sh;
             }
             key |= (u64)s_raw[q - 1];
             keys[i] = key;
@@ -166,6 +172,48 @@ __global__ __launch_bounds__(SA_NT) void keybuild_kernel(const u8 *__restrict__ 
         u32 c = s_h[i];
         if (c) atomicAdd(&hist[ONEHIST ? (RDX_MAX_PASSES - 1) * RDX_BINS + i : i], c);
     }
+}
+
+// Histogram of G over all N positions, straight from the text (used when the first radix
+// pass generates its keys itself, so no keybuild launch exists to take it).  Same
+// conflict-free [value][lane] LDS layout as hist256_kernel.  Result in the LAST hist row.
+__global__ __launch_bounds__(256) void ghist_kernel(const u8 *__restrict__ text, u32 n,
+                                                    KeyBuildParams kp, u32 *__restrict__ hist) {
+    __shared__ u32 s_h[256 * 64];
+    __shared__ u16 s_lut[256];
+    for (int i = threadIdx.x; i < 256 * 64; i += 256) s_h[i] = 0;
+    s_lut[threadIdx.x] = kp.lut[threadIdx.x];
+    __syncthreads();
+    u32 *h = s_h + (threadIdx.x & 63);
+    const u64 N = (u64)n + 1;
+    const bool aligned = (((uintptr_t)text) & 15) == 0;
+    const u64 units = (N + 15) / 16;
+    for (u64 u = (u64)blockIdx.x * 256 + threadIdx.x; u < units; u += (u64)gridDim.x * 256) {
+        const u64 p0 = u * 16;
+        u32 c[32];
+        if (aligned && p0 + 32 <= n) {
+            const uint4 *tv = reinterpret_cast<const uint4 *>(text + p0);
+            uint4 a = tv[0], b = tv[1];
+            u32 x[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+#pragma unroll
+            for (int q = 0; q < 32; q++) c[q] = s_lut[(x[q >> 2] >> (8 * (q & 3))) & 255];
+        } else {
+#pragma unroll
+            for (int q = 0; q < 32; q++) c[q] = (p0 + q < n) ? (u32)s_lut[text[p0 + q]] : 0u;
+        }
+#pragma unroll
+        for (int j = 0; j < 16; j++) {
+            if (p0 + j < N) {
+                u32 g = 0;
+                for (u32 t = 0; t < kp.s; t++) g = g * kp.B + c[j + t];   // s <= 8 < 17
+                atomicAdd(&h[g * 64], 1u);
+            }
+        }
+    }
+    __syncthreads();
+    u32 cnt = 0;
+    for (int l = 0; l < 64; l++) cnt += s_h[threadIdx.x * 64 + ((l + threadIdx.x) & 63)];
+    if (cnt) atomicAdd(&hist[(RDX_MAX_PASSES - 1) * RDX_BINS + threadIdx.x], cnt);
 }
 
 // ONEHIST fix-up (one block): H sits in the LAST histogram row; pass q sorts field f_q,
@@ -580,6 +628,8 @@ struct RankLookup {
     const u32 *t_rank;
     u32 t_n;
     const u64 *skeys;    // sorted round-0 keys (low byte = payload), or null
+    const u64 *tkeys;    // keys sorted by their bits >= tshift only (fast path), or null
+    int tshift;
     const u32 *sa;       // the suffix array after round 0 (used when skeys is null)
     const u8 *text;
     u32 n, N;
@@ -610,9 +660,35 @@ __device__ __forceinline__ u32 rank_of(const RankLookup &r, const u16 *s_lut, u6
         if (lo < r.t_n && r.t_idx[lo] == (u32)p) return r.t_rank[lo];
     }
     if (!r.skeys) {
-        // suffix p was unique after round 0: its rank is its position in the SA, found by
-        // comparing the first h0 symbols against the suffixes the SA points at
+        // suffix p was unique after round 0: its rank is its position in the SA.  The
+        // partially sorted keys narrow it to its (tiny) top-bits bucket first; inside
+        // the bucket the first h0 symbols are compared against the suffixes the SA
+        // points at.
         u64 lo = 0, hi = r.N;
+        if (r.tkeys) {
+            u64 key = 0;
+            int sh = 64;
+            u64 q = p;
+            for (u32 f = 0; f < r.P; f++) {
+                u32 g = 0;
+                for (u32 t = 0; t < r.s; t++, q++) g = g * r.B + (q < r.n ? (u32)s_lut[r.text[q]] : 0u);
+                sh -= r.w;
+                key |= (u64)g << sh;
+            }
+            const u64 tk = key >> r.tshift;
+            u64 a = 0, b = r.N;  // first index with top bits >= tk
+            while (a < b) {
+                u64 mid = (a + b) >> 1;
+                if ((r.tkeys[mid] >> r.tshift) < tk) a = mid + 1; else b = mid;
+            }
+            lo = a;
+            b = r.N;             // first index with top bits > tk
+            while (a < b) {
+                u64 mid = (a + b) >> 1;
+                if ((r.tkeys[mid] >> r.tshift) <= tk) a = mid + 1; else b = mid;
+            }
+            hi = a;
+        }
         while (lo < hi) {
             u64 mid = (lo + hi) >> 1;
             if (suffix_cmp(r.text, r.n, r.sa[mid], p, r.h0) < 0) lo = mid + 1; else hi = mid;
