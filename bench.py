@@ -31,18 +31,33 @@ def parse():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--n", type=int, default=GIB, help="record size in bytes (default 1 GiB = BASELINE configs[2])")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-sample", type=int, default=32 << 20, help="bytes of the workload timed on the CPU port")
+    ap.add_argument("--cpu-sample", type=int, default=64 << 20, help="bytes of the workload timed on the CPU port")
     return ap.parse_args()
 
 
 def algorithmic_bytes(st, n):
-    """A = A_sa + A_bwt + A_mtf + A_rle from the counters the library reports."""
+    """A = A_sa + A_bwt + A_mtf + A_rle from the counters the library reports
+    (R, m_r, k_r, P_r); DESIGN.md section 5 states the per-kernel terms."""
     N = n + 1
     a_sa = n
     for r in range(st.rounds):
         m, k, P = int(st.m[r]), int(st.key_bytes[r]), int(st.passes[r])
         a_sa += m * ((k + 4) * 2 * P + k) + m * (k + 12) + m * (k + 8)
     return a_sa + 6 * N + 2 * N + N + 5 * int(st.runs)
+
+
+def radix_launch_bytes(st, n):
+    """Algorithmic bytes of the timed round-0 radix-pass launches: (k+4)*2 = 24 B per suffix
+    per pass, except a fused first pass, which reads the text (1 B) instead of a key array
+    (12 B).  Returns the mean per launch."""
+    N = n + 1
+    L = int(st.radix_launches)
+    if L == 0:
+        return 0
+    total = 24 * N * L
+    if st.keygen_fused:
+        total -= 11 * N
+    return total / L
 
 
 def cpu_baseline(n_sample, seed):
@@ -150,12 +165,12 @@ def main():
         roof = None
         if launches:
             avg_ms = st.ms_radix / launches
-            per_launch = 24 * (n + 1)  # (k+4)*2 bytes per suffix per pass, k = 8 (SURVEY 8d sort term)
+            per_launch = radix_launch_bytes(st, n)
             ach = per_launch / (avg_ms * 1e-3) / 1e9
             roof = {"bound": "hbm", "kernel": "radix_pass_kernel", "achieved": round(ach, 1), "peak": 8000.0,
                     "unit": "GB/s", "frac": round(ach / 8000.0, 4), "traffic": None,
                     "launches_per_step": launches, "avg_launch_ms": round(avg_ms, 4),
-                    "algorithmic_bytes_per_launch": per_launch,
+                    "algorithmic_bytes_per_launch": int(per_launch), "first_pass_builds_keys": bool(st.keygen_fused),
                     "pipeline_algorithmic_bytes": A, "pipeline_bytes_per_input_byte": round(A / n, 1),
                     "pipeline_achieved_GBps": round(A / (dt / a.steps) / 1e9, 1)}
             pj = os.path.join(ROOT, "profiles", "traffic_latest.json")

@@ -69,6 +69,9 @@ typedef struct tc_stats {
      * events on the ctx stream when tc_ctx_set_profile(ctx, 1) is on */
     uint32_t radix_launches;         /* round-0 pass launches timed */
     float ms_radix;                  /* their summed duration */
+    uint32_t keygen_fused;           /* 1: the first pass builds its keys from the text (reads 1 B,
+                                        writes 12 B per suffix instead of 12 + 12) */
+    uint32_t finish_pass;            /* 1: round 0 = partial sort + finish kernel (12 B read, 5 B written) */
 } tc_stats;
 
 /* The encoded block of the fused BWT -> MTF -> RLE pipeline.  The reference has

@@ -227,6 +227,7 @@ static void sa_run(tc_ctx *ctx, SaBuffers &b, const u8 *d_text, u64 n, u32 *d_sa
         // fused first pass: keys are generated inside the first radix pass (no key array
         // written + re-read); needs the shared-histogram configuration
         const bool fuse = onehist && RDX_TILE == SA_TILE && env_int("TC_KEYGEN_FUSED", 1) != 0;
+        st.keygen_fused = fuse ? 1u : 0u;
         RadixKeyGen kg;
         if (fuse) {
             kg.n_text = (u32)n; kg.B = cfg.B; kg.w = cfg.w; kg.s = cfg.s; kg.P = cfg.P;
@@ -303,6 +304,7 @@ static void sa_run(tc_ctx *ctx, SaBuffers &b, const u8 *d_text, u64 n, u32 *d_sa
                 have_groups = true;
                 tkeys = rb.keys;
                 tkeys_shift = 64 - topbits;
+                st.finish_pass = 1;
                 st.rounds = 1;
                 st.m[0] = N; st.key_bytes[0] = 8; st.passes[0] = (u32)plan.npass; st.h[0] = 0;
                 if (m > 0) {  // bring the tied set into SA order (refine relies on it)

@@ -32,7 +32,8 @@ class Stats(C.Structure):
                 ("passes", C.c_uint32 * TC_MAX_ROUNDS), ("h", C.c_uint32 * TC_MAX_ROUNDS),
                 ("runs", C.c_uint64), ("ms_sa", C.c_float), ("ms_bwt", C.c_float),
                 ("ms_mtf", C.c_float), ("ms_rle", C.c_float), ("ms_total", C.c_float),
-                ("radix_launches", C.c_uint32), ("ms_radix", C.c_float)]
+                ("radix_launches", C.c_uint32), ("ms_radix", C.c_float),
+                ("keygen_fused", C.c_uint32), ("finish_pass", C.c_uint32)]
 
 
 class Block(C.Structure):
