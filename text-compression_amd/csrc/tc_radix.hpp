@@ -95,13 +95,12 @@ __global__ __launch_bounds__(256) void radix_scan_hist_kernel(u32 *hist) {
 }
 
 // ---- one pass ---------------------------------------------------------------
-// PERSIST = false: one tile per block, tile id from an atomic ticket (a tile only
-//   ever waits on tiles whose blocks are already running).
-// PERSIST = true: each block draws ONE ticket k and processes tiles k, k+G, k+2G, ..
-//   (G = gridDim.x co-resident blocks), prefetching the next tile into registers.
-// LBB: status words fetched per look-back round trip.
-// SPLIT = true: no look-back at all -- per-tile digit offsets come from a scanned
-//   [tile][digit] matrix written by radix_tile_hist_kernel (classic 3-kernel pass).
+// Shipped instance: PERSIST = false (one tile per block, tile id from an atomic ticket: a
+// tile only ever waits on tiles whose blocks are already running), LBB = 1 (look-back
+// fetches one status word per round trip), SPLIT = false.  The other settings are the
+// round-1 experiments (persistent blocks with register prefetch, batched look-back, offsets
+// from a pre-scanned matrix); none was faster -- profiles/r01_radix_ablation.txt.
+// KEYGEN = true: first pass of the suffix sort, keys built from the text inside the pass.
 template <bool GEN_IDX, bool PERSIST, int LBB, bool SPLIT, bool KEYGEN>
 __global__ __launch_bounds__(RDX_NT, RDX_LB_WAVES(PERSIST)) void radix_pass_kernel(
     const u64 *__restrict__ kin, const u32 *__restrict__ vin, u64 *__restrict__ kout,
@@ -393,93 +392,6 @@ __global__ __launch_bounds__(RDX_NT, RDX_LB_WAVES(PERSIST)) void radix_pass_kern
             }
             __syncthreads();
         }
-    }
-}
-
-// SPLIT variant, kernel 1: per-tile digit counts -> matrix[digit][tile] (digit-major so
-// that one exclusive scan over the flat matrix yields every tile's bucket offset).
-__global__ __launch_bounds__(256) void radix_tile_hist_kernel(const u64 *__restrict__ keys, u32 n,
-                                                              int shift, u32 mask, u32 ntiles,
-                                                              u32 *__restrict__ matrix) {
-    __shared__ u32 s_h[4][RDX_BINS];
-    for (int i = threadIdx.x; i < 4 * RDX_BINS; i += 256) (&s_h[0][0])[i] = 0;
-    __syncthreads();
-    const u32 tile = blockIdx.x;
-    const u64 base = (u64)tile * RDX_TILE;
-    u32 *h = s_h[threadIdx.x >> 6];
-#pragma unroll 4
-    for (int k = 0; k < RDX_TILE / 256; k++) {
-        u64 g = base + k * 256 + threadIdx.x;
-        if (g < n) atomicAdd(&h[(u32)((keys[g] >> shift) & mask)], 1u);
-    }
-    __syncthreads();
-    u32 c = s_h[0][threadIdx.x] + s_h[1][threadIdx.x] + s_h[2][threadIdx.x] + s_h[3][threadIdx.x];
-    matrix[(u64)threadIdx.x * ntiles + tile] = c;
-}
-// kernel 2a/2b/2c: exclusive scan of the flat u32 matrix (len = 256 * ntiles)
-__global__ __launch_bounds__(256) void scan32_reduce_kernel(const u32 *__restrict__ in, u64 len,
-                                                            u32 *__restrict__ part) {
-    __shared__ u32 s[4];
-    u64 base = (u64)blockIdx.x * 4096;
-    u32 v = 0;
-    for (int k = 0; k < 16; k++) {
-        u64 i = base + k * 256 + threadIdx.x;
-        if (i < len) v += in[i];
-    }
-    v = wave_sum(v);
-    if ((threadIdx.x & 63) == 0) s[threadIdx.x >> 6] = v;
-    __syncthreads();
-    if (threadIdx.x == 0) part[blockIdx.x] = s[0] + s[1] + s[2] + s[3];
-}
-__global__ __launch_bounds__(1024) void scan32_spine_kernel(u32 *part, u32 nparts) {
-    __shared__ u32 s_p[1024];
-    u32 per = (nparts + 1023) / 1024;
-    u32 lo = threadIdx.x * per, hi = lo + per < nparts ? lo + per : nparts;
-    u32 v = 0;
-    for (u32 t = lo; t < hi; t++) v += part[t];
-    s_p[threadIdx.x] = v;
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        u32 run = 0;
-        for (int i = 0; i < 1024; i++) {
-            u32 c = s_p[i];
-            s_p[i] = run;
-            run += c;
-        }
-    }
-    __syncthreads();
-    u32 run = s_p[threadIdx.x];
-    for (u32 t = lo; t < hi; t++) {
-        u32 c = part[t];
-        part[t] = run;
-        run += c;
-    }
-}
-// matrix (digit-major) -> tile_offs[tile][digit] = exclusive prefix (global position)
-__global__ __launch_bounds__(256) void scan32_down_kernel(const u32 *__restrict__ in, u64 len,
-                                                          const u32 *__restrict__ part,
-                                                          u32 ntiles, u32 *__restrict__ tile_offs) {
-    __shared__ u32 s[4];
-    u64 base = (u64)blockIdx.x * 4096 + (u64)threadIdx.x * 16;
-    u32 v[16], tot = 0;
-    for (int k = 0; k < 16; k++) {
-        u64 i = base + k;
-        v[k] = i < len ? in[i] : 0;
-        tot += v[k];
-    }
-    u32 inc = wave_incl_sum(tot);
-    if ((threadIdx.x & 63) == 63) s[threadIdx.x >> 6] = inc;
-    __syncthreads();
-    u32 pre = part[blockIdx.x];
-    for (int i = 0; i < (int)(threadIdx.x >> 6); i++) pre += s[i];
-    u32 run = pre + inc - tot;
-    for (int k = 0; k < 16; k++) {
-        u64 i = base + k;
-        if (i < len) {
-            u32 digit = (u32)(i / ntiles), tile = (u32)(i % ntiles);
-            tile_offs[(u64)tile * RDX_BINS + digit] = run;
-        }
-        run += v[k];
     }
 }
 

@@ -1,0 +1,39 @@
+{-# LANGUAGE ForeignFunctionInterface #-}
+-- | Raw bindings of libtextcomp.so (include/textcomp.h).  NOT COMPILED IN THIS REPOSITORY'S
+-- PIPELINE: the build image has no GHC; the same C ABI is exercised by the C++ and Python
+-- mirrors and their parity tests.  Every import is `safe`: device calls run for milliseconds.
+module Data.TextCompression.FFI where
+
+import Data.Int (Int16, Int32, Int64)
+import Data.Word (Word16, Word32, Word64, Word8)
+import Foreign.C.String (CString)
+import Foreign.Ptr (Ptr)
+
+data TcCtx
+data TcFm
+
+foreign import ccall safe "tc_ctx_create"  c_tc_ctx_create  :: Int32 -> Ptr (Ptr TcCtx) -> IO Int32
+foreign import ccall safe "tc_ctx_destroy" c_tc_ctx_destroy :: Ptr TcCtx -> IO ()
+foreign import ccall safe "tc_last_error"  c_tc_last_error  :: Ptr TcCtx -> IO CString
+
+-- Data.BWT
+foreign import ccall safe "tc_bwt_encode"
+  c_tc_bwt_encode :: Ptr TcCtx -> Ptr Word8 -> Word64 -> Ptr Word8 -> Ptr Word64 -> IO Int32
+foreign import ccall safe "tc_bwt_decode_sym"
+  c_tc_bwt_decode_sym :: Ptr TcCtx -> Ptr Int16 -> Word64 -> Ptr Word8 -> Ptr Word64 -> IO Int32
+-- Data.MTF
+foreign import ccall safe "tc_mtf_encode_sym"
+  c_tc_mtf_encode_sym :: Ptr TcCtx -> Ptr Int16 -> Word64 -> Ptr Word16 -> Ptr Int16 -> Ptr Word32 -> IO Int32
+foreign import ccall safe "tc_mtf_decode"
+  c_tc_mtf_decode :: Ptr TcCtx -> Ptr Word16 -> Word64 -> Ptr Int16 -> Word32 -> Ptr Int16 -> IO Int32
+-- Data.RLE
+foreign import ccall safe "tc_rle_encode_sym"
+  c_tc_rle_encode_sym :: Ptr TcCtx -> Ptr Int16 -> Word64 -> Ptr Word32 -> Ptr Int16 -> Ptr Word64 -> IO Int32
+foreign import ccall safe "tc_rle_decode"
+  c_tc_rle_decode :: Ptr TcCtx -> Ptr Word32 -> Ptr Int16 -> Word64 -> Ptr Int16 -> Ptr Word64 -> IO Int32
+-- Data.FMIndex
+foreign import ccall safe "tc_fm_build"
+  c_tc_fm_build :: Ptr TcCtx -> Ptr Word8 -> Word64 -> Ptr (Ptr TcFm) -> IO Int32
+foreign import ccall safe "tc_fm_count"
+  c_tc_fm_count :: Ptr TcCtx -> Ptr TcFm -> Ptr Word8 -> Ptr Word64 -> Word64 -> Ptr Int64 -> IO Int32
+foreign import ccall safe "tc_fm_free" c_tc_fm_free :: Ptr TcFm -> IO ()
