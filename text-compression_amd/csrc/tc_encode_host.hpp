@@ -259,7 +259,8 @@ static void sa_run(tc_ctx *ctx, SaBuffers &b, const u8 *d_text, u64 n, u32 *d_sa
         rb.status = b.rstatus;
         ctx->pev_used = 0;
         radix_sort_pairs(ctx, rb, (u32)N, plan, /*gen_idx=*/true, /*hist_ready=*/true, /*timed=*/true,
-                         d_text, fuse ? &kg : nullptr);
+                         d_text, fuse ? &kg : nullptr,
+                         /*xcd_group=*/!ctx->safe_tickets && env_int("TC_XCD_GROUP", 1) != 0);
     };
     const int rbits = ceil_log2_u64(N);
     const int keybits = (int)(cfg.P * cfg.w);

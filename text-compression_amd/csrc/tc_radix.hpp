@@ -25,6 +25,9 @@
 #define RDX_ITEMS 16
 #endif
 #define RDX_TILE (RDX_NT * RDX_ITEMS)
+#ifndef RDX_XCD_RUN
+#define RDX_XCD_RUN 8
+#endif
 #ifndef RDX_MINW
 #define RDX_MINW 3
 #endif
@@ -111,7 +114,7 @@ __global__ __launch_bounds__(RDX_NT, RDX_LB_WAVES(PERSIST)) void radix_pass_kern
 #ifdef TC_RADIX_DIAG
     const int shift_raw = shift;  // timing-only ablation bits ride in the high bits of `shift`
 #else
-    const int shift_raw = shift & 0x100000;
+    const int shift_raw = shift & 0x300000;
 #endif
     shift &= 0xff;
     // staging area for the sorted tile; the per-wave histograms overlay its head (they
@@ -134,19 +137,27 @@ __global__ __launch_bounds__(RDX_NT, RDX_LB_WAVES(PERSIST)) void radix_pass_kern
         for (int i = tid; i < 256; i += RDX_NT) s_klut[i] = kg.lut[i];
     if (SPLIT) {
         if (tid == 0) s_tile = blockIdx.x;
-    } else if (PERSIST || (shift_raw & 0x100000)) {
-        if (tid == 0) s_tile = atomicAdd(ticket, 1u);  // one counter: always safe
-    } else {
-        // tile ids from 8 ticket counters (one word saturates at ~88 tickets/us): shard =
-        // blockIdx % 8, tile = 8 * ticket + shard.  Every shard receives the same number of
-        // blocks, so tile ids stay within one round of each other across shards as long as
-        // blocks start in roughly increasing blockIdx order; if the hardware ever starts
-        // them wildly out of order the bounded look-back spin trips and the host redoes the
-        // sort with the single counter.
+    } else if (shift_raw & 0x200000) {
+        // XCD-aware tile order (guide T1): workgroups are dealt round-robin over the 8 XCDs,
+        // so blocks with equal blockIdx % 8 share an L2.  Each label x draws tickets from its
+        // own counter and takes tiles in runs of 8: ticket a -> tile (a/8)*64 + 8x + a%8.
+        // Consecutive tiles append to the same bucket tails, so the partially written lines
+        // at the seams merge in ONE L2 instead of being evicted half-filled from two (a
+        // read-for-merge plus a partial write each).  A tile may now wait on a tile whose
+        // ticket is drawn up to 56 blocks later; the bounded look-back spin + the host's
+        // retry with the plain single counter cover a dispatch order that breaks this.
         if (tid == 0) {
-            u32 sh = blockIdx.x & 7u;
-            s_tile = atomicAdd(ticket + 32 * sh, 1u) * 8u + sh;
+            const u32 x = blockIdx.x & 7u;
+            const u32 a = atomicAdd(ticket + 32 * x, 1u);
+            const u32 RL = RDX_XCD_RUN;                  // tiles per run
+            const u32 T = (u32)(((u64)n + RDX_TILE - 1) / RDX_TILE), Gf = T / (8 * RL);
+            u32 t;
+            if (a < Gf * RL) t = (a / RL) * (8 * RL) + x * RL + (a % RL);
+            else t = Gf * (8 * RL) + (a - Gf * RL) * 8 + x;   // tail (< 8*RL tiles): interleaved
+            s_tile = t;
         }
+    } else {
+        if (tid == 0) s_tile = atomicAdd(ticket, 1u);  // one counter: always safe
     }
     __syncthreads();
     const u32 first = s_tile, G = PERSIST ? gridDim.x : 0x7fffffffu;
@@ -415,4 +426,4 @@ static inline size_t radix_status_words(u64 n) {
 
 void radix_sort_pairs(tc_ctx *ctx, RadixBuffers &b, u32 n, const RadixPlan &plan, bool gen_idx,
                       bool hist_ready, bool timed = false, const u8 *text = nullptr,
-                      const RadixKeyGen *keygen = nullptr);
+                      const RadixKeyGen *keygen = nullptr, bool xcd_group = false);

@@ -9,12 +9,12 @@
 template <bool GEN>
 static void radix_launch_pass(tc_ctx *ctx, RadixBuffers &b, u32 n, int shift, u32 mask,
                               const u32 *bucket_base, u32 tiles, u32 *ticket,
-                              const u8 *text, const RadixKeyGen *kg) {
+                              const u8 *text, const RadixKeyGen *kg, bool xcd_group) {
     hipStream_t s = ctx->stream;
 #ifdef TC_RADIX_DIAG
     if (const char *dg = getenv("TC_DIAG")) shift |= (atoi(dg) & 0xfff) << 8;  // timing-only ablations
 #endif
-    shift |= 0x100000;  // single ticket counter
+    shift |= xcd_group ? 0x200000 : 0x100000;  // XCD-grouped tile order, or the single safe counter
     if (kg) {
         radix_pass_kernel<true, false, 1, false, true><<<tiles, RDX_NT, 0, s>>>(
             b.keys, b.vals, b.keys_alt, b.vals_alt, n, shift, mask, bucket_base, b.status, ticket,
@@ -30,7 +30,8 @@ static void radix_launch_pass(tc_ctx *ctx, RadixBuffers &b, u32 n, int shift, u3
 
 // keygen != null: the FIRST pass builds its keys from `text` (b.keys is not read).
 void radix_sort_pairs(tc_ctx *ctx, RadixBuffers &b, u32 n, const RadixPlan &plan, bool gen_idx,
-                      bool hist_ready, bool timed, const u8 *text, const RadixKeyGen *keygen) {
+                      bool hist_ready, bool timed, const u8 *text, const RadixKeyGen *keygen,
+                      bool xcd_group) {
     if (n == 0 || plan.npass == 0) return;
     RadixPlanDev pd;
     pd.npass = plan.npass;
@@ -57,13 +58,13 @@ void radix_sort_pairs(tc_ctx *ctx, RadixBuffers &b, u32 n, const RadixPlan &plan
         if (ev) TC_HIP(ctx, hipEventRecord(ctx->pev[2 * ctx->pev_used], s));
         if (p == 0 && keygen)
             radix_launch_pass<true>(ctx, b, n, plan.shift[p], plan.mask[p], b.hist + p * RDX_BINS, tiles,
-                                    ticket, text, keygen);
+                                    ticket, text, keygen, xcd_group);
         else if (gen_idx && p == 0)
             radix_launch_pass<true>(ctx, b, n, plan.shift[p], plan.mask[p], b.hist + p * RDX_BINS, tiles,
-                                    ticket, nullptr, nullptr);
+                                    ticket, nullptr, nullptr, xcd_group);
         else
             radix_launch_pass<false>(ctx, b, n, plan.shift[p], plan.mask[p], b.hist + p * RDX_BINS, tiles,
-                                     ticket, nullptr, nullptr);
+                                     ticket, nullptr, nullptr, xcd_group);
         if (ev) {
             TC_HIP(ctx, hipEventRecord(ctx->pev[2 * ctx->pev_used + 1], s));
             ctx->pev_used++;
