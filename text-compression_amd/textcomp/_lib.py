@@ -86,6 +86,32 @@ SYMBOLS = [
 _LIB = None
 
 
+def _prefer_process_hip_runtime():
+    """One process, one HIP runtime.  PyTorch-ROCm wheels bundle their own libamdhip64.so.7;
+    libtextcomp.so names the same SONAME.  Whichever copy is loaded first serves both, and
+    torch does not come up on the system copy ("No HIP GPUs are available").  So, when a
+    torch installation is present and its runtime is not in the process yet, load torch's
+    copy first (without importing torch); TEXTCOMP_SYSTEM_HIP=1 keeps /opt/rocm's."""
+    if os.environ.get("TEXTCOMP_SYSTEM_HIP") == "1":
+        return
+    import importlib.util
+    import sys
+    if "torch" in sys.modules:
+        return  # torch already brought its runtime in
+    try:
+        spec = importlib.util.find_spec("torch")
+    except (ImportError, ValueError):
+        spec = None
+    if spec is None or not spec.origin:
+        return
+    cand = os.path.join(os.path.dirname(spec.origin), "lib", "libamdhip64.so")
+    if os.path.exists(cand):
+        try:
+            C.CDLL(cand, mode=C.RTLD_GLOBAL)
+        except OSError:
+            pass
+
+
 def load():
     """dlopen libtextcomp.so and type every entry point; raises if it is missing."""
     global _LIB
@@ -94,6 +120,7 @@ def load():
             raise ImportError(
                 "libtextcomp.so not built (%s): run __graft_entry__.build() or `make -C "
                 "text-compression_amd`; there is no CPU fallback" % LIB_PATH)
+        _prefer_process_hip_runtime()
         lib = C.CDLL(LIB_PATH)
         for name, res, args in SYMBOLS:
             fn = getattr(lib, name)  # AttributeError if the .so lacks a declared symbol
