@@ -29,7 +29,7 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--n", type=int, default=GIB, help="record size in bytes (default 1 GiB = BASELINE configs[2])")
+    ap.add_argument("--n", "--record-bytes", dest="n", type=int, default=GIB, help="record size in bytes (default 1 GiB = BASELINE configs[2])")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample", type=int, default=64 << 20, help="bytes of the workload timed on the CPU port")
     return ap.parse_args()
@@ -88,10 +88,19 @@ def main():
     if world != a.gpus:
         if world == 1 and a.gpus > 1:
             sys.exit("bench.py --gpus %d must be launched with torch.distributed.run (one rank per GPU)" % a.gpus)
+    # TC_BENCH_REHEARSAL=1: every rank computes on cuda:0 and the exchange runs over gloo with
+    # host staging -- a one-GPU rehearsal of the N > 1 control flow (never a measurement)
+    rehearsal = os.environ.get("TC_BENCH_REHEARSAL") == "1"
+    if rehearsal:
+        local = 0
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     if world > 1:
-        dist.init_process_group("nccl", device_id=dev)
+        if rehearsal:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=dev)
+    xdev = torch.device("cpu") if rehearsal else dev   # where the exchanged payload lives
 
     n = a.n
     cap = n + 2
@@ -113,7 +122,7 @@ def main():
     if world > 1:
         from textcomp.gather import BlockGather
         pcap = n + n // 4 + 4096          # packed bytes per record (iid ACGTN: ~0.8 n), with slack
-        gatherer = BlockGather(pcap, dev, depth=2)
+        gatherer = BlockGather(pcap, xdev, depth=2)
         packed = [torch.empty(pcap, dtype=torch.uint8, device=dev) for _ in range(2)]
     blk = Block()
     step_no = [0]
@@ -128,13 +137,12 @@ def main():
         if gatherer is not None:
             buf = packed[step_no[0] % 2]
             step_no[0] += 1
-            if lib.tc_block_packed_bound(int(blk.nruns), int(blk.sigma)) > pcap and int(blk.nruns) > pcap // 9:
-                raise RuntimeError("packed block may exceed the gather buffer")
-            nb, ne = C.c_uint64(), C.c_uint64()
+            nb, ne = C.c_uint64(pcap), C.c_uint64()
             rc = lib.tc_block_pack_dev(ctx.handle, C.byref(blk), C.c_void_p(buf.data_ptr()), C.byref(nb), C.byref(ne))
             if rc != 0:
                 raise RuntimeError("tc_block_pack_dev rc=%d: %s" % (rc, lib.tc_last_error(ctx.handle).decode()))
-            gatherer.submit([nb.value, int(blk.nruns), ne.value, int(blk.primary), int(blk.sigma), n], buf)
+            payload = buf[:nb.value].cpu() if rehearsal else buf
+            gatherer.submit([nb.value, int(blk.nruns), ne.value, int(blk.primary), int(blk.sigma), n], payload)
 
     def fence():
         if gatherer is not None:
@@ -152,10 +160,14 @@ def main():
     fence()
     dt = time.perf_counter() - t0
     if world > 1:
-        tt = torch.tensor([dt], dtype=torch.float64, device=dev)
+        tt = torch.tensor([dt], dtype=torch.float64, device=xdev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
 
+    if rank == 0 and rehearsal and gatherer is not None:
+        last = gatherer.completed[-1]
+        assert len(last) == world and all(int(h[0]) == len(p) for h, p in last), "gather shape"
+        print("rehearsal: gathered", [(int(h[0]), int(h[1])) for h, _ in last], file=sys.stderr)
     if rank == 0:
         st = ctx.stats()
         total_bytes = n * world * a.steps

@@ -170,8 +170,10 @@ int tc_decode_dev(tc_ctx *ctx, const tc_block *blk, uint8_t *d_text);
  *   (sigma > 16: two bytes per run: value low byte | count-escape byte)
  * count >= 15 ("escape") additionally appends the pair (run index, count) as two
  * uint32 words to the escape list that follows the bytes at the next 8-byte boundary.
- * `packed` needs tc_block_packed_bound(nruns, sigma) bytes; *packed_bytes returns the
- * bytes used and *nesc the number of escapes.  All pointers are DEVICE pointers. */
+ * *packed_bytes: in = capacity of `packed`, out = bytes used (TC_ERR_CAPACITY: bytes needed);
+ * tc_block_packed_bound(nruns, sigma) is always enough (every run escaping), nruns * bytes-per-
+ * run + 8 is enough when no count reaches the escape value.  *nesc returns the number of
+ * escapes.  All pointers are DEVICE pointers. */
 uint64_t tc_block_packed_bound(uint64_t nruns, uint32_t sigma);
 int tc_block_pack_dev(tc_ctx *ctx, const tc_block *blk, uint8_t *d_packed, uint64_t *packed_bytes,
                       uint64_t *nesc);

@@ -199,9 +199,11 @@ def test_block_pack_unpack_roundtrip(ctx):
         blk.run_count = d_c.data_ptr(); blk.run_value = d_v.data_ptr()
         bound = lib.tc_block_packed_bound(k, sigma)
         buf = torch.zeros(bound, dtype=torch.uint8, device="cuda")
-        nb, ne = C.c_uint64(), C.c_uint64()
+        nb, ne = C.c_uint64(bound), C.c_uint64()
         assert lib.tc_block_pack_dev(ctx.handle, C.byref(blk), C.c_void_p(buf.data_ptr()), C.byref(nb), C.byref(ne)) == 0
         assert nb.value <= bound
+        small = C.c_uint64(k // 2)
+        assert lib.tc_block_pack_dev(ctx.handle, C.byref(blk), C.c_void_p(buf.data_ptr()), C.byref(small), C.byref(C.c_uint64())) == -2
         esc_thr = 15 if sigma <= 16 else 127
         assert ne.value == int((counts >= esc_thr).sum())
         o_c = torch.zeros(k, dtype=torch.int32, device="cuda"); o_v = torch.zeros(k, dtype=torch.int16, device="cuda")

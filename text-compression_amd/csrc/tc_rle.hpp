@@ -68,13 +68,18 @@ __global__ __launch_bounds__(RLE_NT, 4) void rle_encode_kernel(Acc acc, RleArgs 
     __shared__ u32 s_tile;
     __shared__ __attribute__((aligned(16))) i16 s_x[RLE_TILE];
     const int tid = threadIdx.x, w = tid >> 6, l = tid & 63;
-    if (tid == 0) s_tile = atomicAdd(a.ticket, 1u);
-    __syncthreads();
     const u64 N = a.N;
     const u32 ntiles = (u32)((N + RLE_TILE - 1) / RLE_TILE);
     SymT *syms = reinterpret_cast<SymT *>(a.syms);
-    // persistent: one ticket per block, tiles strided by the (co-resident) grid
-    for (u32 tile = s_tile; tile < ntiles; tile += gridDim.x) {
+    // persistent blocks, but every tile is drawn from the ticket counter when a block is
+    // ready for it: a tile only ever waits on tiles already claimed by running blocks, so
+    // no co-residency of the whole grid is assumed (other kernels may share the device)
+    for (;;) {
+    __syncthreads();
+    if (tid == 0) s_tile = atomicAdd(a.ticket, 1u);
+    __syncthreads();
+    const u32 tile = s_tile;
+    if (tile >= ntiles) break;
     const u64 base = (u64)tile * RLE_TILE + (u64)w * 64 * RLE_ITEMS;
 
     stage_syms<RLE_TILE, RLE_NT>(acc, (u64)tile * RLE_TILE, N, s_x);
@@ -183,12 +188,18 @@ __global__ __launch_bounds__(RLE_NT, 4) void rle_encode_u16_kernel(U16Acc acc, R
     __shared__ u32 s_tile;
     __shared__ __attribute__((aligned(16))) i16 s_x[RLE16_TILE];
     const int tid = threadIdx.x, w = tid >> 6, l = tid & 63;
-    if (tid == 0) s_tile = atomicAdd(a.ticket, 1u);
-    __syncthreads();
     const u64 N = a.N;
     const u32 ntiles = (u32)((N + RLE16_TILE - 1) / RLE16_TILE);
     u16 *vals = reinterpret_cast<u16 *>(a.syms);
-    for (u32 tile = s_tile; tile < ntiles; tile += gridDim.x) {
+    // persistent blocks, but every tile is drawn from the ticket counter when a block is
+    // ready for it: a tile only ever waits on tiles already claimed by running blocks, so
+    // no co-residency of the whole grid is assumed (other kernels may share the device)
+    for (;;) {
+    __syncthreads();
+    if (tid == 0) s_tile = atomicAdd(a.ticket, 1u);
+    __syncthreads();
+    const u32 tile = s_tile;
+    if (tile >= ntiles) break;
         const u64 base = (u64)tile * RLE16_TILE + (u64)w * 64 * RLE16_ITEMS;
         stage_syms<RLE16_TILE, RLE_NT>(acc, (u64)tile * RLE16_TILE, N, s_x);
         u32 x[RLE16_ITEMS];

@@ -291,13 +291,18 @@ __global__ __launch_bounds__(GRP_NT, 4) void group_kernel(GroupArgs a) {
     __shared__ u64 s_pref[2];
     __shared__ u32 s_tile;
     const int tid = threadIdx.x, w = tid >> 6, l = tid & 63;
-    if (tid == 0) s_tile = atomicAdd(a.ticket, 1u);
-    __syncthreads();
     const u64 KMASK = INIT ? ~0xffull : ~0ull;
     const u64 count = a.count;
     const u32 ntiles = (u32)((count + GRP_TILE - 1) / GRP_TILE);
-    // persistent: one ticket per block, tiles strided by the (co-resident) grid
-    for (u32 tile = s_tile; tile < ntiles; tile += gridDim.x) {
+    // persistent blocks, but every tile is drawn from the ticket counter when a block is
+    // ready for it: a tile only ever waits on tiles already claimed by running blocks, so
+    // no co-residency of the whole grid is assumed (other kernels may share the device)
+    for (;;) {
+    __syncthreads();
+    if (tid == 0) s_tile = atomicAdd(a.ticket, 1u);
+    __syncthreads();
+    const u32 tile = s_tile;
+    if (tile >= ntiles) break;
     const u64 base = (u64)tile * GRP_TILE + (u64)w * 64 * GRP_ITEMS;
 
     // ---- phase 1: head ballots, packed low bytes, wave aggregates -----------------

@@ -672,23 +672,31 @@ int tc_block_pack_dev(tc_ctx *ctx, const tc_block *blk, uint8_t *d_packed, uint6
     TC_API_BEGIN(ctx)
     if (!blk || !packed_bytes || !nesc) TC_FAIL(ctx, TC_ERR_ARG, "bad argument");
     const u64 nruns = blk->nruns;
+    const u64 cap = *packed_bytes;
     *packed_bytes = 0; *nesc = 0;
     if (nruns == 0) return TC_OK;
     if (!d_packed || !blk->run_count || !blk->run_value) TC_FAIL(ctx, TC_ERR_ARG, "null buffer");
     const int bpr = pack_bpr(blk->sigma);
     const u64 body = ((u64)bpr * nruns + 7) & ~7ull;
+    if (body > cap) {
+        *packed_bytes = body;
+        TC_FAIL(ctx, TC_ERR_CAPACITY, "packed runs need at least %llu bytes", (unsigned long long)body);
+    }
+    const u64 esc_cap = (cap - body) / 8;
     u32 *esc = reinterpret_cast<u32 *>(d_packed + body);
     u32 *d_nesc = reinterpret_cast<u32 *>(ctx->d_scalars + 14);
     tc_memset_async(ctx, d_nesc, 0, sizeof(u64));
     u32 grid = tc_cdiv(nruns, 256 * 8);
     if (grid > 8192) grid = 8192;
     pack_runs_kernel<<<grid, 256, 0, ctx->stream>>>(blk->run_count, blk->run_value, nruns, bpr, d_packed,
-                                                   esc, d_nesc, nruns);
+                                                   esc, d_nesc, esc_cap);
     TC_LAUNCH_CHECK(ctx);
     tc_d2h(ctx, &ctx->h_scalars[14], ctx->d_scalars + 14, sizeof(u64));
     TC_HIP(ctx, hipStreamSynchronize(ctx->stream));
     *nesc = (u32)ctx->h_scalars[14];
     *packed_bytes = body + 8 * *nesc;
+    if (*nesc > esc_cap)
+        TC_FAIL(ctx, TC_ERR_CAPACITY, "packed runs need %llu bytes", (unsigned long long)*packed_bytes);
     TC_API_END(ctx)
 }
 
