@@ -47,6 +47,11 @@ class BlockGather:
         works, result = entry
         for w in works:
             w.wait()
+        if works and self.device.type == "cuda":
+            # for RCCL, wait() only orders torch's current stream behind the transfer; the
+            # encoder runs on its own HIP stream, so complete the transfer on the host before
+            # the caller may overwrite the payload buffer
+            torch.cuda.current_stream(self.device).synchronize()
         self._inflight[slot] = None
         if result is not None:
             self.completed.append(result)
