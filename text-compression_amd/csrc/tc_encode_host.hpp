@@ -545,6 +545,7 @@ static void rle_encode_device(tc_ctx *ctx, Arena &A, Acc acc, u64 N, u32 *d_coun
     a.status_pair = status; a.status_sum = status + tiles;
     a.ticket = reinterpret_cast<u32 *>(status + 2 * (size_t)tiles);
     a.scalars = ctx->d_scalars; a.err = ctx->d_err;
+    a.diag = env_int("TC_RLE_DIAG", 0);
     if constexpr (std::is_same<Acc, U16Acc>::value) {
         u32 grid = tc_persistent_grid_for(ctx, rle_encode_u16_kernel, RLE_NT, 2);
         if (grid > tiles) grid = tiles;

@@ -183,8 +183,13 @@ __global__ __launch_bounds__(RDX_NT, RDX_LB_WAVES(PERSIST)) void radix_pass_kern
             }
 #endif
             if (o < lim) {
+#ifdef RDX_NT_LOADS
+                kk[k] = __builtin_nontemporal_load(kt + o);   // read-once stream: keep L2 for the scatter
+                vv[k] = GEN_IDX ? (u32)base + o : __builtin_nontemporal_load(vt + o);
+#else
                 kk[k] = kt[o];
                 vv[k] = GEN_IDX ? (u32)base + o : vt[o];
+#endif
             } else {
                 kk[k] = ~0ull;
                 vv[k] = 0;

@@ -33,6 +33,7 @@ struct RleArgs {
     u32 *ticket;
     u64 *scalars;  // [2] total pairs
     u32 *err;
+    int diag;      // timing-only ablation bits (TC_RLE_DIAG): 1 no stores, 2 no look-back
 };
 
 // Flag ballots of one 64-position item: heads of Just runs, Just positions, own and
@@ -179,67 +180,75 @@ __global__ __launch_bounds__(RLE_NT, 4) void rle_encode_kernel(Acc acc, RleArgs 
 }
 
 // Same pass for a stream that cannot contain Nothing (the MTF index stream): only run
-// heads and run tails exist, so two ballots per item, kept as wave-uniform masks between
-// the aggregate phase and the emit phase.
+// heads and run tails exist.  One tile = RLE16_SUB sub-tiles of 4096 values staged in LDS
+// (neighbours are read from the LDS image, no shuffles); the two look-backs -- the waits on
+// predecessor tiles measured at ~40 % of the 4096-value version -- are paid once per 16384
+// values.
+#define RLE16_SUB 4
+#define RLE16_SUBTILE (RLE_NT * 8)
+#undef RLE16_TILE
+#define RLE16_TILE (RLE16_SUB * RLE16_SUBTILE)
+
 __global__ __launch_bounds__(RLE_NT, 4) void rle_encode_u16_kernel(U16Acc acc, RleArgs a) {
-    constexpr int NW = RLE_NT / 64;
-    __shared__ u32 s_wh[NW], s_ws[NW];
+    constexpr int NW = RLE_NT / 64, NSEG = RLE16_SUB * NW;
+    __shared__ u32 s_wh[NSEG], s_ws[NSEG];
     __shared__ u64 s_pref[2];
-    __shared__ u32 s_tile;
+    __shared__ u32 s_tile, s_edge[2];
     __shared__ __attribute__((aligned(16))) i16 s_x[RLE16_TILE];
     const int tid = threadIdx.x, w = tid >> 6, l = tid & 63;
     const u64 N = a.N;
     const u32 ntiles = (u32)((N + RLE16_TILE - 1) / RLE16_TILE);
     u16 *vals = reinterpret_cast<u16 *>(a.syms);
-    // persistent blocks, but every tile is drawn from the ticket counter when a block is
-    // ready for it: a tile only ever waits on tiles already claimed by running blocks, so
-    // no co-residency of the whole grid is assumed (other kernels may share the device)
     for (;;) {
-    __syncthreads();
-    if (tid == 0) s_tile = atomicAdd(a.ticket, 1u);
-    __syncthreads();
-    const u32 tile = s_tile;
-    if (tile >= ntiles) break;
-        const u64 base = (u64)tile * RLE16_TILE + (u64)w * 64 * RLE16_ITEMS;
-        stage_syms<RLE16_TILE, RLE_NT>(acc, (u64)tile * RLE16_TILE, N, s_x);
-        u32 x[RLE16_ITEMS];
-#pragma unroll
-        for (int k = 0; k < RLE16_ITEMS; k++) x[k] = (u32)(u16)s_x[w * 64 * RLE16_ITEMS + k * 64 + l];
-        u32 xprev0 = 0x10000u, xnextT = 0x10000u;  // impossible values: force head / tail
-        if (base > 0 && base <= N) xprev0 = (u32)acc(base - 1);
-        if (base + (u64)64 * RLE16_ITEMS < N) xnextT = (u32)acc(base + (u64)64 * RLE16_ITEMS);
-        u64 hb[RLE16_ITEMS], pb[RLE16_ITEMS];
-        u32 wh = 0, ws = 0;
-#pragma unroll
-        for (int k = 0; k < RLE16_ITEMS; k++) {
-            const u64 jb0 = base + (u64)k * 64;
-            const u64 j = jb0 + l;
-            const bool in = j < N;
-            u32 up = (u32)__shfl_up((int)x[k], 1, 64), dn = (u32)__shfl_down((int)x[k], 1, 64);
-            u32 p0 = (k == 0) ? xprev0 : (u32)__shfl((int)x[(k + RLE16_ITEMS - 1) % RLE16_ITEMS], 63, 64);
-            u32 n0 = (k == RLE16_ITEMS - 1) ? xnextT : (u32)__shfl((int)x[(k + 1) % RLE16_ITEMS], 0, 64);
-            u32 xp = (l == 0) ? p0 : up, xn = (l == 63) ? n0 : dn;
-            hb[k] = __ballot(in && (j == 0 || xp != x[k]));
-            pb[k] = __ballot(in && (j == N - 1 || xn != x[k]));
-            if (hb[k]) wh = (u32)(jb0 + 63u - (u32)__builtin_clzll(hb[k])) + 1u;
-            ws += (u32)__popcll(pb[k]);
+        __syncthreads();
+        if (tid == 0) s_tile = atomicAdd(a.ticket, 1u);
+        __syncthreads();
+        const u32 tile = s_tile;
+        if (tile >= ntiles) break;
+        const u64 tbase = (u64)tile * RLE16_TILE;
+        if (tid == 0) {  // values just outside the tile; 0x10000 = impossible value (forces head / tail)
+            s_edge[0] = tbase > 0 ? (u32)acc(tbase - 1) : 0x10000u;
+            s_edge[1] = tbase + RLE16_TILE < N ? (u32)acc(tbase + RLE16_TILE) : 0x10000u;
         }
-        if (l == 0) {
-            s_wh[w] = wh;
-            s_ws[w] = ws;
+        stage_syms<RLE16_TILE, RLE_NT>(acc, tbase, N, s_x);  // ends with a barrier
+        auto item = [&](int sub, int k, u64 &hbk, u64 &pbk, u32 &xv) {
+            const u32 p = (u32)sub * RLE16_SUBTILE + (u32)w * 512 + (u32)k * 64 + (u32)l;
+            const u64 j = tbase + p;
+            const bool in = j < N;
+            xv = (u32)(u16)s_x[p];
+            const u32 xp = p > 0 ? (u32)(u16)s_x[p - 1] : s_edge[0];
+            const u32 xn = p + 1 < RLE16_TILE ? (u32)(u16)s_x[p + 1] : s_edge[1];
+            hbk = __ballot(in && (j == 0 || xp != xv));
+            pbk = __ballot(in && (j == N - 1 || xn != xv));
+        };
+        // ---- phase 1: aggregates per (sub-tile, wave) segment of 512 values
+#pragma unroll
+        for (int sub = 0; sub < RLE16_SUB; sub++) {
+            u32 wh = 0, ws = 0;
+#pragma unroll
+            for (int k = 0; k < 8; k++) {
+                u64 hbk, pbk;
+                u32 xv;
+                item(sub, k, hbk, pbk, xv);
+                const u64 jb0 = tbase + (u64)sub * RLE16_SUBTILE + (u64)w * 512 + (u64)k * 64;
+                if (hbk) wh = (u32)(jb0 + 63u - (u32)__builtin_clzll(hbk)) + 1u;
+                ws += (u32)__popcll(pbk);
+            }
+            if (l == 0) {
+                s_wh[sub * NW + w] = wh;
+                s_ws[sub * NW + w] = ws;
+            }
         }
         __syncthreads();
-        u32 ph = 0, ps = 0, bh = 0, bs = 0;
+        u32 bh = 0, bs = 0;
 #pragma unroll
-        for (int i = 0; i < NW; i++) {
-            if (i < w) {
-                ph = ph > s_wh[i] ? ph : s_wh[i];
-                ps += s_ws[i];
-            }
+        for (int i = 0; i < NSEG; i++) {
             bh = bh > s_wh[i] ? bh : s_wh[i];
             bs += s_ws[i];
         }
-        if (w == 0) {
+        if (a.diag & 2) {
+            if (tid == 0) { s_pref[0] = 0; s_pref[1] = (u64)tile * 12000; a.scalars[2] = 1; }
+        } else if (w == 0) {
             u64 e = lb_exclusive<OpMax>(a.status_pair, tile, bh, a.err);
             if (l == 0) s_pref[0] = e;
         } else if (w == 1) {
@@ -250,25 +259,36 @@ __global__ __launch_bounds__(RLE_NT, 4) void rle_encode_u16_kernel(U16Acc acc, R
             }
         }
         __syncthreads();
-        u32 curH = ph > (u32)s_pref[0] ? ph : (u32)s_pref[0];
-        u64 curE = s_pref[1] + ps;
+        // ---- phase 2: emit, segment by segment in position order
 #pragma unroll
-        for (int k = 0; k < RLE16_ITEMS; k++) {
-            const u64 jb0 = base + (u64)k * 64;
-            if (jb0 >= N) break;
-            if ((pb[k] >> l) & 1ull) {
-                const u64 hm = hb[k] & ((2ull << l) - 1ull);
-                const u32 H = hm ? (u32)(jb0 + 63u - (u32)__builtin_clzll(hm)) + 1u : curH;
-                const u64 e = curE + (u64)__popcll(pb[k] & lanemask_lt());
-                if (e < a.cap) {
-                    a.counts[e] = (u32)(jb0 + l + 2 - H);
-                    vals[e] = (u16)x[k];
-                }
+        for (int sub = 0; sub < RLE16_SUB; sub++) {
+            u32 curH = (u32)s_pref[0];
+            u64 curE = s_pref[1];
+            const int seg = sub * NW + w;
+            for (int i = 0; i < seg; i++) {
+                curH = curH > s_wh[i] ? curH : s_wh[i];
+                curE += s_ws[i];
             }
-            if (hb[k]) curH = (u32)(jb0 + 63u - (u32)__builtin_clzll(hb[k])) + 1u;
-            curE += (u64)__popcll(pb[k]);
+#pragma unroll
+            for (int k = 0; k < 8; k++) {
+                const u64 jb0 = tbase + (u64)sub * RLE16_SUBTILE + (u64)w * 512 + (u64)k * 64;
+                if (jb0 >= N) break;
+                u64 hbk, pbk;
+                u32 xv;
+                item(sub, k, hbk, pbk, xv);
+                if ((pbk >> l) & 1ull) {
+                    const u64 hm = hbk & ((2ull << l) - 1ull);
+                    const u32 H = hm ? (u32)(jb0 + 63u - (u32)__builtin_clzll(hm)) + 1u : curH;
+                    const u64 e = curE + (u64)__popcll(pbk & lanemask_lt());
+                    if (e < a.cap && !(a.diag & 1)) {
+                        a.counts[e] = (u32)(jb0 + l + 2 - H);
+                        vals[e] = (u16)xv;
+                    }
+                }
+                if (hbk) curH = (u32)(jb0 + 63u - (u32)__builtin_clzll(hbk)) + 1u;
+                curE += (u64)__popcll(pbk);
+            }
         }
-        __syncthreads();
     }
 }
 
