@@ -154,12 +154,50 @@ __device__ __forceinline__ NibSumm nib_shfl_up(NibSumm v, int d) {
 // Stage one tile of codes into LDS (chunk-major, padded) and return this lane's
 // chunk summary (from the identity list).  0xFF marks padding past N.
 template <class Acc>
-__device__ __forceinline__ void nib_stage(Acc acc, u64 N, u64 base, const u8 *s_lut, u8 *s_code,
-                                          i16 *s_sym) {
-    stage_syms<MTF_TILE, MTF_NT>(acc, base, N, s_sym);
+__device__ __forceinline__ void nib_stage(Acc acc, u64 N, u64 base, const u8 *s_lut, u8 *s_code) {
     for (u32 p = threadIdx.x; p < MTF_TILE; p += MTF_NT) {
-        int v = s_sym[p];
-        s_code[(p / MTF_CH) * MTF_STRIDE + (p % MTF_CH)] = v == -2 ? (u8)0xFF : s_lut[v + 1];
+        u64 j = base + p;
+        u8 c = 0xFF;
+        if (j < N) c = s_lut[acc(j) + 1];
+        s_code[(p / MTF_CH) * MTF_STRIDE + (p % MTF_CH)] = c;
+    }
+}
+// (L, primary): 16 bytes per lane per load, codes written as 4 dwords into the padded image
+template <>
+__device__ __forceinline__ void nib_stage<BwtAcc>(BwtAcc acc, u64 N, u64 base, const u8 *s_lut, u8 *s_code) {
+    const u8 *src = acc.L + base;
+    if ((((uintptr_t)src) & 15) == 0) {
+        for (u32 c = threadIdx.x; c < MTF_TILE / 16; c += MTF_NT) {
+            const u32 p0 = c * 16;
+            const u64 j0 = base + p0;
+            u32 out[4] = {0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu};
+            if (j0 + 16 <= N) {
+                uint4 v = *reinterpret_cast<const uint4 *>(src + p0);
+                u32 x[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+                for (int q = 0; q < 4; q++)
+                    out[q] = (u32)s_lut[(x[q] & 255) + 1] | ((u32)s_lut[((x[q] >> 8) & 255) + 1] << 8) |
+                             ((u32)s_lut[((x[q] >> 16) & 255) + 1] << 16) | ((u32)s_lut[(x[q] >> 24) + 1] << 24);
+            } else {
+                for (int q = 0; q < 16; q++)
+                    if (j0 + q < N) out[q >> 2] = (out[q >> 2] & ~(0xFFu << (8 * (q & 3)))) | ((u32)s_lut[(u32)src[p0 + q] + 1] << (8 * (q & 3)));
+            }
+            u32 *dst = reinterpret_cast<u32 *>(s_code + (p0 / MTF_CH) * MTF_STRIDE + (p0 % MTF_CH));
+            dst[0] = out[0]; dst[1] = out[1]; dst[2] = out[2]; dst[3] = out[3];
+        }
+    } else {
+        for (u32 p = threadIdx.x; p < MTF_TILE; p += MTF_NT) {
+            u64 j = base + p;
+            s_code[(p / MTF_CH) * MTF_STRIDE + (p % MTF_CH)] = j < N ? s_lut[(u32)src[p] + 1] : (u8)0xFF;
+        }
+    }
+    // the sentinel slot carries byte 0 in L: patch its code
+    if (acc.primary >= (i64)base && acc.primary < (i64)(base + MTF_TILE)) {
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            u32 p = (u32)(acc.primary - (i64)base);
+            s_code[(p / MTF_CH) * MTF_STRIDE + (p % MTF_CH)] = s_lut[0];
+        }
     }
 }
 
@@ -262,13 +300,12 @@ __global__ __launch_bounds__(MTF_NT) void mtf_nib_summary_kernel(Acc acc, u64 N,
                                                                   Lut8 lut,
                                                                   u64 *__restrict__ t_perm,
                                                                   u32 *__restrict__ t_mask) {
-    __shared__ u8 s_code[MTF_NT * MTF_STRIDE];
-    __shared__ __attribute__((aligned(16))) i16 s_sym[MTF_TILE];
+    __shared__ __attribute__((aligned(16))) u8 s_code[MTF_NT * MTF_STRIDE];
     __shared__ u8 s_lut[260];
     __shared__ NibSumm s_w[MTF_NT / 64];
     for (int i = threadIdx.x; i < 257; i += MTF_NT) s_lut[i] = lut.v[i];
     __syncthreads();
-    nib_stage(acc, N, (u64)blockIdx.x * MTF_TILE, s_lut, s_code, s_sym);
+    nib_stage(acc, N, (u64)blockIdx.x * MTF_TILE, s_lut, s_code);
     __syncthreads();
     NibSumm mine = nib_chunk_summary(s_code);
     NibSumm agg;
@@ -309,14 +346,13 @@ __global__ __launch_bounds__(MTF_NT) void mtf_nib_apply_kernel(Acc acc, u64 N,
                                                                 const u64 *__restrict__ t_perm,
                                                                 u16 *__restrict__ idx, u32 sigma,
                                                                 u32 *flag) {
-    __shared__ u8 s_code[MTF_NT * MTF_STRIDE];
-    __shared__ __attribute__((aligned(16))) i16 s_sym[MTF_TILE];
+    __shared__ __attribute__((aligned(16))) u8 s_code[MTF_NT * MTF_STRIDE];
     __shared__ u8 s_lut[260];
     __shared__ NibSumm s_w[MTF_NT / 64];
     for (int i = threadIdx.x; i < 257; i += MTF_NT) s_lut[i] = lut.v[i];
     __syncthreads();
     const u64 base = (u64)blockIdx.x * MTF_TILE;
-    nib_stage(acc, N, base, s_lut, s_code, s_sym);
+    nib_stage(acc, N, base, s_lut, s_code);
     __syncthreads();
     NibSumm mine = nib_chunk_summary(s_code);
     NibSumm agg;
@@ -354,18 +390,17 @@ __global__ __launch_bounds__(MTF_NT) void mtf_nib_apply_kernel(Acc acc, u64 N,
         cw[q] = ov;  // indices overwrite the codes in place
     }
     __syncthreads();
-    for (u32 p = threadIdx.x; p < MTF_TILE; p += MTF_NT)
-        s_sym[p] = (i16)s_code[(p / MTF_CH) * MTF_STRIDE + (p % MTF_CH)];
-    __syncthreads();
-    if ((((uintptr_t)(idx + base)) & 15) == 0) {
-        for (u32 c = threadIdx.x; c < MTF_TILE / 8; c += MTF_NT) {
-            u64 j = base + (u64)c * 8;
-            if (j + 8 <= N) *reinterpret_cast<uint4 *>(idx + j) = *reinterpret_cast<const uint4 *>(s_sym + c * 8);
-            else for (int q = 0; q < 8; q++) if (j + q < N) idx[j + q] = (u16)s_sym[c * 8 + q];
+    if ((((uintptr_t)(idx + base)) & 3) == 0) {
+        u32 *o32 = reinterpret_cast<u32 *>(idx + base);
+        for (u32 c = threadIdx.x; c < MTF_TILE / 2; c += MTF_NT) {
+            const u32 p = 2 * c;
+            const u8 *sc = s_code + (p / MTF_CH) * MTF_STRIDE + (p % MTF_CH);
+            if (base + p + 2 <= N) o32[c] = (u32)sc[0] | ((u32)sc[1] << 16);
+            else if (base + p < N) idx[base + p] = (u16)sc[0];
         }
     } else {
         for (u32 p = threadIdx.x; p < MTF_TILE; p += MTF_NT)
-            if (base + p < N) idx[base + p] = (u16)s_sym[p];
+            if (base + p < N) idx[base + p] = (u16)s_code[(p / MTF_CH) * MTF_STRIDE + (p % MTF_CH)];
     }
 }
 
