@@ -234,7 +234,8 @@ static void sa_run(tc_ctx *ctx, SaBuffers &b, const u8 *d_text, u64 n, u32 *d_sa
             memcpy(kg.lut, cfg.lut, sizeof kg.lut);
             u32 ggrid = tc_cdiv(N, 256 * 16 * 4);
             if (ggrid > 2048) ggrid = 2048;
-            ghist_kernel<<<ggrid, 256, 0, s>>>(d_text, (u32)n, kp, b.hist);
+            if (cfg.s == 3) ghist_kernel<3><<<ggrid, 256, 0, s>>>(d_text, (u32)n, kp, b.hist);
+            else ghist_kernel<0><<<ggrid, 256, 0, s>>>(d_text, (u32)n, kp, b.hist);
             TC_LAUNCH_CHECK(ctx);
             keyhist_fix_kernel<<<1, 256, 0, s>>>(d_text, (u32)n, kp, b.hist);
         } else if (onehist) {

@@ -177,8 +177,10 @@ __global__ __launch_bounds__(SA_NT) void keybuild_kernel(const u8 *__restrict__ 
 // Histogram of G over all N positions, straight from the text (used when the first radix
 // pass generates its keys itself, so no keybuild launch exists to take it).  Same
 // conflict-free [value][lane] LDS layout as hist256_kernel.  Result in the LAST hist row.
+template <int CS>  // CS: compile-time s (0 = runtime kp.s)
 __global__ __launch_bounds__(256) void ghist_kernel(const u8 *__restrict__ text, u32 n,
                                                     KeyBuildParams kp, u32 *__restrict__ hist) {
+    const u32 KS = CS ? (u32)CS : kp.s;
     __shared__ u32 s_h[256 * 64];
     __shared__ u16 s_lut[256];
     for (int i = threadIdx.x; i < 256 * 64; i += 256) s_h[i] = 0;
@@ -190,22 +192,25 @@ __global__ __launch_bounds__(256) void ghist_kernel(const u8 *__restrict__ text,
     const u64 units = (N + 15) / 16;
     for (u64 u = (u64)blockIdx.x * 256 + threadIdx.x; u < units; u += (u64)gridDim.x * 256) {
         const u64 p0 = u * 16;
-        u32 c[32];
+        constexpr int NC = CS ? 16 + CS - 1 : 24;   // codes needed: 16 positions + (s - 1) look-ahead
+        u32 c[NC];
         if (aligned && p0 + 32 <= n) {
             const uint4 *tv = reinterpret_cast<const uint4 *>(text + p0);
-            uint4 a = tv[0], b = tv[1];
-            u32 x[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+            uint4 a = tv[0];
+            uint2 b = *reinterpret_cast<const uint2 *>(text + p0 + 16);
+            u32 x[6] = {a.x, a.y, a.z, a.w, b.x, b.y};
 #pragma unroll
-            for (int q = 0; q < 32; q++) c[q] = s_lut[(x[q >> 2] >> (8 * (q & 3))) & 255];
+            for (int q = 0; q < NC; q++) c[q] = s_lut[(x[q >> 2] >> (8 * (q & 3))) & 255];
         } else {
 #pragma unroll
-            for (int q = 0; q < 32; q++) c[q] = (p0 + q < n) ? (u32)s_lut[text[p0 + q]] : 0u;
+            for (int q = 0; q < NC; q++) c[q] = (p0 + q < n) ? (u32)s_lut[text[p0 + q]] : 0u;
         }
 #pragma unroll
         for (int j = 0; j < 16; j++) {
             if (p0 + j < N) {
                 u32 g = 0;
-                for (u32 t = 0; t < kp.s; t++) g = g * kp.B + c[j + t];   // s <= 8 < 17
+#pragma unroll
+                for (u32 t = 0; t < KS; t++) g = g * kp.B + c[j + t];   // s <= 8: j + t < 24
                 atomicAdd(&h[g * 64], 1u);
             }
         }
