@@ -165,21 +165,28 @@ int tc_decode(tc_ctx *ctx, const tc_block *blk, uint8_t *text);
 int tc_decode_dev(tc_ctx *ctx, const tc_block *blk, uint8_t *d_text);
 
 /* ---- encoded-block wire format (used by the multi-GPU gather) ----- */
-/* The reference has no on-disk / wire format.  Packed form of a tc_block's runs:
- *   byte k (k < nruns) = value | (min(count, 15) << 4)      when sigma <= 16
- *   (sigma > 16: two bytes per run: value low byte | count-escape byte)
- * count >= 15 ("escape") additionally appends the pair (run index, count) as two
- * uint32 words to the escape list that follows the bytes at the next 8-byte boundary.
+/* The reference has no on-disk / wire format.  Packed form of a tc_block's runs, chosen by sigma
+ * (values must be < sigma):
+ *   sigma <= 6  (an ACGTN record: 5 letters + sentinel) -- nibble stream: code 0..11 starts a run
+ *       (value = code % 6, count = 1 + code / 6); a following 12 / 13 raises a count of 2 to 3 / 4;
+ *       a following 14 means "count = next uint32 of the escape list" (counts 0 and >= 5, in run
+ *       order); 15 is padding (the packer pads each 16384-run tile to a 16-byte boundary).  The
+ *       escape list (4 bytes each) follows the nibble body.  `packed` must be 16-byte aligned.
+ *   sigma <= 16 -- byte k (k < nruns) = value | (min(count, 15) << 4)
+ *   sigma > 16  -- two bytes per run: value low byte, then count (escape 127) | ninth value bit << 7
+ *       in both byte forms count >= 15 (127) additionally appends the pair (run index, count) as two
+ *       uint32 words to the escape list that follows the bytes at the next 8-byte boundary.
  * *packed_bytes: in = capacity of `packed`, out = bytes used (TC_ERR_CAPACITY: bytes needed);
- * tc_block_packed_bound(nruns, sigma) is always enough (every run escaping), nruns * bytes-per-
- * run + 8 is enough when no count reaches the escape value.  *nesc returns the number of
- * escapes.  All pointers are DEVICE pointers. */
+ * tc_block_packed_bound(nruns, sigma) is always enough.  *nesc returns the number of escapes.
+ * All pointers are DEVICE pointers. */
 uint64_t tc_block_packed_bound(uint64_t nruns, uint32_t sigma);
 int tc_block_pack_dev(tc_ctx *ctx, const tc_block *blk, uint8_t *d_packed, uint64_t *packed_bytes,
                       uint64_t *nesc);
-/* Inverse: fills blk->run_count / blk->run_value (device, capacity blk->nruns >= nruns). */
-int tc_block_unpack_dev(tc_ctx *ctx, const uint8_t *d_packed, uint64_t nruns, uint32_t sigma,
-                        uint64_t nesc, tc_block *blk);
+/* Inverse: fills blk->run_count / blk->run_value (device, capacity blk->nruns >= nruns) from
+ * packed_bytes bytes; a body that does not hold exactly nruns runs and nesc escapes is
+ * TC_ERR_MALFORMED. */
+int tc_block_unpack_dev(tc_ctx *ctx, const uint8_t *d_packed, uint64_t packed_bytes, uint64_t nruns,
+                        uint32_t sigma, uint64_t nesc, tc_block *blk);
 
 /* ---- Data.FMIndex -------------------------------------------------------- */
 /* bytestringToBWTToFMIndexB (FMIndex.hs:108-111,162-183): C[c] (seqToCc,

@@ -179,38 +179,82 @@ def test_finish_and_full_paths_agree(ctx, monkeypatch):
     assert ctx.suffix_array(rep).tolist() == O.suffix_array(rep).tolist()
 
 
-def test_block_pack_unpack_roundtrip(ctx):
-    """Packed wire format of the runs (used by the multi-GPU gather): exact inverse, incl. count
-    escapes and the two-byte form for sigma > 16."""
+def _pack_roundtrip(ctx, sigma, counts, vals):
     import ctypes as C
     import torch
     from textcomp import Block
     lib = ctx.lib
-    rng = np.random.default_rng(12)
-    cases = [(6, rng.integers(1, 4, 50000), rng.integers(0, 6, 50000)),
-             (6, np.array([1, 14, 15, 16, 100000, 2]), np.array([0, 5, 3, 2, 1, 4])),       # escapes
-             (257, rng.integers(1, 300, 20000), rng.integers(0, 257, 20000)),               # 2 bytes / run
-             (16, np.array([2 ** 31]), np.array([15]))]
-    for sigma, counts, vals in cases:
-        k = len(counts)
-        d_c = torch.from_numpy(counts.astype(np.uint32).view(np.int32)).cuda()
-        d_v = torch.from_numpy(vals.astype(np.uint16).view(np.int16)).cuda()
-        blk = Block(); blk.nruns = k; blk.sigma = sigma
-        blk.run_count = d_c.data_ptr(); blk.run_value = d_v.data_ptr()
-        bound = lib.tc_block_packed_bound(k, sigma)
-        buf = torch.zeros(bound, dtype=torch.uint8, device="cuda")
-        nb, ne = C.c_uint64(bound), C.c_uint64()
-        assert lib.tc_block_pack_dev(ctx.handle, C.byref(blk), C.c_void_p(buf.data_ptr()), C.byref(nb), C.byref(ne)) == 0
-        assert nb.value <= bound
-        small = C.c_uint64(k // 2)
+    k = len(counts)
+    d_c = torch.from_numpy(counts.astype(np.uint32).view(np.int32)).cuda()
+    d_v = torch.from_numpy(vals.astype(np.uint16).view(np.int16)).cuda()
+    blk = Block(); blk.nruns = k; blk.sigma = sigma
+    blk.run_count = d_c.data_ptr(); blk.run_value = d_v.data_ptr()
+    bound = lib.tc_block_packed_bound(k, sigma)
+    buf = torch.zeros(bound, dtype=torch.uint8, device="cuda")
+    nb, ne = C.c_uint64(bound), C.c_uint64()
+    assert lib.tc_block_pack_dev(ctx.handle, C.byref(blk), C.c_void_p(buf.data_ptr()), C.byref(nb), C.byref(ne)) == 0
+    assert nb.value <= bound
+    if k >= 64:
+        small = C.c_uint64(k // 4)
         assert lib.tc_block_pack_dev(ctx.handle, C.byref(blk), C.c_void_p(buf.data_ptr()), C.byref(small), C.byref(C.c_uint64())) == -2
-        esc_thr = 15 if sigma <= 16 else 127
-        assert ne.value == int((counts >= esc_thr).sum())
-        o_c = torch.zeros(k, dtype=torch.int32, device="cuda"); o_v = torch.zeros(k, dtype=torch.int16, device="cuda")
-        out = Block(); out.nruns = k; out.run_count = o_c.data_ptr(); out.run_value = o_v.data_ptr()
-        assert lib.tc_block_unpack_dev(ctx.handle, C.c_void_p(buf.data_ptr()), k, sigma, ne.value, C.byref(out)) == 0
-        assert np.array_equal(o_c.cpu().numpy().view(np.uint32), counts.astype(np.uint32))
-        assert np.array_equal(o_v.cpu().numpy().view(np.uint16), vals.astype(np.uint16))
+        assert small.value > k // 4        # bytes needed
+        assert lib.tc_block_pack_dev(ctx.handle, C.byref(blk), C.c_void_p(buf.data_ptr()), C.byref(nb), C.byref(ne)) == 0
+    o_c = torch.zeros(k, dtype=torch.int32, device="cuda"); o_v = torch.zeros(k, dtype=torch.int16, device="cuda")
+    out = Block(); out.nruns = k; out.run_count = o_c.data_ptr(); out.run_value = o_v.data_ptr()
+    assert lib.tc_block_unpack_dev(ctx.handle, C.c_void_p(buf.data_ptr()), nb.value, k, sigma, ne.value, C.byref(out)) == 0
+    assert np.array_equal(o_c.cpu().numpy().view(np.uint32), counts.astype(np.uint32))
+    assert np.array_equal(o_v.cpu().numpy().view(np.uint16), vals.astype(np.uint16))
+    return nb.value, ne.value, buf
+
+
+def test_block_pack_unpack_roundtrip(ctx):
+    """Packed wire format of the runs (used by the multi-GPU gather): exact inverse, incl. count
+    escapes, the nibble stream for sigma <= 6 and the two-byte form for sigma > 16."""
+    rng = np.random.default_rng(12)
+    byte_cases = [(16, rng.integers(1, 4, 50000), rng.integers(0, 16, 50000)),
+                  (7, np.array([1, 14, 15, 16, 100000, 2]), np.array([0, 5, 3, 2, 1, 6])),       # escapes
+                  (257, rng.integers(1, 300, 20000), rng.integers(0, 257, 20000)),               # 2 bytes / run
+                  (16, np.array([2 ** 31]), np.array([15]))]
+    for sigma, counts, vals in byte_cases:
+        nb, ne, _ = _pack_roundtrip(ctx, sigma, counts, vals)
+        assert ne == int((counts >= (15 if sigma <= 16 else 127)).sum())
+
+
+def test_block_pack_nibble_stream(ctx):
+    """sigma <= 6: 4 bits per run of count 1-2, 8 bits for 3-4, escapes beyond; tiles of 16384 runs
+    end on 16-byte boundaries."""
+    import ctypes as C
+    import torch
+    from textcomp import Block
+    rng = np.random.default_rng(13)
+    geo = lambda k: np.minimum(rng.geometric(0.8, k), 9)
+    cases = [(6, np.array([1]), np.array([5])),
+             (6, np.array([1, 2, 3, 4, 5, 0, 6, 2 ** 31, 1]), np.array([0, 1, 2, 3, 4, 5, 0, 1, 2])),
+             (6, geo(31), rng.integers(0, 6, 31)),
+             (5, geo(16384), rng.integers(0, 5, 16384)),              # exactly one packer tile
+             (6, geo(16385), rng.integers(0, 6, 16385)),
+             (6, np.full(40000, 7), rng.integers(0, 6, 40000)),       # every run escapes
+             (6, np.full(70000, 3), rng.integers(0, 6, 70000)),       # every run 2 nibbles
+             (2, np.ones(100001, dtype=np.int64), rng.integers(0, 2, 100001)),
+             (6, geo(1500000), rng.integers(0, 6, 1500000))]
+    for sigma, counts, vals in cases:
+        nb, ne, buf = _pack_roundtrip(ctx, sigma, counts, vals)
+        assert ne == int(((counts < 1) | (counts > 4)).sum())
+        nibbles = len(counts) + int((counts > 2).sum()) + int((counts < 1).sum())
+        tiles = -(-len(counts) // 16384)
+        assert nibbles / 2 <= nb - 4 * ne <= nibbles / 2 + 16 * tiles
+    # a body that does not match its header is malformed, never an out-of-bounds write
+    counts, vals = geo(50000), rng.integers(0, 6, 50000)
+    nb, ne, buf = _pack_roundtrip(ctx, 6, counts, vals)
+    lib = ctx.lib
+    k = len(counts)
+    o_c = torch.zeros(k, dtype=torch.int32, device="cuda"); o_v = torch.zeros(k, dtype=torch.int16, device="cuda")
+    out = Block(); out.nruns = k; out.run_count = o_c.data_ptr(); out.run_value = o_v.data_ptr()
+    assert lib.tc_block_unpack_dev(ctx.handle, C.c_void_p(buf.data_ptr()), nb, k - 1, 6, ne, C.byref(out)) == -3
+    out.nruns = k
+    assert lib.tc_block_unpack_dev(ctx.handle, C.c_void_p(buf.data_ptr()), nb - 16, k, 6, ne, C.byref(out)) == -3
+    out.nruns = k
+    assert lib.tc_block_unpack_dev(ctx.handle, C.c_void_p(buf.data_ptr()), nb - 3, k, 6, ne, C.byref(out)) == -3
 
 
 def test_mtf_slow_and_fast_incoming_list_paths(ctx, monkeypatch):

@@ -31,7 +31,8 @@ def _worker(rank, world, port, n, q):
     try:
         from textcomp.gather import BlockGather, shard_patterns
         g = BlockGather(n + 64, torch.device("cpu"), depth=2)
-        ok = True
+        g.prime()
+        ok = g.completed == [] and g._step == 0
         steps = 5
         bufs = [None, None]
         for st in range(steps):     # pipelined: submit only posts; buffers are double-buffered

@@ -4,6 +4,7 @@
 #include "tc_encode_host.hpp"
 #include "tc_decode_host.hpp"
 #include "tc_fm_host.hpp"
+#include "tc_pack.hpp"
 #include "textcomp_debug.h"
 
 // ================================================================== context
@@ -274,55 +275,6 @@ __global__ __launch_bounds__(256) void dbg_check_sorted_kernel(const u64 *keys, 
         u64 a = keys[i] >> (64 - key_bits), b = keys[i + 1] >> (64 - key_bits);
         if (a > b || (a == b && vals[i] >= vals[i + 1])) atomicAdd(bad, 1u);
     }
-}
-
-// ------------------------------------------------------------ packed run format
-// bytes per run: 1 (sigma <= 16) or 2 (value byte, count byte with 255 = escape; the
-// ninth value bit of sigma = 257 rides in the count byte's top bit -> counts escape at 127)
-static inline int pack_bpr(u32 sigma) { return sigma <= 16 ? 1 : 2; }
-
-__global__ __launch_bounds__(256) void pack_runs_kernel(const u32 *__restrict__ cnt,
-                                                        const u16 *__restrict__ val, u64 nruns,
-                                                        int bpr, u8 *__restrict__ out,
-                                                        u32 *__restrict__ esc, u32 *nesc, u64 esc_cap) {
-    for (u64 k = (u64)blockIdx.x * 256 + threadIdx.x; k < nruns; k += (u64)gridDim.x * 256) {
-        const u32 c = cnt[k], v = val[k];
-        bool e;
-        if (bpr == 1) {
-            e = c >= 15;
-            out[k] = (u8)((v & 15u) | ((e ? 15u : c) << 4));
-        } else {
-            e = c >= 127;
-            out[2 * k] = (u8)v;
-            out[2 * k + 1] = (u8)((e ? 127u : c) | ((v >> 8) << 7));
-        }
-        if (e) {
-            u32 slot = atomicAdd(nesc, 1u);
-            if (slot < esc_cap) {
-                esc[2 * (u64)slot] = (u32)k;
-                esc[2 * (u64)slot + 1] = c;
-            }
-        }
-    }
-}
-__global__ __launch_bounds__(256) void unpack_runs_kernel(const u8 *__restrict__ in, u64 nruns, int bpr,
-                                                          u32 *__restrict__ cnt, u16 *__restrict__ val) {
-    for (u64 k = (u64)blockIdx.x * 256 + threadIdx.x; k < nruns; k += (u64)gridDim.x * 256) {
-        if (bpr == 1) {
-            u8 b = in[k];
-            val[k] = (u16)(b & 15);
-            cnt[k] = (u32)(b >> 4);
-        } else {
-            u8 lo = in[2 * k], hi = in[2 * k + 1];
-            val[k] = (u16)(lo | ((hi >> 7) << 8));
-            cnt[k] = (u32)(hi & 127);
-        }
-    }
-}
-__global__ __launch_bounds__(256) void unpack_esc_kernel(const u32 *__restrict__ esc, u64 nesc,
-                                                         u64 nruns, u32 *__restrict__ cnt) {
-    u64 i = (u64)blockIdx.x * 256 + threadIdx.x;
-    if (i < nesc && esc[2 * i] < nruns) cnt[esc[2 * i]] = esc[2 * i + 1];
 }
 
 extern "C" {
@@ -663,8 +615,11 @@ int tc_decode(tc_ctx *ctx, const tc_block *blk, uint8_t *text) {
 
 // ====================================================== encoded-block wire format
 uint64_t tc_block_packed_bound(uint64_t nruns, uint32_t sigma) {
-    // bytes + 8-byte alignment + worst-case escape list (every run escapes)
-    return (((u64)pack_bpr(sigma) * nruns + 7) & ~7ull) + 8 * nruns + 8;
+    const int fmt = pack_format(sigma);
+    // nibble stream: <= 1 byte per run + 16 bytes of padding per packer tile + 4-byte escapes
+    if (fmt == 0) return nruns + 16 * ((nruns + PK_TILE - 1) / PK_TILE + 1) + 4 * nruns;
+    // bytes + 8-byte alignment + worst-case escape list (every run escaping)
+    return (((u64)fmt * nruns + 7) & ~7ull) + 8 * nruns + 8;
 }
 
 int tc_block_pack_dev(tc_ctx *ctx, const tc_block *blk, uint8_t *d_packed, uint64_t *packed_bytes,
@@ -676,7 +631,50 @@ int tc_block_pack_dev(tc_ctx *ctx, const tc_block *blk, uint8_t *d_packed, uint6
     *packed_bytes = 0; *nesc = 0;
     if (nruns == 0) return TC_OK;
     if (!d_packed || !blk->run_count || !blk->run_value) TC_FAIL(ctx, TC_ERR_ARG, "null buffer");
-    const int bpr = pack_bpr(blk->sigma);
+    if (nruns > (u64)TC_MAX_N + 2) TC_FAIL(ctx, TC_ERR_ARG, "too many runs");
+    const int fmt = pack_format(blk->sigma);
+    if (fmt == 0) {
+        if ((uintptr_t)d_packed & 15) TC_FAIL(ctx, TC_ERR_ARG, "packed buffer must be 16-byte aligned");
+        const u32 ntiles = tc_cdiv(nruns, PK_TILE);
+        u64 *status = nullptr;
+        u32 *esc = nullptr;
+        // escape scratch: sized for the capacity the caller offers (an escape costs 4 bytes there)
+        const u64 esc_cap = cap / 4 < nruns ? cap / 4 : nruns;
+        auto carve = [&](Arena &A) {
+            status = A.get<u64>((size_t)ntiles + 2);
+            esc = A.get<u32>(esc_cap + 4);
+        };
+        Arena dry(nullptr);
+        carve(dry);
+        tc_ws_reserve(ctx, dry.off);
+        Arena A(ctx->ws);
+        carve(A);
+        tc_memset_async(ctx, status, 0, ((size_t)ntiles + 2) * sizeof(u64));
+        PackNibArgs a;
+        a.cnt = blk->run_count; a.val = blk->run_value; a.nruns = nruns;
+        a.out = d_packed; a.cap_units = cap / 16;
+        a.esc = esc; a.esc_cap = esc_cap;
+        a.status = status; a.ticket = reinterpret_cast<u32 *>(status + ntiles); a.err = ctx->d_err;
+        a.ntiles = ntiles;
+        u32 grid = tc_persistent_grid_for(ctx, pack_nib_kernel, PK_NT, 4);
+        if (grid > ntiles) grid = ntiles;
+        pack_nib_kernel<<<grid, PK_NT, 0, ctx->stream>>>(a);
+        TC_LAUNCH_CHECK(ctx);
+        tc_d2h(ctx, &ctx->h_scalars[14], status + (ntiles - 1), sizeof(u64));
+        tc_sync_check(ctx);
+        const u64 tot = LB_VALUE(ctx->h_scalars[14]);
+        const u64 body = (tot >> 32) * 16, ne = tot & 0xffffffffull;
+        *nesc = ne;
+        *packed_bytes = body + 4 * ne;
+        if (*packed_bytes > cap || ne > esc_cap)
+            TC_FAIL(ctx, TC_ERR_CAPACITY, "packed runs need %llu bytes", (unsigned long long)*packed_bytes);
+        if (ne) {
+            TC_HIP(ctx, hipMemcpyAsync(d_packed + body, esc, 4 * ne, hipMemcpyDeviceToDevice, ctx->stream));
+            TC_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        }
+        return TC_OK;
+    }
+    const int bpr = fmt;
     const u64 body = ((u64)bpr * nruns + 7) & ~7ull;
     if (body > cap) {
         *packed_bytes = body;
@@ -700,14 +698,54 @@ int tc_block_pack_dev(tc_ctx *ctx, const tc_block *blk, uint8_t *d_packed, uint6
     TC_API_END(ctx)
 }
 
-int tc_block_unpack_dev(tc_ctx *ctx, const uint8_t *d_packed, uint64_t nruns, uint32_t sigma,
-                        uint64_t nesc, tc_block *blk) {
+int tc_block_unpack_dev(tc_ctx *ctx, const uint8_t *d_packed, uint64_t packed_bytes, uint64_t nruns,
+                        uint32_t sigma, uint64_t nesc, tc_block *blk) {
     TC_API_BEGIN(ctx)
     if (!blk || blk->nruns < nruns) TC_FAIL(ctx, TC_ERR_ARG, "bad argument");
     if (nruns == 0) { blk->nruns = 0; return TC_OK; }
     if (!d_packed || !blk->run_count || !blk->run_value) TC_FAIL(ctx, TC_ERR_ARG, "null buffer");
-    const int bpr = pack_bpr(sigma);
+    const int fmt = pack_format(sigma);
+    if (fmt == 0) {
+        if ((uintptr_t)d_packed & 15) TC_FAIL(ctx, TC_ERR_ARG, "packed buffer must be 16-byte aligned");
+        if (packed_bytes < 4 * nesc || ((packed_bytes - 4 * nesc) & 15) || nesc > nruns)
+            TC_FAIL(ctx, TC_ERR_MALFORMED, "packed block: %llu bytes do not hold a nibble body and %llu escapes",
+                    (unsigned long long)packed_bytes, (unsigned long long)nesc);
+        const u64 body = packed_bytes - 4 * nesc, units = body / 16;
+        if (units > (u64)nruns + (nruns + PK_TILE - 1) / PK_TILE + 1)  // > 1 byte per run + padding
+            TC_FAIL(ctx, TC_ERR_MALFORMED, "packed block: body too long for %llu runs", (unsigned long long)nruns);
+        const u32 ntiles = tc_cdiv(units, UP_TILE_UNITS);
+        u64 *status = nullptr;
+        auto carve = [&](Arena &A) { status = A.get<u64>((size_t)ntiles + 2); };
+        Arena dry(nullptr);
+        carve(dry);
+        tc_ws_reserve(ctx, dry.off);
+        Arena A(ctx->ws);
+        carve(A);
+        tc_memset_async(ctx, status, 0, ((size_t)ntiles + 2) * sizeof(u64));
+        UnpackNibArgs a;
+        a.body = d_packed; a.units = units;
+        a.esc = reinterpret_cast<const u32 *>(d_packed + body); a.nesc = nesc; a.nruns = nruns;
+        a.cnt = blk->run_count; a.val = blk->run_value;
+        a.status = status; a.ticket = reinterpret_cast<u32 *>(status + ntiles); a.err = ctx->d_err;
+        a.ntiles = ntiles;
+        u32 grid = tc_persistent_grid_for(ctx, unpack_nib_kernel, UP_NT, 4);
+        if (grid > ntiles) grid = ntiles;
+        unpack_nib_kernel<<<grid, UP_NT, 0, ctx->stream>>>(a);
+        TC_LAUNCH_CHECK(ctx);
+        tc_d2h(ctx, &ctx->h_scalars[14], status + (ntiles - 1), sizeof(u64));
+        tc_sync_check(ctx);
+        const u64 tot = LB_VALUE(ctx->h_scalars[14]);
+        if ((tot >> 31) != nruns || (tot & 0x7fffffffull) != nesc)
+            TC_FAIL(ctx, TC_ERR_MALFORMED, "packed block holds %llu runs / %llu escapes, header says %llu / %llu",
+                    (unsigned long long)(tot >> 31), (unsigned long long)(tot & 0x7fffffffull),
+                    (unsigned long long)nruns, (unsigned long long)nesc);
+        blk->nruns = nruns;
+        blk->sigma = sigma;
+        return TC_OK;
+    }
+    const int bpr = fmt;
     const u64 body = ((u64)bpr * nruns + 7) & ~7ull;
+    if (packed_bytes < body + 8 * nesc) TC_FAIL(ctx, TC_ERR_MALFORMED, "packed block too short");
     u32 grid = tc_cdiv(nruns, 256 * 8);
     if (grid > 8192) grid = 8192;
     unpack_runs_kernel<<<grid, 256, 0, ctx->stream>>>(d_packed, nruns, bpr, blk->run_count, blk->run_value);

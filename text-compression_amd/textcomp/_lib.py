@@ -73,7 +73,7 @@ SYMBOLS = [
     ("tc_decode_dev", _INT, [_P, C.POINTER(Block), _P]),
     ("tc_block_packed_bound", _U64, [_U64, _U32]),
     ("tc_block_pack_dev", _INT, [_P, C.POINTER(Block), _P, _PU64, _PU64]),
-    ("tc_block_unpack_dev", _INT, [_P, _P, _U64, _U32, _U64, C.POINTER(Block)]),
+    ("tc_block_unpack_dev", _INT, [_P, _P, _U64, _U64, _U32, _U64, C.POINTER(Block)]),
     ("tc_fm_build", _INT, [_P, _P, _U64, C.POINTER(_P)]),
     ("tc_fm_free", None, [_P]),
     ("tc_fm_count", _INT, [_P, _P, _P, _P, _U64, _P]),

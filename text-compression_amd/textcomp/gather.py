@@ -5,8 +5,8 @@ gather of the encoded blocks on rank 0.
 Design for xGMI (point-to-point links, no switch): a root gather posted as one batch
 of sends/receives lets rank 0 ingest on all of its links at once, where a ring would be
 bound by a single link.  Two further measures keep the exchange off the critical path:
-  * the payload is the PACKED run format of include/textcomp.h (1 byte per run for
-    sigma <= 16 instead of 6), and
+  * the payload is the PACKED run format of include/textcomp.h (an ACGTN record: a nibble
+    stream of ~0.53 bytes per run instead of 6), and
   * the exchange is pipelined: `submit()` only posts the transfers (double-buffered),
     so the gather of record k overlaps the encode of record k+1; `drain()` completes
     everything still in flight.
@@ -93,6 +93,16 @@ class BlockGather:
             ops.append(dist.P2POp(dist.isend, payload[:nbytes], 0, group=self.group))
         works = dist.batch_isend_irecv(ops) if ops else []
         self._inflight[slot] = (works, result)
+
+    def prime(self):
+        """Untimed set-up: one tiny exchange so that both communicators and the peer-to-peer
+        connections to rank 0 exist before the first real record is posted."""
+        if self.world == 1:
+            return
+        self.submit([16, 0, 0, 0, 0, 0], torch.zeros(16, dtype=torch.uint8, device=self.device))
+        self.drain()
+        self.completed.clear()
+        self._step = 0
 
     def drain(self):
         """Complete every transfer still in flight (oldest first)."""
