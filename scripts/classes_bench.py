@@ -1,0 +1,82 @@
+#!/usr/bin/env python3
+"""Encode + decode time per input class (device-resident): how the path behaves away from iid ACGTN."""
+import ctypes as C, os, sys, time
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "text-compression_amd"))
+import numpy as np, torch, textcomp
+from textcomp import Block
+n = int(sys.argv[1]) if len(sys.argv) > 1 else 1 << 28
+only = sys.argv[2].split(",") if len(sys.argv) > 2 else None
+ctx = textcomp.Context(0); lib = ctx.lib
+g = torch.Generator(device="cuda"); g.manual_seed(7)
+def rnd(sigma, lo=0):
+    return (torch.randint(0, sigma, (n,), generator=g, device="cuda", dtype=torch.int32) + lo).to(torch.uint8)
+def repeat(block):
+    base = rnd(4, 65)[:block]
+    return base.repeat(n // block + 1)[:n].contiguous()
+def markov():
+    # order-1 biased: long-ish runs (each symbol repeats with p = 0.9)
+    keep = torch.rand(n, generator=g, device="cuda") < 0.9
+    sym = rnd(4, 65)
+    idx = torch.arange(n, device="cuda")
+    src = torch.where(keep, torch.zeros_like(idx), idx)
+    src = torch.cummax(src, 0).values
+    return sym[src].contiguous()
+def zipf_words(vocab=20000, a=1.1):
+    # English-like: Zipf-distributed words over a random vocabulary, single spaces
+    rs = np.random.default_rng(5)
+    wl = rs.integers(2, 10, vocab)
+    off = np.concatenate([[0], np.cumsum(wl + 1)])
+    flat = rs.integers(97, 123, int(off[-1])).astype(np.uint8)
+    flat[off[1:] - 1] = 32
+    p = 1.0 / np.arange(1, vocab + 1) ** a
+    nw = n // 5 + 1000
+    ids = torch.from_numpy(rs.choice(vocab, nw, p=p / p.sum())).cuda()
+    lens = torch.from_numpy(wl + 1).cuda()[ids]
+    starts = torch.cumsum(lens, 0) - lens
+    src0 = torch.from_numpy(off[:-1]).cuda()[ids]
+    word_of = torch.repeat_interleave(torch.arange(nw, device="cuda"), lens)[:n]
+    pos = torch.arange(n, device="cuda") - starts[word_of]
+    return torch.from_numpy(flat).cuda()[src0[word_of] + pos].contiguous()
+classes = {
+    "zipf_words": zipf_words,
+    "acgtn": lambda: None,
+    "ascii96": lambda: rnd(96, 32),
+    "bytes256": lambda: rnd(256),
+    "binary2": lambda: rnd(2, 48),
+    "runs_p0.9": markov,
+    "repeat_1MiB": lambda: repeat(1 << 20),
+    "repeat_4KiB": lambda: repeat(1 << 12),
+    "all_A": lambda: torch.full((n,), 65, dtype=torch.uint8, device="cuda"),
+}
+cap = n + 2
+d_cnt = torch.empty(cap, dtype=torch.int32, device="cuda"); d_val = torch.empty(cap, dtype=torch.int16, device="cuda")
+d_out = torch.empty(n, dtype=torch.uint8, device="cuda")
+for name, mk in classes.items():
+    if only and name not in only:
+        continue
+    t = mk()
+    if t is None:
+        t = torch.empty(n, dtype=torch.uint8, device="cuda")
+        assert lib.tc_generate_dev(ctx.handle, 0, 0xC3, n, C.c_void_p(t.data_ptr())) == 0
+    torch.cuda.synchronize()
+    enc, dec = [], []
+    for it in range(2):
+        blk = Block(); blk.nruns = cap; blk.run_count = d_cnt.data_ptr(); blk.run_value = d_val.data_ptr()
+        t0 = time.perf_counter()
+        rc = lib.tc_encode_dev(ctx.handle, C.c_void_p(t.data_ptr()), n, C.byref(blk))
+        enc.append(time.perf_counter() - t0)
+        if rc:
+            print(name, "encode rc", rc, lib.tc_last_error(ctx.handle)); break
+        st = ctx.stats()
+        t0 = time.perf_counter()
+        rc = lib.tc_decode_dev(ctx.handle, C.byref(blk), C.c_void_p(d_out.data_ptr()))
+        dec.append(time.perf_counter() - t0)
+        if rc:
+            print(name, "decode rc", rc, lib.tc_last_error(ctx.handle)); break
+    else:
+        ok = bool(torch.equal(d_out, t))
+        print("%-12s n=%d sigma=%d enc %.1f ms (%.2f GB/s) dec %.1f ms (%.2f GB/s) rounds=%d m=%s passes=%s runs=%d exact=%s | sa %.1f mtf %.1f rle %.1f" % (
+            name, n, blk.sigma, min(enc) * 1e3, n / min(enc) / 1e9, min(dec) * 1e3, n / min(dec) / 1e9, st.rounds,
+            [int(st.m[i]) for i in range(st.rounds)][:6], [int(st.passes[i]) for i in range(st.rounds)][:6], blk.nruns, ok, st.ms_sa, st.ms_mtf, st.ms_rle), flush=True)
+    del t

@@ -89,6 +89,25 @@ def test_fused_roundtrip(ctx, t):
     assert ctx.decode(blk) == bytes(t)
 
 
+def test_rle_decode_long_runs(ctx):
+    """Runs below / at / above the wave-fill (32) and grid-fill (16384) thresholds, mixed with
+    Nothing pairs; and the inverse BWT of periodic texts (walks with a constant row mod 256 must
+    still meet splitters)."""
+    counts = np.array([1, 31, 32, 33, 16383, 7, 16384, 16385, 1, 300000, 2, 5], dtype=np.uint32)
+    syms = np.array([5, 6, -1, 7, 8, -1, 9, 10, 11, 12, 13, -1], dtype=np.int16)
+    exp = np.concatenate([np.full(1 if s < 0 else c, s, np.int16) for c, s in zip(counts, syms)])
+    assert np.array_equal(ctx.rle_decode(counts, syms), exp)
+    vals = np.array([5, 6, 0, 7, 8, 65535, 9, 10, 11, 12, 13, 1], dtype=np.uint16)
+    exp = np.concatenate([np.full(c, v, np.uint16) for c, v in zip(counts, vals)])
+    assert np.array_equal(ctx.rle_decode_u16(counts, vals), exp)
+    rng = np.random.default_rng(77)
+    for block, copies in ((4096, 256), (1000, 300), (256, 1024)):
+        t = (bytes(rng.choice(list(b"ACGT"), block).astype(np.uint8)) * copies)
+        assert ctx.decode(ctx.encode(t)) == t
+    t = b"A" * 200000
+    assert ctx.decode(ctx.encode(t)) == t
+
+
 def test_fused_decode_rejects_inconsistent_block(ctx):
     import textcomp
     blk = ctx.encode(b"mississippi" * 50)

@@ -75,6 +75,46 @@ def test_mtf_general_path_equals_nibble_path(ctx, monkeypatch):
     assert a[0].tolist() == O.mtf_encode_arr(sym)[0].tolist()
 
 
+@pytest.mark.parametrize("sigma", [17, 40, 64, 65, 100, 128, 129, 192, 193, 255, 256, 257])
+def test_mtf_general_sigma(ctx, sigma, monkeypatch):
+    """sigma > 16: one chunk per lane (byte lists in LDS, sigma <= 256) or per wave (sigma = 257);
+    lengths around the 128-symbol lane chunk and the 32768-symbol tile; skewed data (small ranks,
+    late first occurrences) and uniform data (large ranks)."""
+    rng = np.random.default_rng(1000 + sigma)
+    nsym = sigma - 1 if sigma == 257 or sigma % 2 else sigma       # with / without a Nothing
+    with_nothing = nsym < sigma
+    alphabet = rng.permutation(256)[:nsym]
+    for N, skew in ((1, 0), (127, 1), (129, 0), (32768, 1), (32769, 0), (100001, 1), (70000, 0)):
+        if skew:
+            p = 1.0 / np.arange(1, nsym + 1) ** 1.5
+            body = rng.choice(nsym, N, p=p / p.sum())
+            late = rng.integers(0, N, min(N, nsym))        # every symbol occurs at least once, somewhere
+            body[late[:min(N, nsym)]] = np.arange(min(N, nsym))
+        else:
+            body = rng.integers(0, nsym, N)
+            if N >= nsym:
+                body[rng.permutation(N)[:nsym]] = np.arange(nsym)
+        sym = alphabet[body].astype(np.int16)
+        if with_nothing and N > 1:
+            sym[rng.integers(0, N)] = -1
+        eidx, efl = O.mtf_encode_arr(sym)
+        idx, fl = ctx.mtf_encode_sym(sym)
+        assert np.array_equal(idx, eidx) and fl.tolist() == efl.tolist(), (sigma, N, skew)
+        if N == 100001:
+            monkeypatch.setenv("TC_MTF_WAVE_CHUNKS", "1")
+            idx, fl = ctx.mtf_encode_sym(sym)
+            monkeypatch.delenv("TC_MTF_WAVE_CHUNKS")
+            assert np.array_equal(idx, eidx) and fl.tolist() == efl.tolist()
+        if (sym >= 0).all() or int(np.sum(sym < 0)) == 1:
+            # (L, primary) accessor form: 16-byte staged loads + sentinel patch
+            prim = int(np.nonzero(sym < 0)[0][0]) if (sym < 0).any() else None
+            Lb = np.where(sym < 0, 0, sym).astype(np.uint8)
+            idx, fl = ctx.mtf_encode(Lb, prim)
+            assert np.array_equal(idx, eidx) and fl.tolist() == efl.tolist()
+        dec = ctx.mtf_decode(eidx, efl)
+        assert np.array_equal(dec, sym)
+
+
 @pytest.mark.parametrize("t", TEXTS, ids=_ids)
 def test_rle(ctx, t):
     eL, eprim, sym = _expect_bwt(t)

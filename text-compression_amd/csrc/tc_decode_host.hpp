@@ -7,7 +7,9 @@
 //   1. stable counting sort of positions by symbol (Nothing first) = one/two radix
 //      passes -> spos[d] (the `snd` column of the sorted Seq); the `fst` column is
 //      implied by the symbol boundaries C[].
-//   2. the chase becomes list ranking: every row r with r % S == 0 is a splitter;
+//   2. the chase becomes list ranking: one row per block of S rows is a splitter (its offset in
+//      the block is a byte-sum hash of the block number, so that periodic inputs -- whose walks
+//      keep a constant row mod S -- cannot miss every splitter);
 //      each splitter walks to the next splitter (independent walks, in parallel),
 //      the splitter chain is ranked by pointer jumping (log K rounds), then every
 //      splitter on row e's chain re-walks its segment writing text bytes at their
@@ -19,6 +21,13 @@
 #define IBWT_S 256  // splitter spacing (rows)
 
 #ifdef __HIPCC__
+
+// the splitter of block q = r / 256 sits at offset -(byte sum of q) mod 256; block 0: row 0
+__device__ __forceinline__ u32 ibwt_split_off(u32 q) {
+    return (0u - (q + (q >> 8) + (q >> 16))) & 255u;
+}
+__device__ __forceinline__ u32 ibwt_split_row(u32 q) { return q * IBWT_S + ibwt_split_off(q); }
+__device__ __forceinline__ bool ibwt_is_splitter(u32 r) { return (r & 255u) == ibwt_split_off(r >> 8); }
 
 template <class Acc>
 __global__ __launch_bounds__(256) void ibwt_keys_kernel(Acc acc, u32 N, Lut16 lut,
@@ -49,11 +58,16 @@ __global__ __launch_bounds__(256) void ibwt_walk1_kernel(const u32 *__restrict__
                                                          u32 *__restrict__ dist) {
     u32 q = blockIdx.x * 256 + threadIdx.x;
     if (q >= K) return;
-    u32 r = q * IBWT_S, steps = 0;
+    u32 r = ibwt_split_row(q), steps = 0;
+    if (r >= N) {  // the last, partial block may not hold its splitter row: inert slot
+        nxt[q] = q;
+        dist[q] = 0;
+        return;
+    }
     do {
         r = spos[r];
         steps++;
-    } while (r % IBWT_S != 0 && steps <= N);
+    } while (!ibwt_is_splitter(r) && steps <= N);
     nxt[q] = r / IBWT_S;
     dist[q] = steps;
 }
@@ -102,7 +116,7 @@ __global__ __launch_bounds__(256) void ibwt_walk2_kernel(const u32 *__restrict__
     if (q != 0 && nxt[q] != 0) return;  // not on row e's chain
     const u32 Lc = (u32)scalars[6];
     u32 p = (q == 0) ? 0u : Lc - dist[q];
-    u32 r = q * IBWT_S, steps = 0;
+    u32 r = ibwt_split_row(q), steps = 0;
     while (steps++ <= N) {
         r = spos[r];
         if (r == 0) break;
@@ -112,7 +126,7 @@ __global__ __launch_bounds__(256) void ibwt_walk2_kernel(const u32 *__restrict__
             break;
         }
         text[p++] = (u8)sym;
-        if (r % IBWT_S == 0) break;
+        if (ibwt_is_splitter(r)) break;
     }
 }
 
@@ -193,9 +207,31 @@ static void imtf_launch(tc_ctx *ctx, const u16 *d_idx, u64 N, u32 sigma, u16 *pe
     hipStream_t s = ctx->stream;
     imtf_summary_kernel<ROWS><<<chunks, 64, 0, s>>>(d_idx, N, sigma, perms, ctx->d_err);
     TC_LAUNCH_CHECK(ctx);
-    imtf_scan_kernel<ROWS><<<1, 64, 0, s>>>(perms, chunks);
+    imtf_scan_kernel<ROWS><<<1, 64 * MTFG_SCAN_WAVES, 0, s>>>(perms, chunks);
     TC_LAUNCH_CHECK(ctx);
     imtf_apply_kernel<ROWS><<<chunks, 64, 0, s>>>(d_idx, N, sigma, perms, tab, d_out);
+    TC_LAUNCH_CHECK(ctx);
+}
+
+// sigma <= 256: one chunk per lane (tc_mtf.hpp, "inverse MTF, lane chunks")
+template <int ROWS>
+static void imtf_lane_launch(tc_ctx *ctx, const u16 *d_idx, u64 N, u32 sigma, u16 *perms,
+                             const SymTab &tab, i16 *d_out) {
+    hipStream_t s = ctx->stream;
+    GmiArgs a;
+    a.N = N; a.sigma = sigma; a.ls = ((sigma + 3) / 4) | 1u;
+    a.idx = d_idx; a.perms = perms; a.tab = tab; a.out = d_out; a.err = ctx->d_err;
+    const u32 tiles = tc_cdiv(N, GM_TILE);
+    const size_t lds = gm_lds_bytes(a.ls);
+    TC_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(imtf_gm_kernel<ROWS, false>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    TC_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(imtf_gm_kernel<ROWS, true>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    imtf_gm_kernel<ROWS, false><<<tiles, GM_NT, lds, s>>>(a);
+    TC_LAUNCH_CHECK(ctx);
+    imtf_scan_kernel<ROWS><<<1, 64 * MTFG_SCAN_WAVES, 0, s>>>(perms, tiles);
+    TC_LAUNCH_CHECK(ctx);
+    imtf_gm_kernel<ROWS, true><<<tiles, GM_NT, lds, s>>>(a);
     TC_LAUNCH_CHECK(ctx);
 }
 
@@ -214,7 +250,14 @@ static void mtf_decode_device(tc_ctx *ctx, Arena &A, const u16 *d_idx, u64 N, co
     u32 sigma = 0;
     for (int v = 0; v < 257; v++)
         if (seen[v]) tab.v[sigma++] = (i16)(v - 1);
-    if (sigma <= 64) imtf_launch<1>(ctx, d_idx, N, sigma, perms, chunks, tab, d_out);
+    for (u32 v = sigma; v < 260; v++) tab.v[v] = 0;
+    if (sigma <= 256 && env_int("TC_MTF_WAVE_CHUNKS", 0) == 0) {
+        const u32 rows = (sigma + 63) / 64;
+        if (rows <= 1) imtf_lane_launch<1>(ctx, d_idx, N, sigma, perms, tab, d_out);
+        else if (rows == 2) imtf_lane_launch<2>(ctx, d_idx, N, sigma, perms, tab, d_out);
+        else if (rows == 3) imtf_lane_launch<3>(ctx, d_idx, N, sigma, perms, tab, d_out);
+        else imtf_lane_launch<4>(ctx, d_idx, N, sigma, perms, tab, d_out);
+    } else if (sigma <= 64) imtf_launch<1>(ctx, d_idx, N, sigma, perms, chunks, tab, d_out);
     else if (sigma <= 128) imtf_launch<2>(ctx, d_idx, N, sigma, perms, chunks, tab, d_out);
     else imtf_launch<5>(ctx, d_idx, N, sigma, perms, chunks, tab, d_out);
 }
@@ -228,8 +271,12 @@ static void rle_decode_device(tc_ctx *ctx, Arena &A, const u32 *d_counts, const 
     u64 *len = A.get<u64>(nruns + 1);
     u64 *offs = A.get<u64>(nruns + 1);
     u64 *tsum = A.get<u64>(tiles + 2);
+    const u32 huge_cap = (u32)(cap / RLE_HUGE + 2);
+    HugeRun *huge = A.get<HugeRun>(huge_cap);
+    u32 *nhuge = A.get<u32>(4);
     if (dry) return;
     hipStream_t s = ctx->stream;
+    tc_memset_async(ctx, nhuge, 0, 4 * sizeof(u32));
     rle_len_kernel<SymT><<<tc_cdiv(nruns, 256), 256, 0, s>>>(d_counts, d_syms, nruns, has_nothing, len);
     TC_LAUNCH_CHECK(ctx);
     scan64_reduce_kernel<<<(u32)tiles, SCAN_NT, 0, s>>>(len, nruns, tsum);
@@ -243,7 +290,9 @@ static void rle_decode_device(tc_ctx *ctx, Arena &A, const u32 *d_counts, const 
     *N_out = ctx->h_scalars[7];
     if (*N_out > cap) return;  // caller reports TC_ERR_CAPACITY
     rle_fill_kernel<SymT><<<tc_cdiv(nruns, 256), 256, 0, s>>>(offs, d_counts, d_syms, nruns,
-                                                              has_nothing, cap, d_out);
+                                                              has_nothing, cap, d_out, huge, nhuge, huge_cap);
+    TC_LAUNCH_CHECK(ctx);
+    rle_fill_huge_kernel<SymT><<<tc_persistent_grid(ctx, 4), 256, 0, s>>>(huge, nhuge, huge_cap, cap, d_out);
     TC_LAUNCH_CHECK(ctx);
 }
 

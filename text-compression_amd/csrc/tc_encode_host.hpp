@@ -461,9 +461,32 @@ static void mtf_general_launch(tc_ctx *ctx, Acc acc, u64 N, const Lut16 &lut, u1
     hipStream_t s = ctx->stream;
     mtf_gen_summary_kernel<Acc, ROWS><<<chunks, 64, 0, s>>>(acc, N, lut, lists, seen);
     TC_LAUNCH_CHECK(ctx);
-    mtf_gen_scan_kernel<ROWS><<<1, 64, 0, s>>>(lists, seen, chunks);
+    mtf_gen_scan_kernel<ROWS><<<1, 64 * MTFG_SCAN_WAVES, 0, s>>>(lists, seen, chunks);
     TC_LAUNCH_CHECK(ctx);
     mtf_gen_apply_kernel<Acc, ROWS><<<chunks, 64, 0, s>>>(acc, N, lut, lists, d_idx);
+    TC_LAUNCH_CHECK(ctx);
+}
+
+// sigma <= 256: one chunk per lane (tc_mtf.hpp, "general path, lane chunks")
+template <class Acc, int ROWS>
+static void mtf_lane_launch(tc_ctx *ctx, Acc acc, u64 N, const Alphabet &al, u16 *lists, u32 *seen,
+                            u16 *d_idx) {
+    hipStream_t s = ctx->stream;
+    GmArgs a;
+    a.N = N; a.sigma = al.sigma; a.ls = ((al.sigma + 3) / 4) | 1u;
+    for (int v = 0; v < 257; v++) a.lut.v[v] = (u8)al.code_of_sym[v];
+    a.lists = lists; a.seen = seen; a.idx = d_idx;
+    const u32 tiles = tc_cdiv(N, GM_TILE);
+    const size_t lds = gm_lds_bytes(a.ls);
+    TC_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(mtf_gm_kernel<Acc, ROWS, false>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    TC_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(mtf_gm_kernel<Acc, ROWS, true>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    mtf_gm_kernel<Acc, ROWS, false><<<tiles, GM_NT, lds, s>>>(acc, a);
+    TC_LAUNCH_CHECK(ctx);
+    mtf_gen_scan_kernel<ROWS><<<1, 64 * MTFG_SCAN_WAVES, 0, s>>>(lists, seen, tiles);
+    TC_LAUNCH_CHECK(ctx);
+    mtf_gm_kernel<Acc, ROWS, true><<<tiles, GM_NT, lds, s>>>(acc, a);
     TC_LAUNCH_CHECK(ctx);
 }
 
@@ -521,12 +544,24 @@ static void mtf_encode_device(tc_ctx *ctx, Arena &A, Acc acc, u64 N, const u32 *
     } else {
         Lut16 lut;
         for (int v = 0; v < 257; v++) lut.v[v] = al.code_of_sym[v];
-        int rows = al.sigma <= 64 ? 1 : (al.sigma <= 128 ? 2 : 5);
-        if (rows == 1) mtf_general_launch<Acc, 1>(ctx, acc, N, lut, lists, seen, chunks, d_idx);
-        else if (rows == 2) mtf_general_launch<Acc, 2>(ctx, acc, N, lut, lists, seen, chunks, d_idx);
-        else mtf_general_launch<Acc, 5>(ctx, acc, N, lut, lists, seen, chunks, d_idx);
+        int rows;
+        u32 last;  // slot of the final list
+        if (al.sigma <= 256 && env_int("TC_MTF_WAVE_CHUNKS", 0) == 0) {
+            rows = (int)((al.sigma + 63) / 64);
+            last = tc_cdiv(N, GM_TILE);
+            if (rows == 1) mtf_lane_launch<Acc, 1>(ctx, acc, N, al, lists, seen, d_idx);
+            else if (rows == 2) mtf_lane_launch<Acc, 2>(ctx, acc, N, al, lists, seen, d_idx);
+            else if (rows == 3) mtf_lane_launch<Acc, 3>(ctx, acc, N, al, lists, seen, d_idx);
+            else mtf_lane_launch<Acc, 4>(ctx, acc, N, al, lists, seen, d_idx);
+        } else {  // sigma = 257 (nine-bit codes): one chunk per wave
+            rows = al.sigma <= 64 ? 1 : (al.sigma <= 128 ? 2 : 5);
+            last = chunks;
+            if (rows == 1) mtf_general_launch<Acc, 1>(ctx, acc, N, lut, lists, seen, chunks, d_idx);
+            else if (rows == 2) mtf_general_launch<Acc, 2>(ctx, acc, N, lut, lists, seen, chunks, d_idx);
+            else mtf_general_launch<Acc, 5>(ctx, acc, N, lut, lists, seen, chunks, d_idx);
+        }
         std::vector<u16> fl(rows * 64);
-        tc_d2h(ctx, fl.data(), lists + (size_t)chunks * (rows * 64), fl.size() * sizeof(u16));
+        tc_d2h(ctx, fl.data(), lists + (size_t)last * (rows * 64), fl.size() * sizeof(u16));
         TC_HIP(ctx, hipStreamSynchronize(s));
         for (u32 i = 0; i < al.sigma; i++) final_list[i] = al.sym_of_code[fl[i]];
     }

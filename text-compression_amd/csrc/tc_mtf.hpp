@@ -487,24 +487,90 @@ __global__ __launch_bounds__(64) void mtf_gen_summary_kernel(Acc acc, u64 N,
     if (lane_id() == 0) seen[blockIdx.x] = nseen;
 }
 
-// single wave: incoming[c] = list before chunk c; lists[c] is overwritten with it.
-// tail slot `chunks` receives the final list.
+__device__ __forceinline__ void wave_fence() {
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+}
+
+// S := "S then B" for list states held across the lanes of a wave.  B is a summary: its first
+// Bd entries are the distinct codes it saw, most recent first.  The result is B's recency list
+// followed by the entries of S that B did not see, in S's order (one ballot-compaction per
+// row instead of Bd sequential move-to-front steps).  Sd counts the leading "seen" entries of
+// S (S itself a summary from the identity list); it is maintained for callers that need it.
+// inB: zeroed byte table indexed by code (left zeroed); newl: scratch list.
+template <int ROWS, class LT>
+__device__ __forceinline__ void wl_compose(WaveList<ROWS> &S, u32 &Sd, const WaveList<ROWS> &B, u32 Bd,
+                                           u32 nvalid, u8 *inB, LT *newl) {
+    if (Bd == 0) return;
+    const u32 lane = lane_id();
+#pragma unroll
+    for (int r = 0; r < ROWS; r++)
+        if (r * 64 + lane < Bd) inB[B.row[r]] = 1;
+    wave_fence();
+    u32 off = Bd, kept = 0;
+#pragma unroll
+    for (int r = 0; r < ROWS; r++) {
+        const u32 q = r * 64 + lane, v = S.row[r];
+        const bool keep = q < nvalid && inB[v] == 0;
+        const u64 m = __ballot(keep);
+        if (keep) newl[off + __popcll(m & lanemask_lt())] = (LT)v;
+        kept += (u32)__popcll(__ballot(keep && q < Sd));
+        off += (u32)__popcll(m);
+        if (q < Bd) newl[q] = (LT)B.row[r];
+    }
+    wave_fence();
+#pragma unroll
+    for (int r = 0; r < ROWS; r++) {
+        const u32 q = r * 64 + lane;
+        if (q < nvalid) S.row[r] = newl[q];
+        if (q < Bd) inB[B.row[r]] = 0;
+    }
+    wave_fence();
+    Sd = Bd + kept;
+}
+
+// Exclusive scan of the chunk summaries, in place: lists[c] := list before chunk c; slot `chunks`
+// receives the final list.  One block of MTFG_SCAN_WAVES waves: every wave folds a contiguous
+// segment of chunks, the segment aggregates are folded, then every wave replays its segment
+// from its true incoming list.
+#define MTFG_SCAN_WAVES 16
 template <int ROWS>
-__global__ __launch_bounds__(64) void mtf_gen_scan_kernel(u16 *lists, const u32 *seen, u32 chunks) {
-    WaveList<ROWS> st;
+__global__ __launch_bounds__(64 * MTFG_SCAN_WAVES) void mtf_gen_scan_kernel(u16 *lists, const u32 *seen,
+                                                                           u32 chunks) {
+    constexpr int LW = ROWS * 64;
+    __shared__ u8 s_in[MTFG_SCAN_WAVES][LW];
+    __shared__ u16 s_new[MTFG_SCAN_WAVES][LW];
+    __shared__ u16 s_agg[MTFG_SCAN_WAVES][LW];
+    __shared__ u32 s_aggd[MTFG_SCAN_WAVES];
+    const u32 w = threadIdx.x >> 6, lane = lane_id();
+    const u32 per = (chunks + MTFG_SCAN_WAVES - 1) / MTFG_SCAN_WAVES;
+    const u32 lo = w * per < chunks ? w * per : chunks;
+    const u32 hi = lo + per < chunks ? lo + per : chunks;
+    for (int i = lane; i < LW; i += 64) s_in[w][i] = 0;
+    wave_fence();
+    WaveList<ROWS> st, rec;
+    u32 sd = 0;
     st.init_identity();
-    for (u32 c = 0; c < chunks; c++) {
-        u16 *lp = lists + (u64)c * (ROWS * 64);
-        WaveList<ROWS> rec;
+    for (u32 c = lo; c < hi; c++) {
+        rec.load(lists + (u64)c * LW);
+        wl_compose<ROWS, u16>(st, sd, rec, seen[c], LW, s_in[w], s_new[w]);
+    }
+    st.store(s_agg[w]);
+    if (lane == 0) s_aggd[w] = sd;
+    __syncthreads();
+    st.init_identity();
+    sd = 0;
+    for (u32 v = 0; v < w; v++) {
+        rec.load(s_agg[v]);
+        wl_compose<ROWS, u16>(st, sd, rec, s_aggd[v], LW, s_in[w], s_new[w]);
+    }
+    for (u32 c = lo; c < hi; c++) {
+        u16 *lp = lists + (u64)c * LW;
         rec.load(lp);
         st.store(lp);
-        u32 d = seen[c];
-        for (int i = (int)d - 1; i >= 0; i--) {
-            u32 code = __shfl(rec.row[i >> 6], i & 63, 64);
-            (void)st.step(code);
-        }
+        wl_compose<ROWS, u16>(st, sd, rec, seen[c], LW, s_in[w], s_new[w]);
     }
-    st.store(lists + (u64)chunks * (ROWS * 64));
+    if (w == MTFG_SCAN_WAVES - 1) st.store(lists + (u64)chunks * LW);
 }
 
 template <class Acc, int ROWS>
@@ -526,6 +592,241 @@ __global__ __launch_bounds__(64) void mtf_gen_apply_kernel(Acc acc, u64 N,
             if (lane_id() == t) out = pos;
         }
         if (j < N) idx[j] = (u16)out;
+    }
+}
+
+// ---- general path, lane chunks (sigma <= 256: byte codes) -------------------------------
+// One chunk of GM_CH symbols per LANE (64 independent sequential chains per wave instead of
+// one): the lane's list is a byte array in LDS, four codes per dword; a step scans dwords from
+// the front (SWAR zero-byte test), shifting them up by one byte as it goes -- cost ~ rank / 4,
+// and BWT output keeps ranks small.  Pass 1 runs every chunk from the identity list (summary);
+// a wave then folds its 64 lane summaries in order (wl_compose), which yields the wave / tile
+// aggregate (summary kernel) or, restarted from the true incoming list, every lane's incoming
+// list in place (apply kernel); pass 2 replays the chunk from it and the ranks overwrite the
+// codes.  Tile summaries are scanned by mtf_gen_scan_kernel in between.
+#define GM_NT 256
+#define GM_CH 128
+#define GM_TILE (GM_NT * GM_CH)   // 32768
+#define GM_STRIDE (GM_CH + 4)     // 33 dwords: conflict-free across lanes
+
+struct GmArgs {
+    u64 N;
+    u32 sigma;
+    u32 ls;      // lane list stride in dwords (odd, >= ceil(sigma / 4))
+    Lut8 lut;
+    u16 *lists;  // [tiles + 1][ROWS * 64]
+    u32 *seen;   // [tiles]
+    u16 *idx;
+};
+static inline size_t gm_lds_bytes(u32 ls) {
+    return (size_t)GM_NT * GM_STRIDE + (size_t)GM_NT * ls * 4 + 272 + 3 * 4 * 256 + 64;
+}
+
+template <class Acc>
+__device__ __forceinline__ void gm_stage(Acc acc, u64 N, u64 base, const u8 *s_lut, u8 *s_code) {
+    for (u32 p = threadIdx.x; p < GM_TILE; p += GM_NT) {
+        u64 j = base + p;
+        s_code[(p / GM_CH) * GM_STRIDE + (p % GM_CH)] = j < N ? s_lut[acc(j) + 1] : (u8)0;
+    }
+}
+template <>
+__device__ __forceinline__ void gm_stage<BwtAcc>(BwtAcc acc, u64 N, u64 base, const u8 *s_lut, u8 *s_code) {
+    const u8 *src = acc.L + base;
+    if ((((uintptr_t)src) & 15) == 0) {
+        for (u32 c = threadIdx.x; c < GM_TILE / 16; c += GM_NT) {
+            const u32 p0 = c * 16;
+            const u64 j0 = base + p0;
+            u32 out[4] = {0, 0, 0, 0};
+            if (j0 + 16 <= N) {
+                uint4 v = *reinterpret_cast<const uint4 *>(src + p0);
+                u32 x[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+                for (int q = 0; q < 4; q++)
+                    out[q] = (u32)s_lut[(x[q] & 255) + 1] | ((u32)s_lut[((x[q] >> 8) & 255) + 1] << 8) |
+                             ((u32)s_lut[((x[q] >> 16) & 255) + 1] << 16) | ((u32)s_lut[(x[q] >> 24) + 1] << 24);
+            } else {
+                for (int q = 0; q < 16; q++)
+                    if (j0 + q < N) out[q >> 2] |= (u32)s_lut[(u32)src[p0 + q] + 1] << (8 * (q & 3));
+            }
+            u32 *dst = reinterpret_cast<u32 *>(s_code + (p0 / GM_CH) * GM_STRIDE + (p0 % GM_CH));
+            dst[0] = out[0]; dst[1] = out[1]; dst[2] = out[2]; dst[3] = out[3];
+        }
+    } else {
+        for (u32 p = threadIdx.x; p < GM_TILE; p += GM_NT) {
+            u64 j = base + p;
+            s_code[(p / GM_CH) * GM_STRIDE + (p % GM_CH)] = j < N ? s_lut[(u32)src[p] + 1] : (u8)0;
+        }
+    }
+    if (acc.primary >= (i64)base && acc.primary < (i64)(base + GM_TILE)) {
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            u32 p = (u32)(acc.primary - (i64)base);
+            s_code[(p / GM_CH) * GM_STRIDE + (p % GM_CH)] = s_lut[0];
+        }
+    }
+}
+
+// move code c to the front of this lane's dword-packed list; returns its rank
+__device__ __forceinline__ u32 gm_step(u32 *lst, u32 c, u32 ls) {
+    u32 w = lst[0];
+    if ((w & 0xffu) == c) return 0;
+    const u32 cc = c * 0x01010101u;
+    u32 carry = c, d = 0;
+    while (true) {
+        const u32 x = w ^ cc;
+        const u32 z = (x - 0x01010101u) & ~x & 0x80808080u;
+        if (z) {
+            const u32 k = (u32)__builtin_ctz(z) >> 3;
+            const u32 sh = (w << 8) | carry;
+            const u32 keep = k == 3 ? 0u : (0xFFFFFFFFu << (8 * (k + 1)));
+            lst[d] = (w & keep) | (sh & ~keep);
+            return 4 * d + k;
+        }
+        lst[d] = (w << 8) | carry;
+        carry = w >> 24;
+        if (++d >= ls) return 0;  // unreachable for codes < sigma
+        w = lst[d];
+    }
+}
+
+// fold the 64 lane summaries of this wave into S in lane order; WRITE_IN: lane l's list is
+// replaced by the state before it (its incoming list)
+template <int ROWS, bool WRITE_IN>
+__device__ __forceinline__ void gm_wave_pass(WaveList<ROWS> &S, u32 &Sd, u8 *wave_lists, u32 ls, u32 d_mine,
+                                             u32 sigma, u8 *inB, u8 *newl) {
+    const u32 lane = lane_id();
+    for (u32 l = 0; l < 64; l++) {
+        const u32 Bd = __shfl(d_mine, l, 64);
+        u8 *ll = wave_lists + (size_t)l * ls * 4;
+        WaveList<ROWS> B;
+#pragma unroll
+        for (int r = 0; r < ROWS; r++) {
+            const u32 q = r * 64 + lane;
+            B.row[r] = q < sigma ? (u32)ll[q] : 0xFFFFu;
+        }
+        if (WRITE_IN) {
+#pragma unroll
+            for (int r = 0; r < ROWS; r++) {
+                const u32 q = r * 64 + lane;
+                if (q < sigma) ll[q] = (u8)S.row[r];
+            }
+        }
+        wl_compose<ROWS, u8>(S, Sd, B, Bd, sigma, inB, newl);
+    }
+}
+
+template <class Acc, int ROWS, bool APPLY>
+__global__ __launch_bounds__(GM_NT) void mtf_gm_kernel(Acc acc, GmArgs a) {
+    extern __shared__ __attribute__((aligned(16))) u8 gm_smem[];
+    u8 *s_code = gm_smem;
+    u32 *s_list = reinterpret_cast<u32 *>(gm_smem + GM_NT * GM_STRIDE);
+    u8 *s_lut = reinterpret_cast<u8 *>(s_list + (size_t)GM_NT * a.ls);
+    u8 *s_in = s_lut + 272;
+    u8 *s_new = s_in + 4 * 256;
+    u8 *s_wagg = s_new + 4 * 256;
+    u32 *s_wd = reinterpret_cast<u32 *>(s_wagg + 4 * 256);
+    const u32 tid = threadIdx.x, lane = lane_id(), w = tid >> 6;
+    const u32 sigma = a.sigma, ls = a.ls;
+    constexpr int LW = ROWS * 64;
+    const u64 base = (u64)blockIdx.x * GM_TILE;
+    for (int i = tid; i < 257; i += GM_NT) s_lut[i] = a.lut.v[i];
+    for (int i = tid; i < 4 * 256; i += GM_NT) s_in[i] = 0;
+    __syncthreads();
+    gm_stage(acc, a.N, base, s_lut, s_code);
+    __syncthreads();
+
+    // pass 1: this lane's chunk from the identity list
+    u32 *lst = s_list + (size_t)tid * ls;
+    const u64 cbase = base + (u64)tid * GM_CH;
+    const u32 nvalid = cbase >= a.N ? 0u : (a.N - cbase >= GM_CH ? (u32)GM_CH : (u32)(a.N - cbase));
+    u32 *cw = reinterpret_cast<u32 *>(s_code + (size_t)tid * GM_STRIDE);
+    for (u32 d = 0; d < ls; d++) {
+        u32 v = 0;
+#pragma unroll
+        for (int b = 0; b < 4; b++) {
+            const u32 q = 4 * d + b;
+            v |= (q < sigma ? q : 0xFFu) << (8 * b);
+        }
+        lst[d] = v;
+    }
+    u32 nseen = 0;
+    for (u32 q4 = 0; q4 < GM_CH / 4; q4++) {
+        const u32 wv = cw[q4];
+#pragma unroll
+        for (int b = 0; b < 4; b++) {
+            if (4 * q4 + b < nvalid) {
+                const u32 r = gm_step(lst, (wv >> (8 * b)) & 0xffu, ls);
+                if (r >= nseen) nseen++;
+            }
+        }
+    }
+    wave_fence();
+    u8 *wave_lists = reinterpret_cast<u8 *>(s_list + (size_t)(w * 64) * ls);
+    WaveList<ROWS> S;
+    u32 Sd = 0;
+    S.init_identity();
+    gm_wave_pass<ROWS, false>(S, Sd, wave_lists, ls, nseen, sigma, s_in + w * 256, s_new + w * 256);
+#pragma unroll
+    for (int r = 0; r < ROWS; r++)
+        if (r * 64 + lane < 256) s_wagg[w * 256 + r * 64 + lane] = (u8)S.row[r];
+    if (lane == 0) s_wd[w] = Sd;
+    __syncthreads();
+
+    if (!APPLY) {
+        if (w == 0) {
+            WaveList<ROWS> T, B;
+            u32 Td = 0;
+            T.init_identity();
+            for (u32 v = 0; v < GM_NT / 64; v++) {
+#pragma unroll
+                for (int r = 0; r < ROWS; r++) B.row[r] = s_wagg[v * 256 + ((r * 64 + lane) & 255)];
+                wl_compose<ROWS, u8>(T, Td, B, s_wd[v], sigma, s_in, s_new);
+            }
+            T.store(a.lists + (u64)blockIdx.x * LW);
+            if (lane == 0) a.seen[blockIdx.x] = Td;
+        }
+        return;
+    }
+    // true incoming list of this wave: the tile's, then the waves before it
+    WaveList<ROWS> B;
+    S.load(a.lists + (u64)blockIdx.x * LW);
+    Sd = 0;
+    for (u32 v = 0; v < w; v++) {
+#pragma unroll
+        for (int r = 0; r < ROWS; r++) B.row[r] = s_wagg[v * 256 + ((r * 64 + lane) & 255)];
+        wl_compose<ROWS, u8>(S, Sd, B, s_wd[v], sigma, s_in + w * 256, s_new + w * 256);
+    }
+    gm_wave_pass<ROWS, true>(S, Sd, wave_lists, ls, nseen, sigma, s_in + w * 256, s_new + w * 256);
+    wave_fence();
+    // pass 2: replay from the true incoming list; ranks overwrite the codes
+    for (u32 q4 = 0; q4 < GM_CH / 4; q4++) {
+        const u32 wv = cw[q4];
+        u32 ov = 0;
+#pragma unroll
+        for (int b = 0; b < 4; b++) {
+            if (4 * q4 + b < nvalid) ov |= gm_step(lst, (wv >> (8 * b)) & 0xffu, ls) << (8 * b);
+        }
+        cw[q4] = ov;
+    }
+    __syncthreads();
+    if ((((uintptr_t)(a.idx + base)) & 15) == 0) {
+        uint4 *o = reinterpret_cast<uint4 *>(a.idx + base);
+        for (u32 g = tid; g < GM_TILE / 8; g += GM_NT) {
+            const u32 p = 8 * g;
+            const u32 *sc = reinterpret_cast<const u32 *>(s_code + (p / GM_CH) * GM_STRIDE + (p % GM_CH));
+            if (base + p + 8 <= a.N) {
+                const u32 lo = sc[0], hi = sc[1];
+                o[g] = make_uint4((lo & 0xffu) | ((lo & 0xff00u) << 8), ((lo >> 16) & 0xffu) | ((lo >> 24) << 16),
+                                  (hi & 0xffu) | ((hi & 0xff00u) << 8), ((hi >> 16) & 0xffu) | ((hi >> 24) << 16));
+            } else {
+                const u8 *sb = reinterpret_cast<const u8 *>(sc);
+                for (u32 q = 0; q < 8; q++)
+                    if (base + p + q < a.N) a.idx[base + p + q] = (u16)sb[q];
+            }
+        }
+    } else {
+        for (u32 p = tid; p < GM_TILE; p += GM_NT)
+            if (base + p < a.N) a.idx[base + p] = (u16)s_code[(p / GM_CH) * GM_STRIDE + (p % GM_CH)];
     }
 }
 
@@ -576,23 +877,50 @@ __global__ __launch_bounds__(64) void imtf_summary_kernel(const u16 *__restrict_
     wl.store(perms + (u64)blockIdx.x * (ROWS * 64));
 }
 
-// single wave: state[c] = list (of codes) before chunk c; compose with chunk perms.
+// S[q] := S[P[q]] for lists held across the lanes of a wave (scratch: LW entries of LDS)
+template <int ROWS, class LT>
+__device__ __forceinline__ void wl_gather(WaveList<ROWS> &S, const WaveList<ROWS> &P, u32 nvalid, LT *scratch) {
+    const u32 lane = lane_id();
+#pragma unroll
+    for (int r = 0; r < ROWS; r++)
+        if (r * 64 + lane < nvalid) scratch[r * 64 + lane] = (LT)S.row[r];
+    wave_fence();
+#pragma unroll
+    for (int r = 0; r < ROWS; r++)
+        if (r * 64 + lane < nvalid) S.row[r] = scratch[P.row[r] < nvalid ? P.row[r] : 0];
+    wave_fence();
+}
+
+// Exclusive scan over the chunk permutations, in place: perms[c] := list (of codes) before chunk
+// c.  One block of MTFG_SCAN_WAVES waves: fold a contiguous segment each (perm composition),
+// fold the segment aggregates, replay every segment from its true incoming list.
 template <int ROWS>
-__global__ __launch_bounds__(64) void imtf_scan_kernel(u16 *perms, u32 chunks) {
-    __shared__ u16 s_list[ROWS * 64];
-    WaveList<ROWS> st;
+__global__ __launch_bounds__(64 * MTFG_SCAN_WAVES) void imtf_scan_kernel(u16 *perms, u32 chunks) {
+    constexpr int LW = ROWS * 64;
+    __shared__ u16 s_tmp[MTFG_SCAN_WAVES][LW];
+    __shared__ u16 s_agg[MTFG_SCAN_WAVES][LW];
+    const u32 w = threadIdx.x >> 6;
+    const u32 per = (chunks + MTFG_SCAN_WAVES - 1) / MTFG_SCAN_WAVES;
+    const u32 lo = w * per < chunks ? w * per : chunks;
+    const u32 hi = lo + per < chunks ? lo + per : chunks;
+    WaveList<ROWS> st, pm;
     st.init_identity();
-    for (u32 c = 0; c < chunks; c++) {
-        u16 *pp = perms + (u64)c * (ROWS * 64);
-        WaveList<ROWS> pm;
+    for (u32 c = lo; c < hi; c++) {
+        pm.load(perms + (u64)c * LW);
+        wl_gather<ROWS, u16>(st, pm, LW, s_tmp[w]);
+    }
+    st.store(s_agg[w]);
+    __syncthreads();
+    st.init_identity();
+    for (u32 v = 0; v < w; v++) {
+        pm.load(s_agg[v]);
+        wl_gather<ROWS, u16>(st, pm, LW, s_tmp[w]);
+    }
+    for (u32 c = lo; c < hi; c++) {
+        u16 *pp = perms + (u64)c * LW;
         pm.load(pp);
         st.store(pp);
-        // new_state[q] = state[pm[q]]
-        st.store(s_list);
-        __builtin_amdgcn_wave_barrier();
-#pragma unroll
-        for (int r = 0; r < ROWS; r++) st.row[r] = s_list[pm.row[r]];
-        __builtin_amdgcn_wave_barrier();
+        wl_gather<ROWS, u16>(st, pm, LW, s_tmp[w]);
     }
 }
 
@@ -617,6 +945,191 @@ __global__ __launch_bounds__(64) void imtf_apply_kernel(const u16 *__restrict__ 
             if (lane_id() == t) res = c;
         }
         if (j < N) out[j] = sym_of_code.v[res];
+    }
+}
+
+// ---- inverse MTF, lane chunks (sigma <= 256) -------------------------------------------
+// Same organisation as mtf_gm_kernel.  A chunk's effect on the list is a permutation of list
+// POSITIONS (new[q] = old[P[q]]), obtained by running the chunk on the identity; permutations
+// compose by a gather, so a wave folds its 64 lane permutations with one LDS round trip each.
+struct GmiArgs {
+    u64 N;
+    u32 sigma;
+    u32 ls;
+    const u16 *idx;
+    u16 *perms;  // [tiles + 1][ROWS * 64]
+    SymTab tab;
+    i16 *out;
+    u32 *err;
+};
+
+// move the entry at position pos of this lane's dword-packed list to the front; returns it
+__device__ __forceinline__ u32 gmi_step(u32 *lst, u32 pos) {
+    const u32 D = pos >> 2, k = pos & 3u;
+    const u32 wD = lst[D];
+    const u32 c = (wD >> (8 * k)) & 0xffu;
+    if (pos == 0) return c;
+    u32 carry = c;
+    for (u32 d = 0; d < D; d++) {
+        const u32 w = lst[d];
+        lst[d] = (w << 8) | carry;
+        carry = w >> 24;
+    }
+    const u32 sh = (wD << 8) | carry;
+    const u32 keep = k == 3 ? 0u : (0xFFFFFFFFu << (8 * (k + 1)));
+    lst[D] = (wD & keep) | (sh & ~keep);
+    return c;
+}
+
+template <int ROWS, bool WRITE_IN>
+__device__ __forceinline__ void gmi_wave_pass(WaveList<ROWS> &S, u8 *wave_lists, u32 ls, u32 sigma, u8 *scratch) {
+    const u32 lane = lane_id();
+    for (u32 l = 0; l < 64; l++) {
+        u8 *ll = wave_lists + (size_t)l * ls * 4;
+        WaveList<ROWS> P;
+#pragma unroll
+        for (int r = 0; r < ROWS; r++) {
+            const u32 q = r * 64 + lane;
+            P.row[r] = q < sigma ? (u32)ll[q] : 0u;
+        }
+        if (WRITE_IN) {
+#pragma unroll
+            for (int r = 0; r < ROWS; r++) {
+                const u32 q = r * 64 + lane;
+                if (q < sigma) ll[q] = (u8)S.row[r];
+            }
+        }
+        wl_gather<ROWS, u8>(S, P, sigma, scratch);
+    }
+}
+
+template <int ROWS, bool APPLY>
+__global__ __launch_bounds__(GM_NT) void imtf_gm_kernel(GmiArgs a) {
+    extern __shared__ __attribute__((aligned(16))) u8 gm_smem[];
+    u8 *s_code = gm_smem;
+    u32 *s_list = reinterpret_cast<u32 *>(gm_smem + GM_NT * GM_STRIDE);
+    i16 *s_tab = reinterpret_cast<i16 *>(s_list + (size_t)GM_NT * a.ls);   // 256 entries
+    u8 *s_tmp = reinterpret_cast<u8 *>(s_tab + 256);                      // 4 x 256
+    u8 *s_wagg = s_tmp + 4 * 256;                                         // 4 x 256
+    const u32 tid = threadIdx.x, lane = lane_id(), w = tid >> 6;
+    const u32 sigma = a.sigma, ls = a.ls;
+    constexpr int LW = ROWS * 64;
+    const u64 base = (u64)blockIdx.x * GM_TILE;
+    if (APPLY) s_tab[tid] = a.tab.v[tid];
+    // stage the indices as bytes (an index >= sigma is DS.index out of range: flagged, read as 0)
+    {
+        const u16 *src = a.idx + base;
+        bool bad = false;
+        if ((((uintptr_t)src) & 15) == 0) {
+            for (u32 g = tid; g < GM_TILE / 8; g += GM_NT) {
+                const u32 p = 8 * g;
+                u32 v[8];
+                if (base + p + 8 <= a.N) {
+                    const uint4 t = *reinterpret_cast<const uint4 *>(src + p);
+                    v[0] = t.x & 0xffffu; v[1] = t.x >> 16; v[2] = t.y & 0xffffu; v[3] = t.y >> 16;
+                    v[4] = t.z & 0xffffu; v[5] = t.z >> 16; v[6] = t.w & 0xffffu; v[7] = t.w >> 16;
+                } else {
+#pragma unroll
+                    for (int q = 0; q < 8; q++) v[q] = base + p + q < a.N ? (u32)src[p + q] : 0u;
+                }
+#pragma unroll
+                for (int q = 0; q < 8; q++)
+                    if (v[q] >= sigma) { bad = true; v[q] = 0; }
+                u32 *dst = reinterpret_cast<u32 *>(s_code + (p / GM_CH) * GM_STRIDE + (p % GM_CH));
+                dst[0] = v[0] | (v[1] << 8) | (v[2] << 16) | (v[3] << 24);
+                dst[1] = v[4] | (v[5] << 8) | (v[6] << 16) | (v[7] << 24);
+            }
+        } else {
+            for (u32 p = tid; p < GM_TILE; p += GM_NT) {
+                u32 v = base + p < a.N ? (u32)src[p] : 0u;
+                if (v >= sigma) { bad = true; v = 0; }
+                s_code[(p / GM_CH) * GM_STRIDE + (p % GM_CH)] = (u8)v;
+            }
+        }
+        if (bad) atomicOr(a.err, 0x100u);
+    }
+    __syncthreads();
+
+    u32 *lst = s_list + (size_t)tid * ls;
+    const u64 cbase = base + (u64)tid * GM_CH;
+    const u32 nvalid = cbase >= a.N ? 0u : (a.N - cbase >= GM_CH ? (u32)GM_CH : (u32)(a.N - cbase));
+    u32 *cw = reinterpret_cast<u32 *>(s_code + (size_t)tid * GM_STRIDE);
+    for (u32 d = 0; d < ls; d++) {
+        u32 v = 0;
+#pragma unroll
+        for (int b = 0; b < 4; b++) {
+            const u32 q = 4 * d + b;
+            v |= (q < sigma ? q : 0xFFu) << (8 * b);
+        }
+        lst[d] = v;
+    }
+    // pass 1: the chunk's position permutation
+    for (u32 q4 = 0; q4 < GM_CH / 4; q4++) {
+        const u32 wv = cw[q4];
+#pragma unroll
+        for (int b = 0; b < 4; b++)
+            if (4 * q4 + b < nvalid) (void)gmi_step(lst, (wv >> (8 * b)) & 0xffu);
+    }
+    wave_fence();
+    u8 *wave_lists = reinterpret_cast<u8 *>(s_list + (size_t)(w * 64) * ls);
+    WaveList<ROWS> S, P;
+    S.init_identity();
+    gmi_wave_pass<ROWS, false>(S, wave_lists, ls, sigma, s_tmp + w * 256);
+#pragma unroll
+    for (int r = 0; r < ROWS; r++)
+        if (r * 64 + lane < 256) s_wagg[w * 256 + r * 64 + lane] = (u8)S.row[r];
+    __syncthreads();
+
+    if (!APPLY) {
+        if (w == 0) {
+            WaveList<ROWS> T;
+            T.init_identity();
+            for (u32 v = 0; v < GM_NT / 64; v++) {
+#pragma unroll
+                for (int r = 0; r < ROWS; r++) P.row[r] = s_wagg[v * 256 + ((r * 64 + lane) & 255)];
+                wl_gather<ROWS, u8>(T, P, sigma, s_tmp);
+            }
+            T.store(a.perms + (u64)blockIdx.x * LW);
+        }
+        return;
+    }
+    S.load(a.perms + (u64)blockIdx.x * LW);  // list of codes before this tile
+    for (u32 v = 0; v < w; v++) {
+#pragma unroll
+        for (int r = 0; r < ROWS; r++) P.row[r] = s_wagg[v * 256 + ((r * 64 + lane) & 255)];
+        wl_gather<ROWS, u8>(S, P, sigma, s_tmp + w * 256);
+    }
+    gmi_wave_pass<ROWS, true>(S, wave_lists, ls, sigma, s_tmp + w * 256);
+    wave_fence();
+    // pass 2: replay from the true incoming list; codes overwrite the indices
+    for (u32 q4 = 0; q4 < GM_CH / 4; q4++) {
+        const u32 wv = cw[q4];
+        u32 ov = 0;
+#pragma unroll
+        for (int b = 0; b < 4; b++)
+            if (4 * q4 + b < nvalid) ov |= gmi_step(lst, (wv >> (8 * b)) & 0xffu) << (8 * b);
+        cw[q4] = ov;
+    }
+    __syncthreads();
+    if ((((uintptr_t)(a.out + base)) & 15) == 0) {
+        uint4 *o = reinterpret_cast<uint4 *>(a.out + base);
+        for (u32 g = tid; g < GM_TILE / 8; g += GM_NT) {
+            const u32 p = 8 * g;
+            const u8 *sb = s_code + (p / GM_CH) * GM_STRIDE + (p % GM_CH);
+            if (base + p + 8 <= a.N) {
+                u32 t[4];
+#pragma unroll
+                for (int q = 0; q < 4; q++)
+                    t[q] = (u32)(u16)s_tab[sb[2 * q]] | ((u32)(u16)s_tab[sb[2 * q + 1]] << 16);
+                o[g] = make_uint4(t[0], t[1], t[2], t[3]);
+            } else {
+                for (u32 q = 0; q < 8; q++)
+                    if (base + p + q < a.N) a.out[base + p + q] = s_tab[sb[q]];
+            }
+        }
+    } else {
+        for (u32 p = tid; p < GM_TILE; p += GM_NT)
+            if (base + p < a.N) a.out[base + p] = s_tab[s_code[(p / GM_CH) * GM_STRIDE + (p % GM_CH)]];
     }
 }
 

@@ -378,21 +378,26 @@ __global__ __launch_bounds__(SCAN_NT) void scan64_down_kernel(const u64 *__restr
     }
 }
 
-// one wave per run fills its slice (long runs are rare; short runs dominate on
-// iid data where a wave handles 64 runs at once instead)
+// one lane per run fills its slice; runs >= 32 are filled by the whole wave; runs >= RLE_HUGE are
+// queued and filled by the whole grid afterwards (a block of "AAAA..." is a handful of runs)
+#define RLE_HUGE 16384
+struct HugeRun {
+    u64 off, len;
+    u32 sym, pad;
+};
 template <class SymT>
 __global__ __launch_bounds__(256) void rle_fill_kernel(const u64 *__restrict__ offs,
                                                        const u32 *__restrict__ counts,
                                                        const SymT *__restrict__ syms, u64 nruns,
                                                        bool has_nothing, u64 cap,
-                                                       SymT *__restrict__ out) {
+                                                       SymT *__restrict__ out, HugeRun *huge, u32 *nhuge,
+                                                       u32 huge_cap) {
     u64 k = (u64)blockIdx.x * 256 + threadIdx.x;
     bool in = k < nruns;
     u64 o = in ? offs[k] : 0;
     SymT s = in ? syms[k] : (SymT)0;
     u64 len = 0;
     if (in) len = (has_nothing && s == (SymT)-1) ? 1ull : (u64)counts[k];
-    // short runs: each lane writes its own; long runs: the wave cooperates
     const u64 LONG = 32;
     if (in && len < LONG)
         for (u64 q = 0; q < len; q++)
@@ -403,8 +408,28 @@ __global__ __launch_bounds__(256) void rle_fill_kernel(const u64 *__restrict__ o
         longmask &= longmask - 1;
         u64 lo = __shfl(o, src, 64), ll = __shfl(len, src, 64);
         SymT ss = (SymT)__shfl((int)s, src, 64);
+        if (ll >= RLE_HUGE) {
+            if (lane_id() == 0) {
+                u32 slot = atomicAdd(nhuge, 1u);
+                if (slot < huge_cap) huge[slot] = HugeRun{lo, ll, (u32)(u16)ss, 0u};
+            }
+            continue;
+        }
         for (u64 q = lane_id(); q < ll; q += 64)
             if (lo + q < cap) out[lo + q] = ss;
+    }
+}
+template <class SymT>
+__global__ __launch_bounds__(256) void rle_fill_huge_kernel(const HugeRun *__restrict__ huge,
+                                                            const u32 *__restrict__ nhuge, u32 huge_cap,
+                                                            u64 cap, SymT *__restrict__ out) {
+    u32 n = *nhuge;
+    if (n > huge_cap) n = huge_cap;
+    for (u32 h = 0; h < n; h++) {
+        const HugeRun r = huge[h];
+        const SymT ss = (SymT)(u16)r.sym;
+        for (u64 q = (u64)blockIdx.x * 256 + threadIdx.x; q < r.len; q += (u64)gridDim.x * 256)
+            if (r.off + q < cap) out[r.off + q] = ss;
     }
 }
 
