@@ -38,7 +38,36 @@ def zipf_words(vocab=20000, a=1.1):
     word_of = torch.repeat_interleave(torch.arange(nw, device="cuda"), lens)[:n]
     pos = torch.arange(n, device="cuda") - starts[word_of]
     return torch.from_numpy(flat).cuda()[src0[word_of] + pos].contiguous()
+def genome_like():
+    # iid ACGT + interspersed repeats (300-bp family, 15% divergence), poly-A tracts, tandem repeats
+    t = rnd(4, 0)
+    lut = torch.tensor([65, 67, 71, 84], dtype=torch.uint8, device="cuda")
+    t = lut[t.long()]
+    rs = np.random.default_rng(11)
+    fam = torch.from_numpy(rs.choice(np.frombuffer(b"ACGT", np.uint8), 300)).cuda()
+    ncopy = n // 3000                                  # ~10% of the sequence
+    pos = torch.from_numpy(rs.integers(0, n - 400, ncopy)).cuda()
+    off = torch.arange(300, device="cuda")
+    dst = (pos[:, None] + off[None, :]).reshape(-1)
+    src = fam[off].repeat(ncopy)
+    mut = torch.rand(dst.numel(), generator=g, device="cuda") < 0.15
+    src = torch.where(mut, lut[torch.randint(0, 4, (dst.numel(),), generator=g, device="cuda")], src)
+    t[dst] = src
+    npoly = n // 20000
+    pos = torch.from_numpy(rs.integers(0, n - 100, npoly)).cuda()
+    ln = torch.from_numpy(rs.integers(15, 60, npoly)).cuda()
+    off = torch.arange(60, device="cuda")
+    msk = off[None, :] < ln[:, None]
+    dst = (pos[:, None] + off[None, :])[msk]
+    t[dst] = 65
+    ntr = n // 100000                                  # (CA)n microsatellites
+    pos = torch.from_numpy(rs.integers(0, n - 200, ntr)).cuda()
+    dst = (pos[:, None] + torch.arange(100, device="cuda")[None, :]).reshape(-1)
+    t[dst] = torch.tensor([67, 65], dtype=torch.uint8, device="cuda").repeat(50).repeat(ntr)
+    return t.contiguous()
 classes = {
+    "genome_like": genome_like,
+    "acgt4": lambda: torch.tensor([65, 67, 71, 84], dtype=torch.uint8, device="cuda")[rnd(4, 0).long()],
     "zipf_words": zipf_words,
     "acgtn": lambda: None,
     "ascii96": lambda: rnd(96, 32),

@@ -219,6 +219,46 @@ def test_finish_and_full_paths_agree(ctx, monkeypatch):
     assert ctx.suffix_array(rep).tolist() == O.suffix_array(rep).tolist()
 
 
+def _genome_like(seed, n, poly, copies, unit):
+    rng = np.random.default_rng(seed)
+    t = rng.choice(np.frombuffer(b"ACGT", np.uint8), n)
+    fam = rng.choice(np.frombuffer(b"ACGT", np.uint8), unit)
+    for p in rng.integers(0, n - unit, copies):
+        c = fam.copy()
+        mut = rng.random(unit) < 0.1
+        c[mut] = rng.choice(np.frombuffer(b"ACGT", np.uint8), int(mut.sum()))
+        t[p:p + unit] = c
+    for p in rng.integers(0, n - poly, 6):
+        t[p:p + rng.integers(poly // 2, poly)] = 65
+    p = int(rng.integers(0, n - 400))
+    t[p:p + 400] = np.frombuffer(b"CA" * 200, np.uint8)
+    return t.tobytes()
+
+
+@pytest.mark.parametrize("seed,n,poly,copies,unit", [(1, 200000, 500, 40, 120), (2, 70001, 300, 10, 300),
+                                                      (3, 300000, 2000, 200, 60), (4, 131072, 90, 5, 1000)])
+def test_oversize_buckets_become_tied_groups(ctx, seed, n, poly, copies, unit, monkeypatch):
+    """Repeats in otherwise random DNA make a few equal-prefix buckets longer than the finish pass
+    ranks in a wave: those buckets are emitted whole as tied groups and ordered by the doubling
+    rounds, the rest of the text stays on the fast path (no restart with all passes)."""
+    t = _genome_like(seed, n, poly, copies, unit)
+    exp = O.suffix_array(t).tolist()
+    assert ctx.suffix_array(t).tolist() == exp
+    st = ctx.stats()
+    assert st.finish_pass == 1 and st.rounds >= 2 and 0 < st.m[1] < (n + 1) // 8
+    monkeypatch.setenv("TC_SA_TIER2", "0")          # old behaviour: restart on the full path
+    assert ctx.suffix_array(t).tolist() == exp
+    assert ctx.stats().finish_pass == 0
+    monkeypatch.delenv("TC_SA_TIER2")
+    blk = ctx.encode(t)
+    assert ctx.decode(blk) == t
+    _, eprim, sym = _expect_bwt(t)
+    eidx, efl = O.mtf_encode_arr(sym)
+    ec, ev = O.rle_encode_u32_arr(eidx)
+    assert blk["primary"] == eprim
+    assert blk["run_count"].tolist() == ec.tolist() and blk["run_value"].tolist() == ev.tolist()
+
+
 def _pack_roundtrip(ctx, sigma, counts, vals):
     import ctypes as C
     import torch

@@ -270,6 +270,7 @@ static void sa_run(tc_ctx *ctx, SaBuffers &b, const u8 *d_text, u64 n, u32 *d_sa
     const u64 *tkeys = nullptr;
     int tkeys_shift = 0;
     u64 m = 0;
+    u64 h_start = cfg.h0;
     bool have_groups = false;
     tc_memset_async(ctx, ctx->d_scalars, 0, 16 * sizeof(u64));
 
@@ -295,14 +296,18 @@ static void sa_run(tc_ctx *ctx, SaBuffers &b, const u8 *d_text, u64 n, u32 *d_sa
             fa.sa_out = va; fa.L = d_L;
             fa.out_slot = b.act[0][0]; fa.out_idx = b.act[0][1]; fa.out_grp = b.act[0][2];
             fa.act_cap = (u32)N; fa.counters = counters;
+            fa.tier2 = env_int("TC_SA_TIER2", 1) != 0 ? 1 : 0;
             const u32 waves = tc_cdiv(N, 64 * FIN_WPW);
             finish_kernel<<<tc_cdiv(waves, FIN_NT / 64), FIN_NT, 0, s>>>(fa);
             TC_LAUNCH_CHECK(ctx);
             tc_d2h(ctx, &ctx->h_scalars[12], ctx->d_scalars + 12, sizeof(u64));
             TC_HIP(ctx, hipStreamSynchronize(s));
             const u32 fm = (u32)(ctx->h_scalars[12] & 0xffffffffu), over = (u32)(ctx->h_scalars[12] >> 32);
-            if (!over && fm <= b.sparse_cap - 1024) {
+            if (!(over & 1u) && fm <= b.sparse_cap - 1024) {
                 m = fm;
+                // whole buckets were emitted as tied groups: they share only the globally sorted
+                // symbols, so the doubling starts from those
+                if (over & 2u) h_start = (u64)(topbits / (int)cfg.w) * cfg.s;
                 have_groups = true;
                 tkeys = rb.keys;
                 tkeys_shift = 64 - topbits;
@@ -378,7 +383,8 @@ static void sa_run(tc_ctx *ctx, SaBuffers &b, const u8 *d_text, u64 n, u32 *d_sa
 
     // 6. prefix doubling on the tied suffixes
     int cur = 0;
-    u64 h = cfg.h0;
+    if (env_int("TC_SA_H_START", 0) > 0) h_start = (u64)env_int("TC_SA_H_START", 0);  // experiments: any h <= sorted depth is valid
+    u64 h = h_start;
     while (m > 0) {
         if (st.rounds >= TC_MAX_ROUNDS) TC_FAIL(ctx, TC_ERR_INTERNAL, "suffix sort did not converge");
         u32 mm = (u32)m;

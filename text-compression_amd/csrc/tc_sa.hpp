@@ -469,7 +469,10 @@ struct FinishArgs {
     u8 *L;
     u32 *out_slot, *out_idx, *out_grp;
     u32 act_cap;
-    u32 *counters;     // [0] active count, [1] oversize flag
+    u32 *counters;     // [0] active count, [1] bit 0: a bucket this kernel cannot handle (caller takes
+                       //     the full path), bit 1: members of oversize buckets were emitted as tied
+    int tier2;         // 1: a bucket too long for the window logic is emitted whole as ONE tied group
+                       //    (group = bucket start, members left in place) instead of raising bit 0
 };
 
 __global__ __launch_bounds__(FIN_NT) void finish_kernel(FinishArgs a) {
@@ -493,6 +496,9 @@ __global__ __launch_bounds__(FIN_NT) void finish_kernel(FinishArgs a) {
     }
     u64 tprev = ws0 > 0 ? (a.keys[ws0 - 1] >> a.tshift) : 0;  // wave-uniform
     bool hasprev = ws0 > 0;
+    // does the window before this one contain a bucket head?  (sorted keys: it does unless its 64
+    // keys and the key before them all share their top bits)
+    bool prev_head = ws0 < 65 || (a.keys[ws0 - 65] >> a.tshift) != tprev;
 
 #pragma unroll
     for (int win = 0; win < FIN_WPW; win++) {
@@ -515,12 +521,17 @@ __global__ __launch_bounds__(FIN_NT) void finish_kernel(FinishArgs a) {
         const int a0 = hbA ? __builtin_ctzll(hbA) : 64;
         const int b0 = hbB ? __builtin_ctzll(hbB) : 64;
         // the bucket running out of A must end inside B (a head in B, or the array ends there)
-        if (hbA && !hbB && (~inbB) == 0ull) {
-            // no head in a full B: the last bucket of A is longer than this kernel handles
-            if (l == 0) atomicOr(&a.counters[1], 1u);
-        }
-        const bool ownA = inA && l >= a0;
-        const bool ownB = inB && hbA && l < b0;
+        // no head in a full B: the last bucket of A is longer than the window logic handles
+        const bool lastOver = hbA && !hbB && (~inbB) == 0ull;
+        if (lastOver && !a.tier2 && l == 0) atomicOr(&a.counters[1], 1u);
+        const int lastHeadA0 = hbA ? 63 - __builtin_clzll(hbA) : 0;
+        // lanes before the first head continue a bucket from before this window: the previous
+        // window ranked them iff it holds that bucket's head and the bucket ends in here
+        const bool lead_ok = prev_head && (hbA != 0ull || (~inbA) != 0ull);
+        const bool ovLead = a.tier2 && inA && l < a0 && !lead_ok;
+        const bool ovLast = a.tier2 && lastOver && inA && l >= lastHeadA0;
+        const bool ownA = inA && l >= a0 && !ovLast;
+        const bool ownB = inB && hbA && l < b0 && !(a.tier2 && lastOver);
         // bucket [s, t) in combined coordinates c = 0..127
         u64 mleA = hbA & ((2ull << l) - 1ull);
         int sA = mleA ? 63 - __builtin_clzll(mleA) : 0;            // start of my bucket (A lanes)
@@ -560,7 +571,7 @@ __global__ __launch_bounds__(FIN_NT) void finish_kernel(FinishArgs a) {
         }
         const u32 eqA = ownA ? leA - ltA - 1u : 0u;  // other members with the same remaining bits
         u32 rankB = 0, ltB = 0, leB = 0;
-        if (hbA && b0 > 0) {  // wave-uniform: some B-lanes continue A's last bucket
+        if (hbA && b0 > 0 && !(a.tier2 && lastOver)) {  // wave-uniform: some B-lanes continue A's last bucket
             for (int u = sB; u < tBend; u++) {
                 const u32 y = low[u];
                 ltB += y < lowB;
@@ -573,7 +584,30 @@ __global__ __launch_bounds__(FIN_NT) void finish_kernel(FinishArgs a) {
         // outputs
         const bool actA = ownA && eqA > 0, actB = ownB && eqB > 0;
         const u64 abA = __ballot(actA), abB = __ballot(actB);
-        const u32 nact = (u32)__popcll(abA) + (u32)__popcll(abB);
+        const u64 abO = __ballot(ovLead || ovLast);
+        u32 bstart = 0;  // start of the bucket the leading lanes continue
+        if (__ballot(ovLead)) {
+            // first index whose top bits are >= those of lane 0's key: 64-ary search below ws
+            const u64 t0 = __shfl(tA, 0, 64);
+            u64 lo = 0, hi = ws;
+            while (hi - lo >= 64) {  // the last step needs a lane past hi (answer == hi)
+                const u64 step = (hi - lo) / 64;
+                const bool ge = (a.keys[lo + step * l] >> a.tshift) >= t0;
+                const u64 mge = __ballot(ge);
+                if (mge == 0) {
+                    lo = lo + step * 63 + 1;
+                } else {
+                    const int f = __builtin_ctzll(mge);
+                    hi = lo + step * f;
+                    if (f > 0) lo = lo + step * (f - 1) + 1;
+                }
+            }
+            const bool ge = lo + l < hi ? (a.keys[lo + l] >> a.tshift) >= t0 : true;
+            bstart = (u32)(lo + __builtin_ctzll(__ballot(ge)));
+            if (l == 0) atomicOr(&a.counters[1], 2u);
+        }
+        if (__ballot(ovLast) && l == 0) atomicOr(&a.counters[1], 2u);
+        const u32 nact = (u32)__popcll(abA) + (u32)__popcll(abB) + (u32)__popcll(abO);
         u32 abase = 0;
         if (nact) {
             if (l == 0) abase = atomicAdd(&a.counters[0], nact);
@@ -605,8 +639,20 @@ __global__ __launch_bounds__(FIN_NT) void finish_kernel(FinishArgs a) {
                 }
             }
         }
+        if (ovLead || ovLast) {
+            const u32 j = (u32)ws + (u32)l;  // members stay where they are; the rounds order them
+            a.sa_out[j] = vA;
+            a.L[j] = (u8)(kA & 0xff);
+            const u32 o = abase + (u32)__popcll(abA) + (u32)__popcll(abB) + (u32)__popcll(abO & lanemask_lt());
+            if (o < a.act_cap) {
+                a.out_slot[o] = j;
+                a.out_idx[o] = vA;
+                a.out_grp[o] = ovLead ? bstart : (u32)ws + (u32)lastHeadA0;
+            }
+        }
         tprev = lastA;
         hasprev = true;
+        prev_head = hbA != 0ull;
     }
 }
 
