@@ -270,6 +270,7 @@ static void sa_run(tc_ctx *ctx, SaBuffers &b, const u8 *d_text, u64 n, u32 *d_sa
     const u64 *tkeys = nullptr;
     int tkeys_shift = 0;
     u64 m = 0;
+    u32 fm_dropped = 0;
     u64 h_start = cfg.h0;
     bool have_groups = false;
     tc_memset_async(ctx, ctx->d_scalars, 0, 16 * sizeof(u64));
@@ -296,15 +297,41 @@ static void sa_run(tc_ctx *ctx, SaBuffers &b, const u8 *d_text, u64 n, u32 *d_sa
             fa.sa_out = va; fa.L = d_L;
             fa.out_slot = b.act[0][0]; fa.out_idx = b.act[0][1]; fa.out_grp = b.act[0][2];
             fa.act_cap = (u32)N; fa.counters = counters;
-            fa.tier2 = env_int("TC_SA_TIER2", 1) != 0 ? 1 : 0;
+            fa.fix_cap = (u32)(b.sparse_cap - 1024);
+            fa.ovbits = b.act[1][0];   // the second active set is still unused
             const u32 waves = tc_cdiv(N, 64 * FIN_WPW);
             finish_kernel<<<tc_cdiv(waves, FIN_NT / 64), FIN_NT, 0, s>>>(fa);
             TC_LAUNCH_CHECK(ctx);
             tc_d2h(ctx, &ctx->h_scalars[12], ctx->d_scalars + 12, sizeof(u64));
             TC_HIP(ctx, hipStreamSynchronize(s));
-            const u32 fm = (u32)(ctx->h_scalars[12] & 0xffffffffu), over = (u32)(ctx->h_scalars[12] >> 32);
+            u32 fm = (u32)(ctx->h_scalars[12] & 0xffffffffu), over = (u32)(ctx->h_scalars[12] >> 32);
+            u32 slot_bits = (u32)rbits;
+            if ((over & 1u) && fm <= fa.fix_cap && env_int("TC_SA_TIER2", 1) != 0) {
+                // some buckets are longer than a wave window: the second pass turns them into tied
+                // groups (the sorted keys are still in place) and voids what the first pass
+                // emitted for their members
+                const u32 fm_lean = fm;
+                u32 *flagword = reinterpret_cast<u32 *>(ctx->d_scalars + 12) + 1;
+                u32 *ndropped = reinterpret_cast<u32 *>(ctx->d_scalars + 13);
+                tc_memset_async(ctx, flagword, 0, sizeof(u32));
+                tc_memset_async(ctx, ndropped, 0, sizeof(u64));
+                tc_memset_async(ctx, fa.ovbits, 0, ((size_t)tc_cdiv(N, 64) + 1) * sizeof(u64));
+                const u32 fwaves = tc_cdiv(N, 64 * FIX_WIN);
+                finish_fix_kernel<<<tc_cdiv(fwaves, FIN_NT / 64), FIN_NT, 0, s>>>(fa);
+                TC_LAUNCH_CHECK(ctx);
+                if (fm_lean) {
+                    finish_filter_kernel<<<tc_cdiv(fm_lean, 256), 256, 0, s>>>(fa.out_slot, fm_lean, fa.ovbits, ndropped);
+                    TC_LAUNCH_CHECK(ctx);
+                }
+                tc_d2h(ctx, &ctx->h_scalars[12], ctx->d_scalars + 12, 2 * sizeof(u64));
+                TC_HIP(ctx, hipStreamSynchronize(s));
+                fm = (u32)(ctx->h_scalars[12] & 0xffffffffu);
+                over = (u32)(ctx->h_scalars[12] >> 32);
+                fm_dropped = (u32)(ctx->h_scalars[13] & 0xffffffffu);
+                slot_bits = (u32)rbits + 1;   // the void slot value must sort behind slot N - 1
+            }
             if (!(over & 1u) && fm <= b.sparse_cap - 1024) {
-                m = fm;
+                m = fm - fm_dropped;
                 // whole buckets were emitted as tied groups: they share only the globally sorted
                 // symbols, so the doubling starts from those
                 if (over & 2u) h_start = (u64)(topbits / (int)cfg.w) * cfg.s;
@@ -314,13 +341,13 @@ static void sa_run(tc_ctx *ctx, SaBuffers &b, const u8 *d_text, u64 n, u32 *d_sa
                 st.finish_pass = 1;
                 st.rounds = 1;
                 st.m[0] = N; st.key_bytes[0] = 8; st.passes[0] = (u32)plan.npass; st.h[0] = 0;
-                if (m > 0) {  // bring the tied set into SA order (refine relies on it)
-                    u32 mm = (u32)m;
+                if (m > 0) {  // bring the tied set into SA order (refine relies on it); void entries go last
+                    u32 mm = fm;
                     pack_active_kernel<<<tc_cdiv(mm, 256), 256, 0, s>>>(b.act[0][0], b.act[0][2], mm, b.sk[0]);
                     TC_LAUNCH_CHECK(ctx);
                     TC_HIP(ctx, hipMemcpyAsync(b.sv[0], b.act[0][1], mm * sizeof(u32), hipMemcpyDeviceToDevice, s));
                     RadixPlan ps;
-                    ps.add_range(32, 32 + rbits);
+                    ps.add_range(32, 32 + (int)slot_bits);
                     RadixBuffers rs;
                     rs.keys = b.sk[0]; rs.keys_alt = b.sk[1]; rs.vals = b.sv[0]; rs.vals_alt = b.sv[1];
                     rs.hist = b.hist; rs.status = b.rstatus;

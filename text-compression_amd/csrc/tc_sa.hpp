@@ -469,10 +469,11 @@ struct FinishArgs {
     u8 *L;
     u32 *out_slot, *out_idx, *out_grp;
     u32 act_cap;
-    u32 *counters;     // [0] active count, [1] bit 0: a bucket this kernel cannot handle (caller takes
-                       //     the full path), bit 1: members of oversize buckets were emitted as tied
-    int tier2;         // 1: a bucket too long for the window logic is emitted whole as ONE tied group
-                       //    (group = bucket start, members left in place) instead of raising bit 0
+    u32 *counters;     // [0] active count, [1] bit 0: a bucket longer than the window logic handles was
+                       //     met (what was written for its members is void), bit 1: such buckets were emitted as
+                       //     tied groups
+    u32 fix_cap;       // finish_fix_kernel stops writing once the active count exceeds this
+    u32 *ovbits;       // finish_fix_kernel: one bit per position, set for members of over-long buckets
 };
 
 __global__ __launch_bounds__(FIN_NT) void finish_kernel(FinishArgs a) {
@@ -496,9 +497,6 @@ __global__ __launch_bounds__(FIN_NT) void finish_kernel(FinishArgs a) {
     }
     u64 tprev = ws0 > 0 ? (a.keys[ws0 - 1] >> a.tshift) : 0;  // wave-uniform
     bool hasprev = ws0 > 0;
-    // does the window before this one contain a bucket head?  (sorted keys: it does unless its 64
-    // keys and the key before them all share their top bits)
-    bool prev_head = ws0 < 65 || (a.keys[ws0 - 65] >> a.tshift) != tprev;
 
 #pragma unroll
     for (int win = 0; win < FIN_WPW; win++) {
@@ -521,17 +519,15 @@ __global__ __launch_bounds__(FIN_NT) void finish_kernel(FinishArgs a) {
         const int a0 = hbA ? __builtin_ctzll(hbA) : 64;
         const int b0 = hbB ? __builtin_ctzll(hbB) : 64;
         // the bucket running out of A must end inside B (a head in B, or the array ends there)
-        // no head in a full B: the last bucket of A is longer than the window logic handles
-        const bool lastOver = hbA && !hbB && (~inbB) == 0ull;
-        if (lastOver && !a.tier2 && l == 0) atomicOr(&a.counters[1], 1u);
-        const int lastHeadA0 = hbA ? 63 - __builtin_clzll(hbA) : 0;
-        // lanes before the first head continue a bucket from before this window: the previous
-        // window ranked them iff it holds that bucket's head and the bucket ends in here
-        const bool lead_ok = prev_head && (hbA != 0ull || (~inbA) != 0ull);
-        const bool ovLead = a.tier2 && inA && l < a0 && !lead_ok;
-        const bool ovLast = a.tier2 && lastOver && inA && l >= lastHeadA0;
-        const bool ownA = inA && l >= a0 && !ovLast;
-        const bool ownB = inB && hbA && l < b0 && !(a.tier2 && lastOver);
+        if (hbA && !hbB && (~inbB) == 0ull) {
+            // no head in a full B: the last bucket of A is longer than this kernel handles.  What
+            // is written for its members below is meaningless; finish_fix_kernel redoes them
+            // (and finish_filter_kernel drops their entries from the tied list).
+            if (l == 0 && !(__hip_atomic_load(&a.counters[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & 1u))
+                atomicOr(&a.counters[1], 1u);
+        }
+        const bool ownA = inA && l >= a0;
+        const bool ownB = inB && hbA && l < b0;
         // bucket [s, t) in combined coordinates c = 0..127
         u64 mleA = hbA & ((2ull << l) - 1ull);
         int sA = mleA ? 63 - __builtin_clzll(mleA) : 0;            // start of my bucket (A lanes)
@@ -571,7 +567,7 @@ __global__ __launch_bounds__(FIN_NT) void finish_kernel(FinishArgs a) {
         }
         const u32 eqA = ownA ? leA - ltA - 1u : 0u;  // other members with the same remaining bits
         u32 rankB = 0, ltB = 0, leB = 0;
-        if (hbA && b0 > 0 && !(a.tier2 && lastOver)) {  // wave-uniform: some B-lanes continue A's last bucket
+        if (hbA && b0 > 0) {  // wave-uniform: some B-lanes continue A's last bucket
             for (int u = sB; u < tBend; u++) {
                 const u32 y = low[u];
                 ltB += y < lowB;
@@ -584,30 +580,7 @@ __global__ __launch_bounds__(FIN_NT) void finish_kernel(FinishArgs a) {
         // outputs
         const bool actA = ownA && eqA > 0, actB = ownB && eqB > 0;
         const u64 abA = __ballot(actA), abB = __ballot(actB);
-        const u64 abO = __ballot(ovLead || ovLast);
-        u32 bstart = 0;  // start of the bucket the leading lanes continue
-        if (__ballot(ovLead)) {
-            // first index whose top bits are >= those of lane 0's key: 64-ary search below ws
-            const u64 t0 = __shfl(tA, 0, 64);
-            u64 lo = 0, hi = ws;
-            while (hi - lo >= 64) {  // the last step needs a lane past hi (answer == hi)
-                const u64 step = (hi - lo) / 64;
-                const bool ge = (a.keys[lo + step * l] >> a.tshift) >= t0;
-                const u64 mge = __ballot(ge);
-                if (mge == 0) {
-                    lo = lo + step * 63 + 1;
-                } else {
-                    const int f = __builtin_ctzll(mge);
-                    hi = lo + step * f;
-                    if (f > 0) lo = lo + step * (f - 1) + 1;
-                }
-            }
-            const bool ge = lo + l < hi ? (a.keys[lo + l] >> a.tshift) >= t0 : true;
-            bstart = (u32)(lo + __builtin_ctzll(__ballot(ge)));
-            if (l == 0) atomicOr(&a.counters[1], 2u);
-        }
-        if (__ballot(ovLast) && l == 0) atomicOr(&a.counters[1], 2u);
-        const u32 nact = (u32)__popcll(abA) + (u32)__popcll(abB) + (u32)__popcll(abO);
+        const u32 nact = (u32)__popcll(abA) + (u32)__popcll(abB);
         u32 abase = 0;
         if (nact) {
             if (l == 0) abase = atomicAdd(&a.counters[0], nact);
@@ -639,21 +612,122 @@ __global__ __launch_bounds__(FIN_NT) void finish_kernel(FinishArgs a) {
                 }
             }
         }
-        if (ovLead || ovLast) {
-            const u32 j = (u32)ws + (u32)l;  // members stay where they are; the rounds order them
-            a.sa_out[j] = vA;
-            a.L[j] = (u8)(kA & 0xff);
-            const u32 o = abase + (u32)__popcll(abA) + (u32)__popcll(abB) + (u32)__popcll(abO & lanemask_lt());
-            if (o < a.act_cap) {
-                a.out_slot[o] = j;
-                a.out_idx[o] = vA;
-                a.out_grp[o] = ovLead ? bstart : (u32)ws + (u32)lastHeadA0;
-            }
-        }
         tprev = lastA;
         hasprev = true;
-        prev_head = hbA != 0ull;
     }
+}
+
+// Second pass, launched only when the lean pass met a bucket longer than it handles.  Members of
+// such a bucket -- the last bucket of a window when it does not end in the next one, and the
+// leading lanes of a window when the previous window holds no head of their bucket (this covers
+// windows lying entirely inside a bucket) -- become ONE tied group per bucket: group = bucket
+// start, members stay in place; the doubling rounds order them.  Their slots are marked in
+// `ovbits` (one bit per position) so that the entries the lean pass produced for them can be
+// dropped.  A wave covers FIX_WIN windows: it first counts its members (one atomic per wave;
+// nothing is written once the total exceeds fix_cap -- the caller then takes the full path),
+// then emits.
+#define FIX_WIN 16
+__global__ __launch_bounds__(FIN_NT) void finish_fix_kernel(FinishArgs a) {
+    const int w = threadIdx.x >> 6, l = threadIdx.x & 63;
+    const u64 N = a.N;
+    const u64 wave = (u64)blockIdx.x * (FIN_NT / 64) + w;
+    const u64 ws0 = wave * 64 * FIX_WIN;
+    if (ws0 >= N) return;
+    u32 abase = 0;
+    for (int phase = 0; phase < 2; phase++) {
+        u32 total = 0;
+        u64 tprev = ws0 > 0 ? (a.keys[ws0 - 1] >> a.tshift) : 0;
+        // the previous window holds a bucket head unless its 64 keys and the key before them all
+        // share their top bits (sorted keys)
+        bool prev_head = ws0 < 65 || (a.keys[ws0 - 65] >> a.tshift) != tprev;
+        u64 kA = ws0 + l < N ? a.keys[ws0 + l] : ~0ull;
+        for (int win = 0; win < FIX_WIN; win++) {
+            const u64 ws = ws0 + (u64)win * 64;
+            if (ws >= N) break;
+            const bool inA = ws + l < N, inB = ws + 64 + l < N;
+            const u64 kB = inB ? a.keys[ws + 64 + l] : ~0ull;
+            const u64 tA = kA >> a.tshift, tB = kB >> a.tshift;
+            u64 upA = __shfl_up(tA, 1, 64);
+            u64 lastA = __shfl(tA, 63, 64);
+            u64 upB = __shfl_up(tB, 1, 64);
+            bool hA = inA && ((l == 0) ? (ws == 0 || tA != tprev) : (tA != upA));
+            bool hB = inB && ((l == 0) ? (tB != lastA) : (tB != upB));
+            const u64 hbA = __ballot(hA), hbB = __ballot(hB);
+            const u64 inbA = __ballot(inA), inbB = __ballot(inB);
+            const int a0 = hbA ? __builtin_ctzll(hbA) : 64;
+            const int lastHeadA = hbA ? 63 - __builtin_clzll(hbA) : 0;
+            const bool lastOver = hbA && !hbB && (~inbB) == 0ull;
+            // leading lanes were ranked by the previous window iff it holds their bucket's head
+            // and the bucket ends in here
+            const bool lead_ok = prev_head && (hbA != 0ull || (~inbA) != 0ull);
+            const bool ovLead = inA && l < a0 && !lead_ok;
+            const bool ovLast = lastOver && inA && l >= lastHeadA;
+            const u64 abO = __ballot(ovLead || ovLast);
+            if (abO && phase == 1) {
+                if (l == 0) reinterpret_cast<u64 *>(a.ovbits)[ws >> 6] = abO;
+                u32 bstart = 0;  // start of the bucket the leading lanes continue
+                if (__ballot(ovLead)) {
+                    // first index whose top bits are >= those of lane 0's key: 64-ary search below ws
+                    const u64 t0 = __shfl(tA, 0, 64);
+                    u64 lo = 0, hi = ws;
+                    while (hi - lo >= 64) {  // the last step needs a lane past hi (answer == hi)
+                        const u64 step = (hi - lo) / 64;
+                        const bool ge = (a.keys[lo + step * l] >> a.tshift) >= t0;
+                        const u64 mge = __ballot(ge);
+                        if (mge == 0) {
+                            lo = lo + step * 63 + 1;
+                        } else {
+                            const int f = __builtin_ctzll(mge);
+                            hi = lo + step * f;
+                            if (f > 0) lo = lo + step * (f - 1) + 1;
+                        }
+                    }
+                    const bool ge = lo + l < hi ? (a.keys[lo + l] >> a.tshift) >= t0 : true;
+                    bstart = (u32)(lo + __builtin_ctzll(__ballot(ge)));
+                }
+                if (ovLead || ovLast) {
+                    const u32 j = (u32)ws + (u32)l;
+                    const u32 v = a.sa_in[j];
+                    a.sa_out[j] = v;
+                    a.L[j] = (u8)(kA & 0xff);
+                    const u32 o = abase + total + (u32)__popcll(abO & lanemask_lt());
+                    if (o < a.act_cap) {
+                        a.out_slot[o] = j;
+                        a.out_idx[o] = v;
+                        a.out_grp[o] = ovLead ? bstart : (u32)ws + (u32)lastHeadA;
+                    }
+                }
+            }
+            total += (u32)__popcll(abO);
+            tprev = lastA;
+            prev_head = hbA != 0ull;
+            kA = kB;
+        }
+        if (phase == 0) {
+            if (total == 0) return;
+            if (l == 0) {
+                abase = atomicAdd(&a.counters[0], total);
+                atomicOr(&a.counters[1], 2u);
+            }
+            abase = __shfl(abase, 0, 64);
+            if ((u64)abase + total > (u64)a.fix_cap) return;  // too many: the caller falls back
+        }
+    }
+}
+
+// entries of the lean pass whose slot belongs to an over-long bucket are void: slot := ~0 (they
+// sort behind every real entry); *ndropped counts them
+__global__ __launch_bounds__(256) void finish_filter_kernel(u32 *__restrict__ slot, u32 count,
+                                                            const u32 *__restrict__ ovbits, u32 *ndropped) {
+    const u32 k = blockIdx.x * 256 + threadIdx.x;
+    bool drop = false;
+    if (k < count) {
+        const u32 j = slot[k];
+        drop = (ovbits[j >> 5] >> (j & 31)) & 1u;
+        if (drop) slot[k] = 0xFFFFFFFFu;
+    }
+    const u64 m = __ballot(drop);
+    if (m && lane_id() == 0) atomicAdd(ndropped, (u32)__popcll(m));
 }
 
 // active set arrives unordered from finish_kernel; refine needs it in SA order:
