@@ -246,6 +246,12 @@ def test_oversize_buckets_become_tied_groups(ctx, seed, n, poly, copies, unit, m
     assert ctx.suffix_array(t).tolist() == exp
     st = ctx.stats()
     assert st.finish_pass == 1 and st.rounds >= 2 and 0 < st.m[1] < (n + 1) // 8
+    monkeypatch.setenv("TC_SA_ACCEL_MIN", "0")      # rank lookups through the bitmap / key directory
+    assert ctx.suffix_array(t).tolist() == exp
+    monkeypatch.setenv("TC_SA_FINISH", "0")         # ... also from the full path (sorted keys)
+    assert ctx.suffix_array(t).tolist() == exp
+    monkeypatch.delenv("TC_SA_FINISH")
+    monkeypatch.delenv("TC_SA_ACCEL_MIN")
     monkeypatch.setenv("TC_SA_TIER2", "0")          # old behaviour: restart on the full path
     assert ctx.suffix_array(t).tolist() == exp
     assert ctx.stats().finish_pass == 0

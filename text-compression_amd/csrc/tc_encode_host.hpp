@@ -50,6 +50,7 @@ struct Alphabet {
 };
 
 // ------------------------------------------------------------------ suffix array
+#define SA_KDIR_BITS 22
 struct SaBuffers {
     u64 *k0, *k1;
     u32 *v0, *v1;
@@ -60,6 +61,10 @@ struct SaBuffers {
     u64 *sk[2];
     u32 *sv[2];
     u32 *t_idx, *t_rank;
+    u64 *t_bits;   // N bits
+    u32 *t_dir;    // per 64-bit word of t_bits
+    u32 *t_bsum;
+    u32 *kdir;     // 2^SA_KDIR_BITS + 1
     u64 sparse_cap;
     u32 *hist;
     u64 *rstatus;
@@ -83,6 +88,10 @@ static size_t sa_carve(Arena &A, u64 N, SaBuffers &b, bool own_v1) {
     }
     b.t_idx = A.get<u32>(b.sparse_cap);
     b.t_rank = A.get<u32>(b.sparse_cap);
+    b.t_bits = A.get<u64>(N / 64 + 2);
+    b.t_dir = A.get<u32>(N / 64 + 2);
+    b.t_bsum = A.get<u32>(N / 64 / BDIR_TILE + 2);
+    b.kdir = A.get<u32>((1u << SA_KDIR_BITS) + 2);
     b.hist = A.get<u32>(RDX_MAX_PASSES * RDX_BINS);
     b.rstatus = A.get<u64>(radix_status_words(N));
     b.gstatus = A.get<u64>(2 * (size_t)tc_cdiv(N, GRP_TILE) + 4);
@@ -402,9 +411,31 @@ static void sa_run(tc_ctx *ctx, SaBuffers &b, const u8 *d_text, u64 n, u32 *d_sa
             rt.keys = b.sk[0]; rt.keys_alt = b.sk[1]; rt.vals = b.sv[0]; rt.vals_alt = b.sv[1];
             rt.hist = b.hist; rt.status = b.rstatus;
             radix_sort_pairs(ctx, rt, mm, pt, true, false);
+            // large tied sets: bitmap + popcount directory instead of a binary search per lookup,
+            // and a directory into the sorted keys for the ranks of untied suffixes
+            const bool accel = m >= (u64)env_int("TC_SA_ACCEL_MIN", 65536);
+            const u32 nwords = (u32)(N / 64 + 1);
+            if (accel) tc_memset_async(ctx, b.t_bits, 0, (size_t)nwords * sizeof(u64));
             table_build_kernel<<<tc_cdiv(mm, 256), 256, 0, s>>>(rt.keys, rt.vals, b.act[0][2], mm,
-                                                               b.t_idx, b.t_rank, b.act[0][3]);
+                                                               b.t_idx, b.t_rank, b.act[0][3],
+                                                               accel ? b.t_bits : nullptr);
             TC_LAUNCH_CHECK(ctx);
+            if (accel) {
+                const u32 nb = tc_cdiv(nwords, BDIR_TILE);
+                bitdir_sum_kernel<<<nb, 256, 0, s>>>(b.t_bits, nwords, b.t_bsum);
+                TC_LAUNCH_CHECK(ctx);
+                bitdir_spine_kernel<<<1, 1024, 0, s>>>(b.t_bsum, nb);
+                TC_LAUNCH_CHECK(ctx);
+                bitdir_down_kernel<<<nb, 256, 0, s>>>(b.t_bits, nwords, b.t_bsum, b.t_dir);
+                TC_LAUNCH_CHECK(ctx);
+                rl.t_bits = b.t_bits; rl.t_dir = b.t_dir;
+                if (tkeys) {
+                    int kb = 64 - tkeys_shift < SA_KDIR_BITS ? 64 - tkeys_shift : SA_KDIR_BITS;
+                    kdir_build_kernel<<<tc_cdiv((1ull << kb) + 1, 256), 256, 0, s>>>(tkeys, (u32)N, kb, b.kdir);
+                    TC_LAUNCH_CHECK(ctx);
+                    rl.kdir = b.kdir; rl.kdir_bits = kb;
+                }
+            }
         }
     }
 

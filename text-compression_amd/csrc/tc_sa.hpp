@@ -761,6 +761,13 @@ struct RankLookup {
     const u64 *tkeys;    // keys sorted by their bits >= tshift only (fast path), or null
     int tshift;
     const u32 *sa;       // the suffix array after round 0 (used when skeys is null)
+    // optional accelerators (large tied sets): one bit per text position that is in the table +
+    // prefix popcounts per 64-bit word (table index in two loads instead of a binary search),
+    // and a directory over the top kdir_bits key bits into tkeys (first index per prefix)
+    const u64 *t_bits;
+    const u32 *t_dir;
+    const u32 *kdir;
+    int kdir_bits;
     const u8 *text;
     u32 n, N;
     u32 B, w, s, P;
@@ -781,7 +788,11 @@ __device__ __forceinline__ int suffix_cmp(const u8 *text, u32 n, u64 x, u64 y, u
 __device__ __forceinline__ u32 rank_of(const RankLookup &r, const u16 *s_lut, u64 p) {
     if (p >= r.N) return 0u;
     if (r.isa) return r.isa[p];
-    {   // binary search in the table of ever-tied positions
+    if (r.t_bits) {
+        const u64 wbits = r.t_bits[p >> 6];
+        if ((wbits >> (p & 63)) & 1ull)
+            return r.t_rank[r.t_dir[p >> 6] + (u32)__popcll(wbits & ((1ull << (p & 63)) - 1ull))];
+    } else {   // binary search in the table of ever-tied positions
         u32 lo = 0, hi = r.t_n;
         while (lo < hi) {
             u32 mid = (lo + hi) >> 1;
@@ -789,51 +800,44 @@ __device__ __forceinline__ u32 rank_of(const RankLookup &r, const u16 *s_lut, u6
         }
         if (lo < r.t_n && r.t_idx[lo] == (u32)p) return r.t_rank[lo];
     }
+    // round-0 key of suffix p, straight from the text
+    u64 key = 0;
+    {
+        int sh = 64;
+        u64 q = p;
+        for (u32 f = 0; f < r.P; f++) {
+            u32 g = 0;
+            for (u32 t = 0; t < r.s; t++, q++) g = g * r.B + (q < r.n ? (u32)s_lut[r.text[q]] : 0u);
+            sh -= r.w;
+            key |= (u64)g << sh;
+        }
+    }
     if (!r.skeys) {
-        // suffix p was unique after round 0: its rank is its position in the SA.  The
-        // partially sorted keys narrow it to its (tiny) top-bits bucket first; inside
-        // the bucket the first h0 symbols are compared against the suffixes the SA
-        // points at.
+        // suffix p was unique after round 0: its rank is its position in the SA.  tkeys is sorted
+        // by the top bits only; inside p's (small, fully ordered) top-bits bucket the first h0
+        // symbols are compared against the suffixes the SA points at.  One lower bound over the
+        // composite order (top bits, then suffix).
         u64 lo = 0, hi = r.N;
         if (r.tkeys) {
-            u64 key = 0;
-            int sh = 64;
-            u64 q = p;
-            for (u32 f = 0; f < r.P; f++) {
-                u32 g = 0;
-                for (u32 t = 0; t < r.s; t++, q++) g = g * r.B + (q < r.n ? (u32)s_lut[r.text[q]] : 0u);
-                sh -= r.w;
-                key |= (u64)g << sh;
-            }
             const u64 tk = key >> r.tshift;
-            u64 a = 0, b = r.N;  // first index with top bits >= tk
-            while (a < b) {
-                u64 mid = (a + b) >> 1;
-                if ((r.tkeys[mid] >> r.tshift) < tk) a = mid + 1; else b = mid;
+            if (r.kdir) {
+                const u64 v = key >> (64 - r.kdir_bits);
+                lo = r.kdir[v];
+                hi = r.kdir[v + 1];
             }
-            lo = a;
-            b = r.N;             // first index with top bits > tk
-            while (a < b) {
-                u64 mid = (a + b) >> 1;
-                if ((r.tkeys[mid] >> r.tshift) <= tk) a = mid + 1; else b = mid;
+            while (lo < hi) {
+                const u64 mid = (lo + hi) >> 1;
+                const u64 t = r.tkeys[mid] >> r.tshift;
+                const bool less = t < tk || (t == tk && suffix_cmp(r.text, r.n, r.sa[mid], p, r.h0) < 0);
+                if (less) lo = mid + 1; else hi = mid;
             }
-            hi = a;
+            return (u32)lo;
         }
         while (lo < hi) {
             u64 mid = (lo + hi) >> 1;
             if (suffix_cmp(r.text, r.n, r.sa[mid], p, r.h0) < 0) lo = mid + 1; else hi = mid;
         }
         return (u32)lo;
-    }
-    // round-0 key of suffix p, straight from the text
-    u64 key = 0;
-    int sh = 64;
-    u64 q = p;
-    for (u32 f = 0; f < r.P; f++) {
-        u32 g = 0;
-        for (u32 t = 0; t < r.s; t++, q++) g = g * r.B + (q < r.n ? (u32)s_lut[r.text[q]] : 0u);
-        sh -= r.w;
-        key |= (u64)g << sh;
     }
     u64 lo = 0, hi = r.N;  // lower_bound over the key bits above the payload byte
     while (lo < hi) {
@@ -869,13 +873,75 @@ __global__ __launch_bounds__(256) void table_build_kernel(const u64 *__restrict_
                                                           const u32 *__restrict__ grp, u32 m,
                                                           u32 *__restrict__ t_idx,
                                                           u32 *__restrict__ t_rank,
-                                                          u32 *__restrict__ tpos) {
+                                                          u32 *__restrict__ tpos, u64 *t_bits) {
     u32 q = blockIdx.x * 256 + threadIdx.x;
     if (q >= m) return;
     u32 k = sorted_k[q];
-    t_idx[q] = (u32)sorted_idx[q];
+    const u32 p = (u32)sorted_idx[q];
+    t_idx[q] = p;
     t_rank[q] = grp[k];
     tpos[k] = q;
+    if (t_bits) atomicOr((unsigned long long *)&t_bits[p >> 6], 1ull << (p & 63));
+}
+
+// t_dir[w] = number of set bits in t_bits[0 .. w): three small launches
+#define BDIR_TILE 2048
+__global__ __launch_bounds__(256) void bitdir_sum_kernel(const u64 *__restrict__ bits, u32 nwords, u32 *bsum) {
+    __shared__ u32 sm[8];
+    u32 c = 0;
+    for (int k = 0; k < BDIR_TILE / 256; k++) {
+        const u32 i = blockIdx.x * BDIR_TILE + k * 256 + threadIdx.x;
+        if (i < nwords) c += (u32)__popcll(bits[i]);
+    }
+    c = wave_sum(c);
+    if (lane_id() == 0) sm[threadIdx.x >> 6] = c;
+    __syncthreads();
+    if (threadIdx.x == 0) bsum[blockIdx.x] = sm[0] + sm[1] + sm[2] + sm[3];
+}
+__global__ __launch_bounds__(1024) void bitdir_spine_kernel(u32 *bsum, u32 nb) {
+    __shared__ u32 sm[1024 / 64 + 1];
+    const u32 per = (nb + 1023) / 1024;
+    const u32 lo = threadIdx.x * per < nb ? threadIdx.x * per : nb;
+    const u32 hi = lo + per < nb ? lo + per : nb;
+    u32 mine = 0;
+    for (u32 i = lo; i < hi; i++) mine += bsum[i];
+    u32 total;
+    u32 run = block_excl_sum<1024>(mine, sm, &total);
+    for (u32 i = lo; i < hi; i++) {
+        const u32 v = bsum[i];
+        bsum[i] = run;
+        run += v;
+    }
+}
+__global__ __launch_bounds__(256) void bitdir_down_kernel(const u64 *__restrict__ bits, u32 nwords,
+                                                          const u32 *__restrict__ bsum, u32 *__restrict__ dir) {
+    __shared__ u32 sm[256 / 64 + 1];
+    const u32 i0 = blockIdx.x * BDIR_TILE + threadIdx.x * (BDIR_TILE / 256);
+    u32 c[BDIR_TILE / 256], mine = 0;
+#pragma unroll
+    for (int k = 0; k < BDIR_TILE / 256; k++) {
+        c[k] = i0 + k < nwords ? (u32)__popcll(bits[i0 + k]) : 0u;
+        mine += c[k];
+    }
+    u32 total;
+    u32 run = bsum[blockIdx.x] + block_excl_sum<256>(mine, sm, &total);
+#pragma unroll
+    for (int k = 0; k < BDIR_TILE / 256; k++) {
+        if (i0 + k < nwords) dir[i0 + k] = run;
+        run += c[k];
+    }
+}
+// kdir[v] = first index of tkeys whose top `bits` bits are >= v (v = 0 .. 2^bits)
+__global__ __launch_bounds__(256) void kdir_build_kernel(const u64 *__restrict__ tkeys, u32 N, int bits,
+                                                         u32 *__restrict__ kdir) {
+    const u64 v = (u64)blockIdx.x * 256 + threadIdx.x;
+    if (v > (1ull << bits)) return;
+    u64 lo = 0, hi = N;
+    while (lo < hi) {
+        const u64 mid = (lo + hi) >> 1;
+        if ((tkeys[mid] >> (64 - bits)) < v) lo = mid + 1; else hi = mid;
+    }
+    kdir[v] = (u32)lo;
 }
 
 __global__ __launch_bounds__(256) void widen_u32_kernel(const u32 *__restrict__ a,
