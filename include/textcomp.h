@@ -72,6 +72,9 @@ typedef struct tc_stats {
     uint32_t keygen_fused;           /* 1: the first pass builds its keys from the text (reads 1 B,
                                         writes 12 B per suffix instead of 12 + 12) */
     uint32_t finish_pass;            /* 1: round 0 = partial sort + finish kernel (12 B read, 5 B written) */
+    uint32_t sample_dups;            /* of 8192 sampled suffixes, how many repeated another sample's
+                                        globally sorted prefix (> 10 %: full path without trying the
+                                        finish pass) */
 } tc_stats;
 
 /* The encoded block of the fused BWT -> MTF -> RLE pipeline.  The reference has

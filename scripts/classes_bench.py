@@ -105,7 +105,7 @@ for name, mk in classes.items():
             print(name, "decode rc", rc, lib.tc_last_error(ctx.handle)); break
     else:
         ok = bool(torch.equal(d_out, t))
-        print("%-12s n=%d sigma=%d enc %.1f ms (%.2f GB/s) dec %.1f ms (%.2f GB/s) rounds=%d m=%s passes=%s runs=%d exact=%s | sa %.1f mtf %.1f rle %.1f" % (
+        print("%-12s n=%d sigma=%d enc %.1f ms (%.2f GB/s) dec %.1f ms (%.2f GB/s) rounds=%d m=%s passes=%s runs=%d exact=%s | sa %.1f mtf %.1f rle %.1f | sample dups %d finish %d" % (
             name, n, blk.sigma, min(enc) * 1e3, n / min(enc) / 1e9, min(dec) * 1e3, n / min(dec) / 1e9, st.rounds,
-            [int(st.m[i]) for i in range(st.rounds)][:6], [int(st.passes[i]) for i in range(st.rounds)][:6], blk.nruns, ok, st.ms_sa, st.ms_mtf, st.ms_rle), flush=True)
+            [int(st.m[i]) for i in range(st.rounds)][:6], [int(st.passes[i]) for i in range(st.rounds)][:6], blk.nruns, ok, st.ms_sa, st.ms_mtf, st.ms_rle, st.sample_dups, st.finish_pass), flush=True)
     del t

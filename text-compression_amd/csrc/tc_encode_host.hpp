@@ -294,7 +294,22 @@ static void sa_run(tc_ctx *ctx, SaBuffers &b, const u8 *d_text, u64 n, u32 *d_sa
         int forcedG = env_int("TC_SA_GLOBAL_PASSES", 0);
         if (forcedG > 0) G = forcedG;
         int topbits = 8 * G < keybits ? 8 * G : keybits;
-        if (keybits - topbits <= 32) {
+        // cheap look before the leap: if a sample of suffixes already collides heavily on the
+        // globally sorted prefix, the tied set would exceed the sparse capacity anyway
+        bool hopeless = false;
+        if (keybits - topbits <= 32 && n >= (1u << 20) && env_int("TC_SA_SAMPLE", 1) != 0) {
+            RadixKeyGen kgs;
+            kgs.n_text = (u32)n; kgs.B = cfg.B; kgs.w = cfg.w; kgs.s = cfg.s; kgs.P = cfg.P;
+            memcpy(kgs.lut, cfg.lut, sizeof kgs.lut);
+            u32 *d_dups = reinterpret_cast<u32 *>(ctx->d_scalars + 14);
+            sample_dup_kernel<<<1, 1024, 0, s>>>(d_text, (u32)n, kgs, topbits, d_dups);
+            TC_LAUNCH_CHECK(ctx);
+            tc_d2h(ctx, &ctx->h_scalars[14], ctx->d_scalars + 14, sizeof(u64));
+            TC_HIP(ctx, hipStreamSynchronize(s));
+            st.sample_dups = (u32)ctx->h_scalars[14];
+            hopeless = st.sample_dups > SAMP_N / 10;
+        }
+        if (keybits - topbits <= 32 && !hopeless) {
             RadixPlan plan;
             plan.add_range(64 - topbits, 64);
             RadixBuffers rb;

@@ -459,6 +459,53 @@ __global__ __launch_bounds__(GRP_NT, 4) void group_kernel(GroupArgs a) {
 #define FIN_WPW 4      // windows per wave
 #define FIN_NT 256
 
+// Will the finish pass pay off?  SAMP_N pseudo-random suffixes, their top `topbits` key bits into an
+// LDS hash set: *out = number of samples whose prefix was already present.  On text with heavy
+// repeated contexts (natural language, long runs) a large share of the samples collide and the
+// caller goes straight to the full path; random-like text gives ~0.
+#define SAMP_N 8192
+#define SAMP_SLOTS 16384
+__global__ __launch_bounds__(1024) void sample_dup_kernel(const u8 *__restrict__ text, u32 n, RadixKeyGen kg,
+                                                           int topbits, u32 *out) {
+    __shared__ u32 table[SAMP_SLOTS];
+    __shared__ u16 s_lut[256];
+    __shared__ u32 s_dups;
+    for (int i = threadIdx.x; i < SAMP_SLOTS; i += 1024) table[i] = 0xFFFFFFFFu;
+    if (threadIdx.x < 256) s_lut[threadIdx.x] = kg.lut[threadIdx.x];
+    if (threadIdx.x == 0) s_dups = 0;
+    __syncthreads();
+    u32 dups = 0;
+    const u32 nf = ((u32)topbits + kg.w - 1) / kg.w;  // fields that reach into the top bits
+    for (u32 k = threadIdx.x; k < SAMP_N; k += 1024) {
+        u64 z = (u64)(k + 1) * 0x9E3779B97F4A7C15ull;
+        z = (z ^ (z >> 29)) * 0xBF58476D1CE4E5B9ull;
+        u64 q = (u64)(((z >> 32) * (u64)n) >> 32);
+        u64 key = 0;
+        int sh = 64;
+        for (u32 f = 0; f < nf; f++) {
+            u32 g = 0;
+            for (u32 t = 0; t < kg.s; t++, q++) g = g * kg.B + (q < n ? (u32)s_lut[text[q]] : 0u);
+            sh -= kg.w;
+            key |= (u64)g << sh;
+        }
+        u64 kt = key >> (64 - topbits);
+        if (topbits > 32) kt = (kt ^ (kt >> 31)) * 0xD6E8FEB86659FD93ull >> 32;   // fold to 32 bits
+        const u32 v = (u32)kt;
+        if (v == 0xFFFFFFFFu) continue;
+        u32 slot = (v * 0x9E3779B1u) >> 18;  // 14 bits
+        for (int probe = 0; probe < SAMP_SLOTS; probe++) {
+            const u32 old = atomicCAS(&table[slot], 0xFFFFFFFFu, v);
+            if (old == 0xFFFFFFFFu) break;
+            if (old == v) { dups++; break; }
+            slot = (slot + 1) & (SAMP_SLOTS - 1);
+        }
+    }
+    dups = wave_sum(dups);
+    if (lane_id() == 0 && dups) atomicAdd(&s_dups, dups);
+    __syncthreads();
+    if (threadIdx.x == 0) *out = s_dups;
+}
+
 struct FinishArgs {
     const u64 *keys;
     const u32 *sa_in;
