@@ -280,6 +280,7 @@ static void sa_run(tc_ctx *ctx, SaBuffers &b, const u8 *d_text, u64 n, u32 *d_sa
     int tkeys_shift = 0;
     u64 m = 0;
     u32 fm_dropped = 0;
+    bool hopeless = false, isa_ready = false;
     u64 h_start = cfg.h0;
     bool have_groups = false;
     tc_memset_async(ctx, ctx->d_scalars, 0, 16 * sizeof(u64));
@@ -296,7 +297,6 @@ static void sa_run(tc_ctx *ctx, SaBuffers &b, const u8 *d_text, u64 n, u32 *d_sa
         int topbits = 8 * G < keybits ? 8 * G : keybits;
         // cheap look before the leap: if a sample of suffixes already collides heavily on the
         // globally sorted prefix, the tied set would exceed the sparse capacity anyway
-        bool hopeless = false;
         if (keybits - topbits <= 32 && n >= (1u << 20) && env_int("TC_SA_SAMPLE", 1) != 0) {
             RadixKeyGen kgs;
             kgs.n_text = (u32)n; kgs.B = cfg.B; kgs.w = cfg.w; kgs.s = cfg.s; kgs.P = cfg.P;
@@ -392,6 +392,7 @@ static void sa_run(tc_ctx *ctx, SaBuffers &b, const u8 *d_text, u64 n, u32 *d_sa
         GroupArgs g0 = {};
         g0.keys = skeys; g0.count = (u32)N; g0.vals = sa;
         g0.out_slot = b.act[0][0]; g0.out_idx = b.act[0][1]; g0.out_grp = b.act[0][2]; g0.out_tpos = b.act[0][3];
+        if (hopeless) { g0.isa = b.isa; isa_ready = true; }  // many ties expected: ranks in the same pass
         run_group(true, g0, sa);
         m = fetch_m();
         st.rounds = 1;
@@ -407,7 +408,7 @@ static void sa_run(tc_ctx *ctx, SaBuffers &b, const u8 *d_text, u64 n, u32 *d_sa
     memcpy(rl.lut, cfg.lut, sizeof rl.lut);
     if (dense && !skeys) TC_FAIL(ctx, TC_ERR_INTERNAL, "dense mode needs the sorted keys");
     if (dense) {
-        if (m > 0) {
+        if (m > 0 && !isa_ready) {
             GroupArgs gi = {};
             gi.keys = skeys; gi.count = (u32)N; gi.vals = sa;
             gi.isa = b.isa; gi.isa_only = 1;

@@ -259,6 +259,7 @@ __global__ __launch_bounds__(256) void keyhist_fix_kernel(const u8 *__restrict__
 //               payload byte; writes L[j] = key low byte; compacts the members of
 //               groups of size >= 2 into the first active set (slot, idx, group).
 //   INIT + isa_only   (dense mode, second pass) rank[sa[j]] = group start, for all j.
+//   INIT + isa        the same ranks written in the first pass (when dense mode is expected).
 //   REFINE      element kk of the sorted active set goes to SA position slot[kk]; tie
 //               <=> equal (group, rank[i+h]); writes SA, L (gathered), the new rank of
 //               every member (dense: isa[idx]; sparse: t_rank[tpos]) and the next set.
@@ -419,16 +420,22 @@ __global__ __launch_bounds__(GRP_NT, 4) void group_kernel(GroupArgs a) {
                 a.isa[a.vals[j]] = g;
             } else {
                 a.L[j] = (u8)(lowb[k >> 2] >> (8 * (k & 3)));
+                const u32 v = a.vals[j];
+                if (a.isa) a.isa[v] = g;   // dense mode expected: ranks in the same pass
                 if (act) {
                     a.out_slot[o] = (u32)j;
-                    a.out_idx[o] = a.vals[j];
+                    a.out_idx[o] = v;
                     a.out_grp[o] = g;
                 }
             }
         } else {
             const u32 i = a.in_idx[k0];
-            a.sa[slot] = i;
-            a.L[slot] = i ? a.text[i - 1] : (u8)0;
+            // dense mode never reads the SA during the rounds: a member that stays tied is
+            // placed (SA, last column) in the round that resolves it
+            if (!(a.isa && act)) {
+                a.sa[slot] = i;
+                a.L[slot] = i ? a.text[i - 1] : (u8)0;
+            }
             u32 tp = 0;
             if (a.isa) a.isa[i] = g;
             else {
