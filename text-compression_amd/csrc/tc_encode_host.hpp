@@ -408,7 +408,7 @@ static void sa_run(tc_ctx *ctx, SaBuffers &b, const u8 *d_text, u64 n, u32 *d_sa
     memcpy(rl.lut, cfg.lut, sizeof rl.lut);
     if (dense && !skeys) TC_FAIL(ctx, TC_ERR_INTERNAL, "dense mode needs the sorted keys");
     if (dense) {
-        if (m > 0 && !isa_ready) {
+        if (!isa_ready) {  // (also with m == 0: the primary index is read from the ranks)
             GroupArgs gi = {};
             gi.keys = skeys; gi.count = (u32)N; gi.vals = sa;
             gi.isa = b.isa; gi.isa_only = 1;
@@ -466,17 +466,30 @@ static void sa_run(tc_ctx *ctx, SaBuffers &b, const u8 *d_text, u64 n, u32 *d_sa
         // dense: the round-0 key buffers are dead; sparse: they hold the sorted keys
         u64 *k2 = dense ? b.k0 : b.sk[0], *k2alt = dense ? b.k1 : b.sk[1];
         u32 *kv = dense ? b.v0 : b.sv[0], *kvalt = dense ? b.v2 : b.sv[1];
-        key2_kernel<<<tc_cdiv(mm, 256), 256, 0, s>>>(b.act[cur][1], b.act[cur][2], rl, mm, hh, k2);
-        TC_LAUNCH_CHECK(ctx);
         RadixPlan p2;
         p2.add_range(0, rbits);
         p2.add_range(32, 32 + rbits);
+        RadixPlanDev pd2;
+        pd2.npass = p2.npass;
+        for (int p = 0; p < p2.npass; p++) { pd2.shift[p] = p2.shift[p]; pd2.mask[p] = p2.mask[p]; }
+        // large rounds: digit histograms on the way; dense: the suffix starts are sorted along
+        // (no gather through the active set afterwards)
+        const bool fuse_hist = mm >= (1u << 16);
+        const bool vals_idx = dense;
+        if (fuse_hist) tc_memset_async(ctx, b.hist, 0, sizeof(u32) * RDX_MAX_PASSES * RDX_BINS);
+        {
+            u32 kgrid = tc_cdiv(mm, 256 * 8);
+            if (kgrid > 8192) kgrid = 8192;
+            if (fuse_hist) key2_kernel<true><<<kgrid, 256, 0, s>>>(b.act[cur][1], b.act[cur][2], rl, mm, hh, k2, vals_idx ? kv : nullptr, pd2, b.hist);
+            else key2_kernel<false><<<kgrid, 256, 0, s>>>(b.act[cur][1], b.act[cur][2], rl, mm, hh, k2, vals_idx ? kv : nullptr, pd2, b.hist);
+        }
+        TC_LAUNCH_CHECK(ctx);
         RadixBuffers r2;
         r2.keys = k2; r2.keys_alt = k2alt; r2.vals = kv; r2.vals_alt = kvalt;
         r2.hist = b.hist; r2.status = b.rstatus;
-        radix_sort_pairs(ctx, r2, mm, p2, /*gen_idx=*/true, false);
+        radix_sort_pairs(ctx, r2, mm, p2, /*gen_idx=*/!vals_idx, /*hist_ready=*/fuse_hist);
         GroupArgs gr = {};
-        gr.keys = r2.keys; gr.count = mm; gr.vals = r2.vals;
+        gr.keys = r2.keys; gr.count = mm; gr.vals = r2.vals; gr.vals_are_idx = vals_idx ? 1 : 0;
         gr.in_slot = b.act[cur][0]; gr.in_idx = b.act[cur][1]; gr.in_tpos = b.act[cur][3];
         gr.isa = dense ? b.isa : nullptr; gr.t_rank = dense ? nullptr : b.t_rank;
         gr.out_slot = b.act[cur ^ 1][0]; gr.out_idx = b.act[cur ^ 1][1];

@@ -274,6 +274,8 @@ struct GroupArgs {
     const u64 *keys;    // sorted keys
     u32 count;
     const u32 *vals;    // INIT: SA.  REFINE: for sorted position kk, index k0 into the in_* arrays
+                        // (vals_are_idx: the suffix start itself, sorted along with the keys)
+    int vals_are_idx;
     const u32 *in_slot; // REFINE: SA position of the kk-th active element (by sorted position)
     const u32 *in_idx;  // REFINE: suffix start, by k0
     const u32 *in_tpos; // REFINE sparse: rank-table position, by k0
@@ -429,7 +431,7 @@ __global__ __launch_bounds__(GRP_NT, 4) void group_kernel(GroupArgs a) {
                 }
             }
         } else {
-            const u32 i = a.in_idx[k0];
+            const u32 i = a.vals_are_idx ? k0 : a.in_idx[k0];
             // dense mode never reads the SA during the rounds: a member that stays tied is
             // placed (SA, last column) in the round that resolves it
             if (!(a.isa && act)) {
@@ -902,15 +904,35 @@ __device__ __forceinline__ u32 rank_of(const RankLookup &r, const u16 *s_lut, u6
 }
 
 // key2[k] = group << 32 | rank[idx + h]
+// HIST: the digit histograms of the sort that follows are built on the way (saves the separate
+// pass over the keys); vals_out (optional) receives a copy of idx to be sorted along.
+template <bool HIST>
 __global__ __launch_bounds__(256) void key2_kernel(const u32 *__restrict__ idx,
                                                    const u32 *__restrict__ grp, RankLookup r, u32 m,
-                                                   u32 h, u64 *__restrict__ keys) {
+                                                   u32 h, u64 *__restrict__ keys, u32 *__restrict__ vals_out,
+                                                   RadixPlanDev plan, u32 *__restrict__ hist) {
     __shared__ u16 s_lut[256];
+    __shared__ u32 s_h[HIST ? RDX_MAX_PASSES * RDX_BINS : 1];
     s_lut[threadIdx.x] = r.lut[threadIdx.x];
+    if (HIST)
+        for (int i = threadIdx.x; i < plan.npass * RDX_BINS; i += 256) s_h[i] = 0;
     __syncthreads();
-    u32 k = blockIdx.x * 256 + threadIdx.x;
-    if (k >= m) return;
-    keys[k] = ((u64)grp[k] << 32) | rank_of(r, s_lut, (u64)idx[k] + h);  // idx + h <= n for a tied suffix
+    for (u64 k = (u64)blockIdx.x * 256 + threadIdx.x; k < m; k += (u64)gridDim.x * 256) {
+        const u32 i = idx[k];
+        const u64 key = ((u64)grp[k] << 32) | rank_of(r, s_lut, (u64)i + h);  // idx + h <= n for a tied suffix
+        keys[k] = key;
+        if (vals_out) vals_out[k] = i;
+        if (HIST)
+            for (int p = 0; p < plan.npass; p++)
+                atomicAdd(&s_h[p * RDX_BINS + (u32)((key >> plan.shift[p]) & plan.mask[p])], 1u);
+    }
+    if (HIST) {
+        __syncthreads();
+        for (int i = threadIdx.x; i < plan.npass * RDX_BINS; i += 256) {
+            const u32 c = s_h[i];
+            if (c) atomicAdd(&hist[i], c);
+        }
+    }
 }
 
 // primary = rank of suffix 0 (its SA position once everything is resolved)
