@@ -1,0 +1,15 @@
+#!/usr/bin/env python3
+"""PCIe-inclusive rate of the host-pointer entry point tc_encode (pageable host buffers in,
+runs out), beside the device-resident tc_encode_dev."""
+import os, sys, time
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "text-compression_amd")); sys.path.insert(0, os.path.join(ROOT, "tests"))
+import numpy as np, textcomp, oracle as O
+n = int(sys.argv[1]) if len(sys.argv) > 1 else 1 << 30
+ctx = textcomp.Context(0)
+t = O.gen_acgtn(0xC3, n)
+for it in range(3):
+    t0 = time.perf_counter(); blk = ctx.encode(t); dt = time.perf_counter() - t0
+    st = ctx.stats()
+    print("tc_encode (host buffers) n=%d: %.1f ms = %.2f GB/s (device part %.1f ms); runs out %.2f GB" % (
+        n, dt * 1e3, n / dt / 1e9, st.ms_total, len(blk["run_count"]) * 6 / 1e9), flush=True)
