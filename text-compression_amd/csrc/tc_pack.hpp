@@ -204,6 +204,8 @@ __global__ __launch_bounds__(UP_NT) void unpack_nib_kernel(UnpackNibArgs a) {
     __shared__ u32 sm[UP_NT / 64 + 1];
     __shared__ u32 s_tile;
     __shared__ u64 s_excl;
+    __shared__ u32 s_cnt[UP_NT * UP_NPT];   // a tile holds at most one run per nibble
+    __shared__ u8 s_val[UP_NT * UP_NPT];
     const int tid = threadIdx.x, lane = lane_id(), w = tid >> 6;
     while (true) {
         if (tid == 0) s_tile = atomicAdd(a.ticket, 1u);
@@ -230,10 +232,12 @@ __global__ __launch_bounds__(UP_NT) void unpack_nib_kernel(UnpackNibArgs a) {
             if (lane == 0) s_excl = e;
         }
         __syncthreads();
-        u64 k = (s_excl >> 31) + (ex & 0xffffu);
+        const u64 kbase = s_excl >> 31;          // first run of this tile
+        u32 kl = ex & 0xffffu;                   // tile-local run index
         u64 e = (s_excl & 0x7fffffffull) + (ex >> 16);
         if ((w0 & 15u) == 14u) e++;  // belongs to the run that starts in the previous unit
         const u32 nextfirst = s_first[tid + 1];
+        // runs are staged tile-locally (count | value << 28 would not hold escaped counts: two arrays)
 #pragma unroll
         for (int p = 0; p < UP_NPT; p++) {
             const u32 code = (u32)((p < 16 ? w0 >> (4 * p) : w1 >> (4 * (p - 16))) & 15u);
@@ -247,11 +251,19 @@ __global__ __launch_bounds__(UP_NT) void unpack_nib_kernel(UnpackNibArgs a) {
                     c = e < a.nesc ? a.esc[e] : 0u;
                     e++;
                 }
-                if (k < a.nruns) {
-                    a.cnt[k] = c;
-                    a.val[k] = (u16)v;
-                }
-                k++;
+                s_cnt[kl] = c;
+                s_val[kl] = (u8)v;
+                kl++;
+            }
+        }
+        __syncthreads();
+        // coalesced write-out of the tile's runs
+        const u32 truns = total & 0xffffu;
+        for (u32 i = tid; i < truns; i += UP_NT) {
+            const u64 k = kbase + i;
+            if (k < a.nruns) {
+                a.cnt[k] = s_cnt[i];
+                a.val[k] = (u16)s_val[i];
             }
         }
         __syncthreads();  // s_first / s_excl reuse
