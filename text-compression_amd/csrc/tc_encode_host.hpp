@@ -191,6 +191,16 @@ static void sa_run(tc_ctx *ctx, SaBuffers &b, const u8 *d_text, u64 n, u32 *d_sa
     if (counts256_out) memcpy(counts256_out, counts, sizeof counts);
     SaConfig cfg;
     sa_choose_config(ctx, counts, n, cfg);
+    if (cfg.sigma_text == 1 && n > 0) {
+        // unary text (a zero-filled buffer, "AAAA..."): the suffixes are ordered by length, no
+        // sort needed (prefix doubling would take log2 n full rounds here)
+        u32 *sa_out = d_sa ? d_sa : b.v1;
+        unary_sa_kernel<<<tc_cdiv(N, 256), 256, 0, s>>>(d_text, (u32)n, sa_out, d_L);
+        TC_LAUNCH_CHECK(ctx);
+        *primary = n;
+        st.sigma = 2; st.rounds = 0; st.radix_launches = 0; st.ms_radix = 0;
+        return;
+    }
 
     // 2. round-0 keys (+ digit histograms), radix sort, groups.
     //    Fast path: sort only the top 8*G key bits globally, then finish_kernel orders the

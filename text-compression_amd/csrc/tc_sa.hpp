@@ -468,6 +468,15 @@ __global__ __launch_bounds__(GRP_NT, 4) void group_kernel(GroupArgs a) {
 #define FIN_WPW 4      // windows per wave
 #define FIN_NT 256
 
+// SA and last column of a text made of one repeated byte: SA = n, n-1, .., 0
+__global__ __launch_bounds__(256) void unary_sa_kernel(const u8 *__restrict__ text, u32 n, u32 *__restrict__ sa,
+                                                        u8 *__restrict__ L) {
+    const u64 j = (u64)blockIdx.x * 256 + threadIdx.x;
+    if (j > n) return;
+    sa[j] = n - (u32)j;
+    L[j] = j < n ? text[0] : (u8)0;   // row n holds suffix 0: the sentinel slot (byte 0 by convention)
+}
+
 // Will the finish pass pay off?  SAMP_N pseudo-random suffixes, their top `topbits` key bits into an
 // LDS hash set: *out = number of samples whose prefix was already present.  On text with heavy
 // repeated contexts (natural language, long runs) a large share of the samples collide and the
