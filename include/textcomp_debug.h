@@ -17,6 +17,10 @@ int tc_dbg_stream_bench(tc_ctx *ctx, uint64_t bytes, int width, int mode, int it
  * device radix sort and returns the mean duration of one pass in ms (HIP events).
  * check != 0: verify the result is sorted and stable (returns TC_ERR_INTERNAL if not). */
 int tc_dbg_sort_bench(tc_ctx *ctx, uint64_t n, int key_bits, int iters, int check, double *ms_per_pass);
+/* The memory pattern of one radix pass alone: 4096-pair tiles read coalesced, written as `bins`
+ * segments per tile, each behind the same segment of the previous tile; xrun > 0: blocks on the
+ * same XCD take tiles in runs of xrun (the pass's XCD-aware order); mean ms per pass. */
+int tc_dbg_scatter_bench(tc_ctx *ctx, uint64_t n, uint32_t bins, uint32_t xrun, int iters, double *ms_per_pass);
 #ifdef __cplusplus
 }
 #endif

@@ -259,6 +259,32 @@ static double dbg_stream_run(tc_ctx *ctx, char *a, char *b, u64 bytes, int mode,
     return moved / (ms * 1e-3) / 1e9;
 }
 
+// memory pattern of one radix pass without any of its work: a tile of 4096 (key, value) pairs is
+// read coalesced and written as `bins` segments, segment d of tile t behind segment d of tile t-1
+// (what the scatter of a pass over uniformly distributed digits looks like to the memory system)
+__global__ __launch_bounds__(256) void dbg_scatter_kernel(const u64 *__restrict__ kin, const u32 *__restrict__ vin,
+                                                          u64 *__restrict__ kout, u32 *__restrict__ vout,
+                                                          u32 ntiles, u32 bins, u32 xrun) {
+    u32 t = blockIdx.x;
+    if (xrun) {  // XCD-aware order: blocks with equal blockIdx % 8 take tiles in runs of `xrun`
+        const u32 x = blockIdx.x & 7u, a = blockIdx.x >> 3, G = ntiles / (8 * xrun);
+        if (a < G * xrun) t = (a / xrun) * (8 * xrun) + x * xrun + (a % xrun);
+    }
+    const u64 base = (u64)t * 4096;
+#pragma unroll
+    for (int k = 0; k < 16; k++) {
+        const u32 e = threadIdx.x + k * 256;
+        const u64 key = kin[base + e];
+        const u32 val = vin[base + e];
+        const u32 d = (u32)(((u64)e * bins) >> 12);
+        u32 lo = (d * 4096u + bins - 1) / bins;            // first element of segment d
+        u32 hi = ((d + 1) * 4096u + bins - 1) / bins;
+        const u64 o = (u64)lo * ntiles + (u64)t * (hi - lo) + (e - lo);
+        kout[o] = key;
+        vout[o] = val;
+    }
+}
+
 __global__ __launch_bounds__(256) void dbg_random_keys_kernel(u64 *keys, u64 n, u64 seed, int key_bits) {
     for (u64 i = (u64)blockIdx.x * 256 + threadIdx.x; i < n; i += (u64)gridDim.x * 256) {
         u64 z = seed + (i + 1) * 0x9E3779B97F4A7C15ull;
@@ -926,6 +952,41 @@ int tc_dbg_stream_bench(tc_ctx *ctx, uint64_t bytes, int width, int mode, int it
     TC_API_END(ctx)
 }
 
+
+int tc_dbg_scatter_bench(tc_ctx *ctx, uint64_t n, uint32_t bins, uint32_t xrun, int iters, double *ms_per_pass) {
+    TC_API_BEGIN(ctx)
+    if (!ms_per_pass || n < 4096 || n > TC_MAX_N || bins < 1 || bins > 4096 || iters < 1)
+        TC_FAIL(ctx, TC_ERR_ARG, "bad argument");
+    const u32 ntiles = (u32)(n / 4096);
+    const u64 m = (u64)ntiles * 4096;
+    u64 *k0 = nullptr, *k1 = nullptr;
+    u32 *v0 = nullptr, *v1 = nullptr;
+    auto carve = [&](Arena &A) {
+        k0 = A.get<u64>(m); k1 = A.get<u64>(m);
+        v0 = A.get<u32>(m); v1 = A.get<u32>(m);
+    };
+    Arena dry(nullptr);
+    carve(dry);
+    tc_ws_reserve(ctx, dry.off);
+    Arena A(ctx->ws);
+    carve(A);
+    hipStream_t s = ctx->stream;
+    tc_memset_async(ctx, k0, 1, m * 8);
+    tc_memset_async(ctx, v0, 1, m * 4);
+    dbg_scatter_kernel<<<ntiles, 256, 0, s>>>(k0, v0, k1, v1, ntiles, bins, xrun);
+    TC_LAUNCH_CHECK(ctx);
+    TC_HIP(ctx, hipEventRecord(ctx->ev[6], s));
+    for (int i = 0; i < iters; i++) {
+        if (i & 1) dbg_scatter_kernel<<<ntiles, 256, 0, s>>>(k0, v0, k1, v1, ntiles, bins, xrun);
+        else dbg_scatter_kernel<<<ntiles, 256, 0, s>>>(k1, v1, k0, v0, ntiles, bins, xrun);
+    }
+    TC_HIP(ctx, hipEventRecord(ctx->ev[7], s));
+    TC_HIP(ctx, hipStreamSynchronize(s));
+    float ms = 0;
+    TC_HIP(ctx, hipEventElapsedTime(&ms, ctx->ev[6], ctx->ev[7]));
+    *ms_per_pass = ms / iters;
+    TC_API_END(ctx)
+}
 
 int tc_dbg_sort_bench(tc_ctx *ctx, uint64_t n, int key_bits, int iters, int check, double *ms_per_pass) {
     TC_API_BEGIN(ctx)
