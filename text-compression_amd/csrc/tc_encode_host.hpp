@@ -439,7 +439,7 @@ static void sa_run(tc_ctx *ctx, SaBuffers &b, const u8 *d_text, u64 n, u32 *d_sa
             radix_sort_pairs(ctx, rt, mm, pt, true, false);
             // large tied sets: bitmap + popcount directory instead of a binary search per lookup,
             // and a directory into the sorted keys for the ranks of untied suffixes
-            const bool accel = m >= (u64)env_int("TC_SA_ACCEL_MIN", 65536);
+            const bool accel = m >= (u64)env_int("TC_SA_ACCEL_MIN", 1 << 20);
             const u32 nwords = (u32)(N / 64 + 1);
             if (accel) tc_memset_async(ctx, b.t_bits, 0, (size_t)nwords * sizeof(u64));
             table_build_kernel<<<tc_cdiv(mm, 256), 256, 0, s>>>(rt.keys, rt.vals, b.act[0][2], mm,
@@ -484,7 +484,7 @@ static void sa_run(tc_ctx *ctx, SaBuffers &b, const u8 *d_text, u64 n, u32 *d_sa
         for (int p = 0; p < p2.npass; p++) { pd2.shift[p] = p2.shift[p]; pd2.mask[p] = p2.mask[p]; }
         // large rounds: digit histograms on the way; dense: the suffix starts are sorted along
         // (no gather through the active set afterwards)
-        const bool fuse_hist = mm >= (1u << 16);
+        const bool fuse_hist = mm >= (1u << 20);
         const bool vals_idx = dense;
         if (fuse_hist) tc_memset_async(ctx, b.hist, 0, sizeof(u32) * RDX_MAX_PASSES * RDX_BINS);
         {
