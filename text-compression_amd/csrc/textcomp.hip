@@ -266,9 +266,10 @@ __global__ __launch_bounds__(256) void dbg_scatter_kernel(const u64 *__restrict_
                                                           u64 *__restrict__ kout, u32 *__restrict__ vout,
                                                           u32 ntiles, u32 bins, u32 xrun) {
     u32 t = blockIdx.x;
-    if (xrun) {  // XCD-aware order: blocks with equal blockIdx % 8 take tiles in runs of `xrun`
-        const u32 x = blockIdx.x & 7u, a = blockIdx.x >> 3, G = ntiles / (8 * xrun);
-        if (a < G * xrun) t = (a / xrun) * (8 * xrun) + x * xrun + (a % xrun);
+    const u32 xr = xrun & 255u;
+    if (xr) {  // XCD-aware order: blocks with equal blockIdx % 8 take tiles in runs of `xr`
+        const u32 x = blockIdx.x & 7u, a = blockIdx.x >> 3, G = ntiles / (8 * xr);
+        if (a < G * xr) t = (a / xr) * (8 * xr) + x * xr + (a % xr);
     }
     const u64 base = (u64)t * 4096;
 #pragma unroll
@@ -279,9 +280,17 @@ __global__ __launch_bounds__(256) void dbg_scatter_kernel(const u64 *__restrict_
         const u32 d = (u32)(((u64)e * bins) >> 12);
         u32 lo = (d * 4096u + bins - 1) / bins;            // first element of segment d
         u32 hi = ((d + 1) * 4096u + bins - 1) / bins;
-        const u64 o = (u64)lo * ntiles + (u64)t * (hi - lo) + (e - lo);
-        kout[o] = key;
-        vout[o] = val;
+        const u64 sbeg = (u64)lo * ntiles + (u64)t * (hi - lo), send = sbeg + (hi - lo);
+        const u64 o = sbeg + (e - lo);
+        const int nt = (int)(xrun >> 8);   // experiment: 1 = all stores non-temporal, 2 = only those into lines this tile fills alone
+        bool knt = nt == 1, vnt = nt == 1;
+        if (nt == 2) {
+            const u64 kl0 = o & ~15ull, vl0 = o & ~31ull;
+            knt = kl0 >= sbeg && kl0 + 16 <= send;
+            vnt = vl0 >= sbeg && vl0 + 32 <= send;
+        }
+        if (knt) __builtin_nontemporal_store(key, kout + o); else kout[o] = key;
+        if (vnt) __builtin_nontemporal_store(val, vout + o); else vout[o] = val;
     }
 }
 
