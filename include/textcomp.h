@@ -191,6 +191,25 @@ int tc_block_pack_dev(tc_ctx *ctx, const tc_block *blk, uint8_t *d_packed, uint6
 int tc_block_unpack_dev(tc_ctx *ctx, const uint8_t *d_packed, uint64_t packed_bytes, uint64_t nruns,
                         uint32_t sigma, uint64_t nesc, tc_block *blk);
 
+/* ---- encoded-block container ------------------------------------------- */
+/* One self-describing byte string per record: a TC_CONTAINER_HEADER-byte little-endian header
+ * (magic "TCBLK01", n, primary, nruns, escapes, payload bytes, 64-bit payload checksum, sigma,
+ * run format id, final MTF list) followed by the packed runs of tc_block_pack_dev.  The reference
+ * has no on-disk / wire format; this is what a caller stores or ships.  Buffers must be 16-byte
+ * aligned.  *bytes: in = capacity, out = bytes used (TC_ERR_CAPACITY: bytes needed, as far as known;
+ * tc_container_bound is always enough).  Reading verifies magic, sizes and the checksum
+ * (TC_ERR_MALFORMED). */
+#define TC_CONTAINER_HEADER 640
+uint64_t tc_container_bound(uint64_t nruns, uint32_t sigma);
+int tc_block_to_container_dev(tc_ctx *ctx, const tc_block *blk /* device runs */, uint8_t *d_out, uint64_t *bytes);
+/* blk->run_count / run_value: device arrays of capacity blk->nruns (TC_ERR_CAPACITY: blk->nruns = needed). */
+int tc_container_to_block_dev(tc_ctx *ctx, const uint8_t *d_in, uint64_t bytes, tc_block *blk);
+/* Host side: text -> container and back in one call each; only the compact form crosses PCIe.
+ * tc_container_info reads n and nruns from a container in HOST memory. */
+int tc_encode_container(tc_ctx *ctx, const uint8_t *text, uint64_t n, uint8_t *out, uint64_t *bytes);
+int tc_container_info(tc_ctx *ctx, const uint8_t *container, uint64_t bytes, uint64_t *n, uint64_t *nruns);
+int tc_decode_container(tc_ctx *ctx, const uint8_t *container, uint64_t bytes, uint8_t *text, uint64_t *n_out);
+
 /* ---- Data.FMIndex -------------------------------------------------------- */
 /* bytestringToBWTToFMIndexB (FMIndex.hs:108-111,162-183): C[c] (seqToCc,
  * FMIndex/Internal.hs:275-316), Occ (seqToOccCK :195-259, kept as rank

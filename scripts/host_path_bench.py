@@ -26,3 +26,9 @@ for it in range(3):
     rc = lib.tc_encode(ctx.handle, C.c_void_p(h_text.data_ptr()), n, C.byref(blk)); dt = time.perf_counter() - t0
     assert rc == 0
     print("tc_encode (pinned host buffers) n=%d: %.1f ms = %.2f GB/s; %d runs" % (n, dt * 1e3, n / dt / 1e9, blk.nruns), flush=True)
+# the container entry point: only the compact form comes back
+for it in range(2):
+    t0 = time.perf_counter(); blob = ctx.encode_container(t); dt = time.perf_counter() - t0
+    print("tc_encode_container (host buffers) n=%d: %.1f ms = %.2f GB/s; container %.3f GB" % (n, dt * 1e3, n / dt / 1e9, len(blob) / 1e9), flush=True)
+t0 = time.perf_counter(); back = ctx.decode_container(blob); dt = time.perf_counter() - t0
+print("tc_decode_container: %.1f ms = %.2f GB/s; exact %s" % (dt * 1e3, n / dt / 1e9, back == t.tobytes()), flush=True)

@@ -657,14 +657,13 @@ uint64_t tc_block_packed_bound(uint64_t nruns, uint32_t sigma) {
     return (((u64)fmt * nruns + 7) & ~7ull) + 8 * nruns + 8;
 }
 
-int tc_block_pack_dev(tc_ctx *ctx, const tc_block *blk, uint8_t *d_packed, uint64_t *packed_bytes,
-                      uint64_t *nesc) {
-    TC_API_BEGIN(ctx)
+static void block_pack_device(tc_ctx *ctx, const tc_block *blk, uint8_t *d_packed, uint64_t *packed_bytes,
+                              uint64_t *nesc) {
     if (!blk || !packed_bytes || !nesc) TC_FAIL(ctx, TC_ERR_ARG, "bad argument");
     const u64 nruns = blk->nruns;
     const u64 cap = *packed_bytes;
     *packed_bytes = 0; *nesc = 0;
-    if (nruns == 0) return TC_OK;
+    if (nruns == 0) return;
     if (!d_packed || !blk->run_count || !blk->run_value) TC_FAIL(ctx, TC_ERR_ARG, "null buffer");
     if (nruns > (u64)TC_MAX_N + 2) TC_FAIL(ctx, TC_ERR_ARG, "too many runs");
     const int fmt = pack_format(blk->sigma);
@@ -707,7 +706,7 @@ int tc_block_pack_dev(tc_ctx *ctx, const tc_block *blk, uint8_t *d_packed, uint6
             TC_HIP(ctx, hipMemcpyAsync(d_packed + body, esc, 4 * ne, hipMemcpyDeviceToDevice, ctx->stream));
             TC_HIP(ctx, hipStreamSynchronize(ctx->stream));
         }
-        return TC_OK;
+        return;
     }
     const int bpr = fmt;
     const u64 body = ((u64)bpr * nruns + 7) & ~7ull;
@@ -730,14 +729,12 @@ int tc_block_pack_dev(tc_ctx *ctx, const tc_block *blk, uint8_t *d_packed, uint6
     *packed_bytes = body + 8 * *nesc;
     if (*nesc > esc_cap)
         TC_FAIL(ctx, TC_ERR_CAPACITY, "packed runs need %llu bytes", (unsigned long long)*packed_bytes);
-    TC_API_END(ctx)
 }
 
-int tc_block_unpack_dev(tc_ctx *ctx, const uint8_t *d_packed, uint64_t packed_bytes, uint64_t nruns,
-                        uint32_t sigma, uint64_t nesc, tc_block *blk) {
-    TC_API_BEGIN(ctx)
+static void block_unpack_device(tc_ctx *ctx, const uint8_t *d_packed, uint64_t packed_bytes, uint64_t nruns,
+                                uint32_t sigma, uint64_t nesc, tc_block *blk) {
     if (!blk || blk->nruns < nruns) TC_FAIL(ctx, TC_ERR_ARG, "bad argument");
-    if (nruns == 0) { blk->nruns = 0; return TC_OK; }
+    if (nruns == 0) { blk->nruns = 0; return; }
     if (!d_packed || !blk->run_count || !blk->run_value) TC_FAIL(ctx, TC_ERR_ARG, "null buffer");
     const int fmt = pack_format(sigma);
     if (fmt == 0) {
@@ -776,7 +773,7 @@ int tc_block_unpack_dev(tc_ctx *ctx, const uint8_t *d_packed, uint64_t packed_by
                     (unsigned long long)nruns, (unsigned long long)nesc);
         blk->nruns = nruns;
         blk->sigma = sigma;
-        return TC_OK;
+        return;
     }
     const int bpr = fmt;
     const u64 body = ((u64)bpr * nruns + 7) & ~7ull;
@@ -793,6 +790,248 @@ int tc_block_unpack_dev(tc_ctx *ctx, const uint8_t *d_packed, uint64_t packed_by
     TC_HIP(ctx, hipStreamSynchronize(ctx->stream));
     blk->nruns = nruns;
     blk->sigma = sigma;
+}
+
+int tc_block_pack_dev(tc_ctx *ctx, const tc_block *blk, uint8_t *d_packed, uint64_t *packed_bytes,
+                      uint64_t *nesc) {
+    TC_API_BEGIN(ctx)
+    block_pack_device(ctx, blk, d_packed, packed_bytes, nesc);
+    TC_API_END(ctx)
+}
+
+int tc_block_unpack_dev(tc_ctx *ctx, const uint8_t *d_packed, uint64_t packed_bytes, uint64_t nruns,
+                        uint32_t sigma, uint64_t nesc, tc_block *blk) {
+    TC_API_BEGIN(ctx)
+    block_unpack_device(ctx, d_packed, packed_bytes, nruns, sigma, nesc, blk);
+    TC_API_END(ctx)
+}
+
+// ====================================================== encoded-block container
+// header (TC_CONTAINER_HEADER bytes, little-endian) + packed runs; SURVEY 8f-4
+struct ContainerHeader {
+    char magic[8];       // "TCBLK01\0"
+    u64 n, primary, nruns, nesc, body_bytes, checksum;
+    u32 sigma, format;
+    i16 final_list[TC_MAX_SIGMA];
+};
+static_assert(sizeof(ContainerHeader) <= TC_CONTAINER_HEADER, "container header layout");
+static const char kContainerMagic[8] = {'T', 'C', 'B', 'L', 'K', '0', '1', 0};
+
+// position-dependent 64-bit checksum of a byte range (16-byte aligned, length a multiple of 4)
+__global__ __launch_bounds__(256) void checksum64_kernel(const u32 *__restrict__ w, u64 nwords, u64 *out) {
+    u64 acc = 0;
+    for (u64 i = (u64)blockIdx.x * 256 + threadIdx.x; i < nwords; i += (u64)gridDim.x * 256) {
+        u64 z = ((u64)w[i] << 32 | (u32)i) + (i >> 32) * 0x9E3779B97F4A7C15ull;
+        z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+        z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+        acc += z ^ (z >> 31);
+    }
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) acc += __shfl_xor(acc, d, 64);
+    if (lane_id() == 0 && acc) atomicAdd((unsigned long long *)out, (unsigned long long)acc);
+}
+static u64 checksum64_device(tc_ctx *ctx, const u8 *d_p, u64 bytes) {
+    u64 *d_sum = ctx->d_scalars + 16;
+    tc_memset_async(ctx, d_sum, 0, sizeof(u64));
+    const u64 nwords = bytes / 4;
+    if (nwords) {
+        u32 grid = tc_cdiv(nwords, 256 * 16);
+        if (grid > 4096) grid = 4096;
+        checksum64_kernel<<<grid, 256, 0, ctx->stream>>>(reinterpret_cast<const u32 *>(d_p), nwords, d_sum);
+        TC_LAUNCH_CHECK(ctx);
+    }
+    tc_d2h(ctx, &ctx->h_scalars[16], d_sum, sizeof(u64));
+    TC_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return ctx->h_scalars[16] ^ (bytes * 0x9E3779B97F4A7C15ull);
+}
+
+uint64_t tc_container_bound(uint64_t nruns, uint32_t sigma) {
+    return TC_CONTAINER_HEADER + tc_block_packed_bound(nruns, sigma);
+}
+
+static void container_write_device(tc_ctx *ctx, const tc_block *blk, u8 *d_out, u64 *bytes) {
+    if (!blk || !bytes) TC_FAIL(ctx, TC_ERR_ARG, "bad argument");
+    const u64 cap = *bytes;
+    *bytes = 0;
+    if (!d_out || ((uintptr_t)d_out & 15)) TC_FAIL(ctx, TC_ERR_ARG, "container buffer must be 16-byte aligned");
+    if (blk->sigma > TC_MAX_SIGMA) TC_FAIL(ctx, TC_ERR_ARG, "bad block");
+    if (cap < TC_CONTAINER_HEADER) {
+        *bytes = tc_container_bound(blk->nruns, blk->sigma);
+        TC_FAIL(ctx, TC_ERR_CAPACITY, "container needs at least %llu bytes", (unsigned long long)*bytes);
+    }
+    ContainerHeader h;
+    memset(&h, 0, sizeof h);
+    memcpy(h.magic, kContainerMagic, 8);
+    h.n = blk->n; h.primary = blk->primary; h.nruns = blk->nruns; h.sigma = blk->sigma;
+    h.format = (u32)pack_format(blk->sigma);
+    for (u32 i = 0; i < blk->sigma; i++) h.final_list[i] = blk->final_list[i];
+    u64 body = cap - TC_CONTAINER_HEADER, nesc = 0;
+    try {
+        block_pack_device(ctx, blk, d_out + TC_CONTAINER_HEADER, &body, &nesc);
+    } catch (const TcFail &f) {
+        if (f.code == TC_ERR_CAPACITY) *bytes = TC_CONTAINER_HEADER + body;
+        throw;
+    }
+    h.nesc = nesc; h.body_bytes = body;
+    h.checksum = checksum64_device(ctx, d_out + TC_CONTAINER_HEADER, body);
+    u8 hdr[TC_CONTAINER_HEADER];
+    memset(hdr, 0, sizeof hdr);
+    memcpy(hdr, &h, sizeof h);
+    tc_h2d(ctx, d_out, hdr, TC_CONTAINER_HEADER);
+    TC_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    *bytes = TC_CONTAINER_HEADER + body;
+}
+
+// parses + validates the header (host copy); returns it
+static ContainerHeader container_header(tc_ctx *ctx, const u8 *d_in, u64 bytes) {
+    if (!d_in || ((uintptr_t)d_in & 15)) TC_FAIL(ctx, TC_ERR_ARG, "container buffer must be 16-byte aligned");
+    if (bytes < TC_CONTAINER_HEADER) TC_FAIL(ctx, TC_ERR_MALFORMED, "container shorter than its header");
+    u8 hdr[TC_CONTAINER_HEADER];
+    tc_d2h(ctx, hdr, d_in, TC_CONTAINER_HEADER);
+    TC_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    ContainerHeader h;
+    memcpy(&h, hdr, sizeof h);
+    if (memcmp(h.magic, kContainerMagic, 8) != 0) TC_FAIL(ctx, TC_ERR_MALFORMED, "not a textcomp container");
+    if (h.n > TC_MAX_N || h.sigma > TC_MAX_SIGMA || h.nruns > (u64)TC_MAX_N + 2 || h.nesc > h.nruns ||
+        h.format != (u32)pack_format(h.sigma) || h.body_bytes != bytes - TC_CONTAINER_HEADER ||
+        (h.n > 0 && (h.primary > h.n || h.nruns == 0)))
+        TC_FAIL(ctx, TC_ERR_MALFORMED, "container header is inconsistent");
+    return h;
+}
+
+static void container_read_device(tc_ctx *ctx, const u8 *d_in, u64 bytes, tc_block *blk) {
+    if (!blk) TC_FAIL(ctx, TC_ERR_ARG, "bad argument");
+    const ContainerHeader h = container_header(ctx, d_in, bytes);
+    if (blk->nruns < h.nruns) {
+        blk->nruns = h.nruns;
+        TC_FAIL(ctx, TC_ERR_CAPACITY, "block needs %llu run slots", (unsigned long long)h.nruns);
+    }
+    if (checksum64_device(ctx, d_in + TC_CONTAINER_HEADER, h.body_bytes) != h.checksum)
+        TC_FAIL(ctx, TC_ERR_MALFORMED, "container checksum mismatch");
+    block_unpack_device(ctx, d_in + TC_CONTAINER_HEADER, h.body_bytes, h.nruns, h.sigma, h.nesc, blk);
+    blk->n = h.n; blk->primary = h.primary; blk->sigma = h.sigma; blk->nruns = h.nruns;
+    for (u32 i = 0; i < h.sigma; i++) blk->final_list[i] = h.final_list[i];
+}
+
+int tc_block_to_container_dev(tc_ctx *ctx, const tc_block *blk, uint8_t *d_out, uint64_t *bytes) {
+    TC_API_BEGIN(ctx)
+    container_write_device(ctx, blk, d_out, bytes);
+    TC_API_END(ctx)
+}
+
+int tc_container_to_block_dev(tc_ctx *ctx, const uint8_t *d_in, uint64_t bytes, tc_block *blk) {
+    TC_API_BEGIN(ctx)
+    container_read_device(ctx, d_in, bytes, blk);
+    TC_API_END(ctx)
+}
+
+int tc_container_info(tc_ctx *ctx, const uint8_t *container, uint64_t bytes, uint64_t *n, uint64_t *nruns) {
+    if (!ctx) return TC_ERR_ARG;
+    try {
+        if (!container || bytes < TC_CONTAINER_HEADER) TC_FAIL(ctx, TC_ERR_MALFORMED, "container shorter than its header");
+        ContainerHeader h;
+        memcpy(&h, container, sizeof h);
+        if (memcmp(h.magic, kContainerMagic, 8) != 0) TC_FAIL(ctx, TC_ERR_MALFORMED, "not a textcomp container");
+        if (n) *n = h.n;
+        if (nruns) *nruns = h.nruns;
+        return TC_OK;
+    } catch (const TcFail &f) {
+        return f.code;
+    }
+}
+
+// host buffers in and out: text -> container.  The copy back is the compact form (an ACGTN record:
+// 0.42 bytes per input byte instead of 4.8 for the raw runs).
+int tc_encode_container(tc_ctx *ctx, const uint8_t *text, uint64_t n, uint8_t *out, uint64_t *bytes) {
+    TC_API_BEGIN(ctx)
+    if (!bytes || n > TC_MAX_N || (n && !text) || !out) TC_FAIL(ctx, TC_ERR_ARG, "bad argument");
+    const u64 cap = *bytes;
+    u8 *d_text = nullptr, *d_out = nullptr;
+    u32 *d_count = nullptr;
+    u16 *d_value = nullptr;
+    int rc = TC_OK;
+    try {
+        const u64 runs_cap = n + 2;
+        TC_HIP(ctx, hipMalloc((void **)&d_text, n + 16));
+        TC_HIP(ctx, hipMalloc((void **)&d_count, (runs_cap + 1) * sizeof(u32)));
+        TC_HIP(ctx, hipMalloc((void **)&d_value, (runs_cap + 1) * sizeof(u16)));
+        tc_block dev;
+        memset(&dev, 0, sizeof dev);
+        dev.nruns = runs_cap; dev.run_count = d_count; dev.run_value = d_value;
+        if (n) {
+            tc_h2d(ctx, d_text, text, n);
+            encode_device(ctx, d_text, n, &dev, runs_cap);
+        } else {
+            dev.nruns = 0;
+        }
+        // the device-side container is sized by what the caller can take, not by the worst case
+        const u64 need_max = tc_container_bound(dev.nruns, dev.sigma);
+        u64 dbytes = cap < need_max ? cap : need_max;
+        if (dbytes < TC_CONTAINER_HEADER) dbytes = TC_CONTAINER_HEADER;
+        TC_HIP(ctx, hipMalloc((void **)&d_out, dbytes + 16));
+        u64 used = dbytes;
+        if (cap < TC_CONTAINER_HEADER) used = 0;   // forces the capacity report
+        try {
+            container_write_device(ctx, &dev, d_out, &used);
+        } catch (const TcFail &f) {
+            *bytes = used;
+            throw;
+        }
+        *bytes = used;
+        tc_d2h(ctx, out, d_out, used);
+        TC_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    } catch (const TcFail &f) {
+        rc = f.code;
+    }
+    (void)hipStreamSynchronize(ctx->stream);
+    if (d_text) (void)hipFree(d_text);
+    if (d_count) (void)hipFree(d_count);
+    if (d_value) (void)hipFree(d_value);
+    if (d_out) (void)hipFree(d_out);
+    if (rc != TC_OK) throw TcFail{rc};
+    TC_API_END(ctx)
+}
+
+// host buffers: container -> text (text must hold the n bytes tc_container_info reports)
+int tc_decode_container(tc_ctx *ctx, const uint8_t *container, uint64_t bytes, uint8_t *text, uint64_t *n_out) {
+    TC_API_BEGIN(ctx)
+    if (!container || !n_out) TC_FAIL(ctx, TC_ERR_ARG, "bad argument");
+    if (bytes < TC_CONTAINER_HEADER) TC_FAIL(ctx, TC_ERR_MALFORMED, "container shorter than its header");
+    u8 *d_in = nullptr, *d_text = nullptr;
+    u32 *d_count = nullptr;
+    u16 *d_value = nullptr;
+    int rc = TC_OK;
+    try {
+        ContainerHeader h0;
+        memcpy(&h0, container, sizeof h0);
+        if (memcmp(h0.magic, kContainerMagic, 8) != 0) TC_FAIL(ctx, TC_ERR_MALFORMED, "not a textcomp container");
+        if (h0.n > TC_MAX_N || h0.nruns > (u64)TC_MAX_N + 2) TC_FAIL(ctx, TC_ERR_MALFORMED, "container header is inconsistent");
+        if (h0.n && !text) TC_FAIL(ctx, TC_ERR_ARG, "null buffer");
+        TC_HIP(ctx, hipMalloc((void **)&d_in, bytes + 16));
+        TC_HIP(ctx, hipMalloc((void **)&d_text, h0.n + 16));
+        TC_HIP(ctx, hipMalloc((void **)&d_count, (h0.nruns + 1) * sizeof(u32)));
+        TC_HIP(ctx, hipMalloc((void **)&d_value, (h0.nruns + 1) * sizeof(u16)));
+        tc_h2d(ctx, d_in, container, bytes);
+        tc_block dev;
+        memset(&dev, 0, sizeof dev);
+        dev.nruns = h0.nruns; dev.run_count = d_count; dev.run_value = d_value;
+        container_read_device(ctx, d_in, bytes, &dev);
+        *n_out = dev.n;
+        if (dev.n) {
+            if (dev.nruns == 0) TC_FAIL(ctx, TC_ERR_MALFORMED, "container holds no runs");
+            decode_device(ctx, &dev, d_text);
+            tc_d2h(ctx, text, d_text, dev.n);
+            TC_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        }
+    } catch (const TcFail &f) {
+        rc = f.code;
+    }
+    (void)hipStreamSynchronize(ctx->stream);
+    if (d_in) (void)hipFree(d_in);
+    if (d_text) (void)hipFree(d_text);
+    if (d_count) (void)hipFree(d_count);
+    if (d_value) (void)hipFree(d_value);
+    if (rc != TC_OK) throw TcFail{rc};
     TC_API_END(ctx)
 }
 

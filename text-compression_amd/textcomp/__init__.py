@@ -230,6 +230,26 @@ class Context:
         self._check(self._lib.tc_decode(self._h, C.byref(b), _ptr(out)))
         return out.tobytes()
 
+    # --------------------------------------------------------- container
+    def encode_container(self, text, cap=None):
+        """text -> one self-describing byte string (header + packed runs); see textcomp.h."""
+        t = _u8(text)
+        n = len(t)
+        cap = int(self._lib.tc_container_bound(n + 2, 257 if n else 0)) if cap is None else int(cap)
+        out = np.empty(max(cap, 1), np.uint8)
+        used = C.c_uint64(cap)
+        self._check(self._lib.tc_encode_container(self._h, _ptr(t), n, _ptr(out), C.byref(used)))
+        return out[:used.value].tobytes()
+
+    def decode_container(self, blob):
+        b = np.frombuffer(bytes(blob), np.uint8)
+        n, nruns = C.c_uint64(), C.c_uint64()
+        self._check(self._lib.tc_container_info(self._h, _ptr(b), len(b), C.byref(n), C.byref(nruns)))
+        out = np.empty(max(n.value, 1), np.uint8)
+        got = C.c_uint64()
+        self._check(self._lib.tc_decode_container(self._h, _ptr(b), len(b), _ptr(out), C.byref(got)))
+        return out[:got.value].tobytes()
+
     # ----------------------------------------------------------- FM-index
     def fm_build(self, text):
         return FMIndexHandle(self, text)

@@ -75,6 +75,12 @@ SYMBOLS = [
     ("tc_block_packed_bound", _U64, [_U64, _U32]),
     ("tc_block_pack_dev", _INT, [_P, C.POINTER(Block), _P, _PU64, _PU64]),
     ("tc_block_unpack_dev", _INT, [_P, _P, _U64, _U64, _U32, _U64, C.POINTER(Block)]),
+    ("tc_container_bound", _U64, [_U64, _U32]),
+    ("tc_block_to_container_dev", _INT, [_P, C.POINTER(Block), _P, _PU64]),
+    ("tc_container_to_block_dev", _INT, [_P, _P, _U64, C.POINTER(Block)]),
+    ("tc_encode_container", _INT, [_P, _P, _U64, _P, _PU64]),
+    ("tc_container_info", _INT, [_P, _P, _U64, _PU64, _PU64]),
+    ("tc_decode_container", _INT, [_P, _P, _U64, _P, _PU64]),
     ("tc_fm_build", _INT, [_P, _P, _U64, C.POINTER(_P)]),
     ("tc_fm_free", None, [_P]),
     ("tc_fm_count", _INT, [_P, _P, _P, _P, _U64, _P]),
