@@ -115,7 +115,7 @@ def main():
     assert rc == 0, rc
     torch.cuda.synchronize()
 
-    # N > 1: the encoded block is packed (nibble stream, ~0.42 bytes per input byte) and gathered on
+    # N > 1: the encoded block becomes a container (header + nibble stream, ~0.42 bytes per input byte), gathered on
     # rank 0, pipelined so that the transfer of record k overlaps the encode of record k+1
     gatherer = None
     packed = None
@@ -138,12 +138,12 @@ def main():
         if gatherer is not None:
             buf = packed[step_no[0] % 2]
             step_no[0] += 1
-            nb, ne = C.c_uint64(pcap), C.c_uint64()
-            rc = lib.tc_block_pack_dev(ctx.handle, C.byref(blk), C.c_void_p(buf.data_ptr()), C.byref(nb), C.byref(ne))
+            nb = C.c_uint64(pcap)       # the block as one self-describing container (header + packed runs)
+            rc = lib.tc_block_to_container_dev(ctx.handle, C.byref(blk), C.c_void_p(buf.data_ptr()), C.byref(nb))
             if rc != 0:
-                raise RuntimeError("tc_block_pack_dev rc=%d: %s" % (rc, lib.tc_last_error(ctx.handle).decode()))
+                raise RuntimeError("tc_block_to_container_dev rc=%d: %s" % (rc, lib.tc_last_error(ctx.handle).decode()))
             payload = buf[:nb.value].cpu() if rehearsal else buf
-            gatherer.submit([nb.value, int(blk.nruns), ne.value, int(blk.primary), int(blk.sigma), n], payload)
+            gatherer.submit([nb.value, int(blk.nruns), 0, int(blk.primary), int(blk.sigma), n], payload)
 
     def fence():
         if gatherer is not None:
@@ -168,6 +168,11 @@ def main():
     if rank == 0 and rehearsal and gatherer is not None:
         last = gatherer.completed[-1]
         assert len(last) == world and all(int(h[0]) == len(p) for h, p in last), "gather shape"
+        for h, p in last:          # every gathered container decodes to a record of the right size
+            got_n, got_runs = C.c_uint64(), C.c_uint64()
+            hb = bytes(p[:640].numpy().tobytes())
+            assert lib.tc_container_info(ctx.handle, hb, len(hb), C.byref(got_n), C.byref(got_runs)) == 0
+            assert got_n.value == n and got_runs.value == int(h[1])
         print("rehearsal: gathered", [(int(h[0]), int(h[1])) for h, _ in last], file=sys.stderr)
     if rank == 0:
         st = ctx.stats()
@@ -198,7 +203,7 @@ def main():
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u8",
             "data": "synthetic",
             "config": {"workload": "%d x %d-byte iid ACGTN record(s) (splitmix64 counter generator), fused BWT->MTF->RLE encode, "
-                                   "in/out resident in HBM%s" % (world, n, ", + RCCL gather of the packed encoded blocks on rank 0 (pipelined)" if world > 1 else ""),
+                                   "in/out resident in HBM%s" % (world, n, ", + RCCL gather of the encoded-block containers on rank 0 (pipelined)" if world > 1 else ""),
                        "record_bytes": n, "records": world, "parallelism": "record-per-gpu x%d" % world},
             "roofline": roof,
             "stages_ms": {"suffix_sort+bwt": round(st.ms_sa, 3), "mtf": round(st.ms_mtf, 3), "rle": round(st.ms_rle, 3),

@@ -5,8 +5,8 @@ gather of the encoded blocks on rank 0.
 Design for xGMI (point-to-point links, no switch): a root gather posted as one batch
 of sends/receives lets rank 0 ingest on all of its links at once, where a ring would be
 bound by a single link.  Two further measures keep the exchange off the critical path:
-  * the payload is the PACKED run format of include/textcomp.h (an ACGTN record: a nibble
-    stream of ~0.53 bytes per run instead of 6), and
+  * the payload is the block's CONTAINER of include/textcomp.h (header + packed runs; an ACGTN
+    record: a nibble stream of ~0.53 bytes per run instead of 6), and
   * the exchange is pipelined: `submit()` only posts the transfers (double-buffered),
     so the gather of record k overlaps the encode of record k+1; `drain()` completes
     everything still in flight.
