@@ -318,7 +318,7 @@ __global__ __launch_bounds__(RDX_NT, RDX_LB_WAVES(PERSIST)) void radix_pass_kern
         u32 tot_real = tot;
         if (tid == 255) tot_real = tot - (RDX_TILE - valid);
         u64 *st = status + (u64)tile * RDX_BINS + tid;
-        if (!SPLIT && tid < RDX_BINS)
+        if (!SPLIT && tid < RDX_BINS && !(shift_raw & 0x10000))  // DIAGNOSTIC bit8: no status stores
             lb_store(st, (tile == 0 ? LB_FLAG_INC : LB_FLAG_AGG) | (u64)tot_real);
         u32 dtot;
         u32 dbase = block_excl_sum<RDX_NT>(tid < RDX_BINS ? tot : 0u, s_scan, &dtot);
@@ -334,7 +334,7 @@ __global__ __launch_bounds__(RDX_NT, RDX_LB_WAVES(PERSIST)) void radix_pass_kern
                 excl = tile_offs[(u64)tile * RDX_BINS + tid];  // already includes bucket base
                 s_gbase[tid] = excl - dbase;
             } else {
-                if (tile > 0) {
+                if (tile > 0 && !(shift_raw & 0x8000)) {  // DIAGNOSTIC bit7: no look-back
                     i64 t = (i64)tile - 1;
                     u32 spins = 0;
                     bool done = false;
@@ -364,7 +364,7 @@ __global__ __launch_bounds__(RDX_NT, RDX_LB_WAVES(PERSIST)) void radix_pass_kern
                         t -= consumed;
                         if (consumed == 0) __builtin_amdgcn_s_sleep(1);
                     }
-                    lb_store(st, LB_FLAG_INC | (u64)(excl + tot_real));
+                    if (!(shift_raw & 0x10000)) lb_store(st, LB_FLAG_INC | (u64)(excl + tot_real));
                 }
                 s_gbase[tid] = bucket_base[tid] + excl - dbase;
             }

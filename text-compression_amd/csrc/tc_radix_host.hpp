@@ -6,6 +6,9 @@
 // one 4096-pair tile per block, tile ids from an atomic ticket, per-digit look-back one
 // status word per round trip.  Batched look-back, persistent blocks with prefetch, a split
 // histogram/scan/scatter pass and sharded tickets were measured and were not faster.
+#ifndef RDX_LBB
+#define RDX_LBB 1   // status words fetched per look-back round trip
+#endif
 template <bool GEN>
 static void radix_launch_pass(tc_ctx *ctx, RadixBuffers &b, u32 n, int shift, u32 mask,
                               const u32 *bucket_base, u32 tiles, u32 *ticket,
@@ -16,12 +19,12 @@ static void radix_launch_pass(tc_ctx *ctx, RadixBuffers &b, u32 n, int shift, u3
 #endif
     shift |= xcd_group ? 0x200000 : 0x100000;  // XCD-grouped tile order, or the single safe counter
     if (kg) {
-        radix_pass_kernel<true, false, 1, false, true><<<tiles, RDX_NT, 0, s>>>(
+        radix_pass_kernel<true, false, RDX_LBB, false, true><<<tiles, RDX_NT, 0, s>>>(
             b.keys, b.vals, b.keys_alt, b.vals_alt, n, shift, mask, bucket_base, b.status, ticket,
             ctx->d_err, nullptr, text, *kg);
     } else {
         RadixKeyGen none = {};
-        radix_pass_kernel<GEN, false, 1, false, false><<<tiles, RDX_NT, 0, s>>>(
+        radix_pass_kernel<GEN, false, RDX_LBB, false, false><<<tiles, RDX_NT, 0, s>>>(
             b.keys, b.vals, b.keys_alt, b.vals_alt, n, shift, mask, bucket_base, b.status, ticket,
             ctx->d_err, nullptr, nullptr, none);
     }
