@@ -488,8 +488,9 @@ static void sa_run(tc_ctx *ctx, SaBuffers &b, const u8 *d_text, u64 n, u32 *d_sa
         const bool vals_idx = dense;
         if (fuse_hist) tc_memset_async(ctx, b.hist, 0, sizeof(u32) * RDX_MAX_PASSES * RDX_BINS);
         {
-            u32 kgrid = tc_cdiv(mm, 256 * 8);
-            if (kgrid > 8192) kgrid = 8192;
+            // one lookup per thread for small sets (latency-bound); coarser when histograms are kept
+            u32 kgrid = fuse_hist ? tc_cdiv(mm, 256 * 8) : tc_cdiv(mm, 256);
+            if (fuse_hist && kgrid > 8192) kgrid = 8192;
             if (fuse_hist) key2_kernel<true><<<kgrid, 256, 0, s>>>(b.act[cur][1], b.act[cur][2], rl, mm, hh, k2, vals_idx ? kv : nullptr, pd2, b.hist);
             else key2_kernel<false><<<kgrid, 256, 0, s>>>(b.act[cur][1], b.act[cur][2], rl, mm, hh, k2, vals_idx ? kv : nullptr, pd2, b.hist);
         }
