@@ -248,6 +248,27 @@ __global__ __launch_bounds__(RDX_NT, RDX_LB_WAVES(PERSIST)) void radix_pass_kern
             }
             __syncthreads();
             const u32 gslots = KG_PRE + RDX_TILE + kg.P * kg.s;
+            if (kg.s == 3 && kg.P == 6 && kg.w == 8) {
+                // the DNA-like configuration, unrolled: 3 symbols per 8-bit field, 6 fields
+                const u32 B = kg.B;
+                for (u32 q = tid; q < gslots; q += RDX_NT)
+                    k_g[q] = (u16)((k_c[q] * B + k_c[q + 1]) * B + k_c[q + 2]);
+                __syncthreads();
+#pragma unroll
+                for (int k = 0; k < RDX_ITEMS; k++) {
+                    const u32 p = wofs + k * 64 + l;
+                    if (base + p < n) {
+                        const u32 q = KG_PRE + p;
+                        const u64 hi = ((u64)k_g[q] << 24) | ((u64)k_g[q + 3] << 16) | ((u64)k_g[q + 6] << 8) | (u64)k_g[q + 9];
+                        const u64 lo = ((u64)k_g[q + 12] << 8) | (u64)k_g[q + 15];
+                        key[k] = (hi << 32) | (lo << 16) | (u64)k_r[q - 1];
+                        val[k] = (u32)base + p;
+                    } else {
+                        key[k] = ~0ull;
+                        val[k] = 0;
+                    }
+                }
+            } else {
             for (u32 q = tid; q < gslots; q += RDX_NT) {
                 u32 g = 0;
                 for (u32 j = 0; j < kg.s; j++) g = g * kg.B + k_c[q + j];
@@ -271,6 +292,7 @@ __global__ __launch_bounds__(RDX_NT, RDX_LB_WAVES(PERSIST)) void radix_pass_kern
                     key[k] = ~0ull;
                     val[k] = 0;
                 }
+            }
             }
             __syncthreads();
         }
