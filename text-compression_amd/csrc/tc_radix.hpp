@@ -231,12 +231,18 @@ __global__ __launch_bounds__(RDX_NT, RDX_LB_WAVES(PERSIST)) void radix_pass_kern
                     }
                 }
                 u32 cw[8], rw[4];
+                if (p0 >= 0 && p0 + 16 <= (i64)nt) {  // interior unit: no range checks per byte
 #pragma unroll
-                for (int q = 0; q < 16; q += 2) {
-                    i64 pa = p0 + q, pb = p0 + q + 1;
-                    u32 ca = (pa >= 0 && pa < (i64)nt) ? (u32)s_klut[raw[q]] : 0u;
-                    u32 cb = (pb >= 0 && pb < (i64)nt) ? (u32)s_klut[raw[q + 1]] : 0u;
-                    cw[q >> 1] = ca | (cb << 16);
+                    for (int q = 0; q < 16; q += 2)
+                        cw[q >> 1] = (u32)s_klut[raw[q]] | ((u32)s_klut[raw[q + 1]] << 16);
+                } else {
+#pragma unroll
+                    for (int q = 0; q < 16; q += 2) {
+                        i64 pa = p0 + q, pb = p0 + q + 1;
+                        u32 ca = (pa >= 0 && pa < (i64)nt) ? (u32)s_klut[raw[q]] : 0u;
+                        u32 cb = (pb >= 0 && pb < (i64)nt) ? (u32)s_klut[raw[q + 1]] : 0u;
+                        cw[q >> 1] = ca | (cb << 16);
+                    }
                 }
 #pragma unroll
                 for (int q = 0; q < 4; q++)
