@@ -13,6 +13,7 @@
 // All distinct suffixes have distinct (infinite) keys, so the result is the unique
 // order the reference's sort produces, whatever its algorithm.
 #pragma once
+#include <type_traits>
 #include "tc_radix.hpp"
 
 #define SA_NT 256
@@ -556,22 +557,33 @@ __global__ __launch_bounds__(FIN_NT) void finish_kernel(FinishArgs a) {
     // all chunks of this wave are requested up front (one round trip instead of one per window)
     u64 kk[FIN_WPW + 1];
     u32 vv[FIN_WPW + 1];
+    // interior waves (all but the last few): no range tests anywhere below
+    const bool interior = ws0 + (u64)(FIN_WPW + 1) * 64 <= N;
+    if (interior) {
 #pragma unroll
-    for (int c = 0; c <= FIN_WPW; c++) {
-        const u64 pos = ws0 + (u64)c * 64 + l;
-        kk[c] = pos < N ? a.keys[pos] : ~0ull;
-        vv[c] = pos < N ? a.sa_in[pos] : 0u;
+        for (int c = 0; c <= FIN_WPW; c++) {
+            const u64 pos = ws0 + (u64)c * 64 + l;
+            kk[c] = a.keys[pos];
+            vv[c] = a.sa_in[pos];
+        }
+    } else {
+#pragma unroll
+        for (int c = 0; c <= FIN_WPW; c++) {
+            const u64 pos = ws0 + (u64)c * 64 + l;
+            kk[c] = pos < N ? a.keys[pos] : ~0ull;
+            vv[c] = pos < N ? a.sa_in[pos] : 0u;
+        }
     }
     u64 tprev = ws0 > 0 ? (a.keys[ws0 - 1] >> a.tshift) : 0;  // wave-uniform
     bool hasprev = ws0 > 0;
 
-#pragma unroll
-    for (int win = 0; win < FIN_WPW; win++) {
+    auto window = [&](auto full_tag, const int win) {
+        constexpr bool FULL = decltype(full_tag)::value;
         const u64 ws = ws0 + (u64)win * 64;
-        if (ws >= N) break;
+        if (!FULL && ws >= N) return;
         const u64 kA = kk[win], kB = kk[win + 1];
         const u32 vA = vv[win], vB = vv[win + 1];
-        const bool inA = ws + l < N, inB = ws + 64 + l < N;
+        const bool inA = FULL || ws + l < N, inB = FULL || ws + 64 + l < N;
         const u64 tA = kA >> a.tshift, tB = kB >> a.tshift;
         // head flags
         u64 upA = __shfl_up(tA, 1, 64);
@@ -681,6 +693,13 @@ __global__ __launch_bounds__(FIN_NT) void finish_kernel(FinishArgs a) {
         }
         tprev = lastA;
         hasprev = true;
+    };
+    if (interior) {
+#pragma unroll
+        for (int win = 0; win < FIN_WPW; win++) window(std::true_type{}, win);
+    } else {
+#pragma unroll
+        for (int win = 0; win < FIN_WPW; win++) window(std::false_type{}, win);
     }
 }
 
