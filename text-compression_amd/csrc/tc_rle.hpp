@@ -211,15 +211,23 @@ __global__ __launch_bounds__(RLE_NT, 4) void rle_encode_u16_kernel(U16Acc acc, R
             s_edge[1] = tbase + RLE16_TILE < N ? (u32)acc(tbase + RLE16_TILE) : 0x10000u;
         }
         stage_syms<RLE16_TILE, RLE_NT>(acc, tbase, N, s_x);  // ends with a barrier
+        // interior tiles (neither the first nor the last): every position is valid and has both
+        // neighbours, the stream-edge tests drop out (block-uniform)
+        const bool inner = tile > 0 && tbase + RLE16_TILE < N;
         auto item = [&](int sub, int k, u64 &hbk, u64 &pbk, u32 &xv) {
             const u32 p = (u32)sub * RLE16_SUBTILE + (u32)w * 512 + (u32)k * 64 + (u32)l;
-            const u64 j = tbase + p;
-            const bool in = j < N;
             xv = (u32)(u16)s_x[p];
             const u32 xp = p > 0 ? (u32)(u16)s_x[p - 1] : s_edge[0];
             const u32 xn = p + 1 < RLE16_TILE ? (u32)(u16)s_x[p + 1] : s_edge[1];
-            hbk = __ballot(in && (j == 0 || xp != xv));
-            pbk = __ballot(in && (j == N - 1 || xn != xv));
+            if (inner) {
+                hbk = __ballot(xp != xv);
+                pbk = __ballot(xn != xv);
+            } else {
+                const u64 j = tbase + p;
+                const bool in = j < N;
+                hbk = __ballot(in && (j == 0 || xp != xv));
+                pbk = __ballot(in && (j == N - 1 || xn != xv));
+            }
         };
         // ---- phase 1: aggregates per (sub-tile, wave) segment of 512 values
 #pragma unroll
