@@ -254,8 +254,8 @@ __global__ __launch_bounds__(RDX_NT, RDX_LB_WAVES(PERSIST)) void radix_pass_kern
             }
             __syncthreads();
             const u32 gslots = KG_PRE + RDX_TILE + kg.P * kg.s;
-            if (kg.s == 3 && kg.P == 6 && kg.w == 8) {
-                // the DNA-like configuration, unrolled: 3 symbols per 8-bit field, 6 fields
+            if (kg.s == 3 && kg.w == 8 && kg.P <= 7) {
+                // the DNA-like configurations, unrolled: 3 symbols per 8-bit field, up to 7 fields
                 const u32 B = kg.B;
                 for (u32 q = tid; q < gslots; q += RDX_NT)
                     k_g[q] = (u16)((k_c[q] * B + k_c[q + 1]) * B + k_c[q + 2]);
@@ -265,9 +265,18 @@ __global__ __launch_bounds__(RDX_NT, RDX_LB_WAVES(PERSIST)) void radix_pass_kern
                     const u32 p = wofs + k * 64 + l;
                     if (base + p < n) {
                         const u32 q = KG_PRE + p;
-                        const u64 hi = ((u64)k_g[q] << 24) | ((u64)k_g[q + 3] << 16) | ((u64)k_g[q + 6] << 8) | (u64)k_g[q + 9];
-                        const u64 lo = ((u64)k_g[q + 12] << 8) | (u64)k_g[q + 15];
-                        key[k] = (hi << 32) | (lo << 16) | (u64)k_r[q - 1];
+                        u64 kk;
+                        if (kg.P == 6) {  // (wave-uniform)
+                            const u64 hi = ((u64)k_g[q] << 24) | ((u64)k_g[q + 3] << 16) | ((u64)k_g[q + 6] << 8) | (u64)k_g[q + 9];
+                            const u64 lo = ((u64)k_g[q + 12] << 8) | (u64)k_g[q + 15];
+                            kk = (hi << 32) | (lo << 16);
+                        } else {
+                            kk = 0;
+#pragma unroll
+                            for (int f = 0; f < 7; f++)
+                                if (f < (int)kg.P) kk |= (u64)k_g[q + 3 * f] << (56 - 8 * f);
+                        }
+                        key[k] = kk | (u64)k_r[q - 1];
                         val[k] = (u32)base + p;
                     } else {
                         key[k] = ~0ull;
