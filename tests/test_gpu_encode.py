@@ -265,6 +265,27 @@ def test_oversize_buckets_become_tied_groups(ctx, seed, n, poly, copies, unit, m
     assert blk["run_count"].tolist() == ec.tolist() and blk["run_value"].tolist() == ev.tolist()
 
 
+@pytest.mark.parametrize("env", [{"TC_XCD_GROUP": "0"}, {"TC_KEYGEN_FUSED": "0"}, {"TC_KB_ONEHIST": "0"},
+                                 {"TC_KEYGEN_FUSED": "0", "TC_KB_ONEHIST": "0"}, {"TC_SA_SAMPLE": "0"},
+                                 {"TC_SA_GLOBAL_PASSES": "3"}, {"TC_SA_GLOBAL_PASSES": "5"}, {"TC_SA_FIELDS": "4"},
+                                 {"TC_GRID_SCALE_PCT": "7"}, {"TC_RADIX_DIGIT_BITS": "5"}],
+                         ids=lambda e: ",".join("%s=%s" % kv for kv in e.items()))
+def test_path_selectors(ctx, env, monkeypatch):
+    """Every alternative the host logic can take (single ticket counter = the retry path after a
+    look-back timeout, unfused key building, other pass counts / key widths, tiny persistent grids,
+    narrower digits) gives the same suffix array and the same encoded block."""
+    texts = [O.gen_acgtn(21, 1 << 20).tobytes(), O.gen_ascii(22, 300000).tobytes(),
+             _genome_like(5, 150000, 400, 30, 100)]
+    ref = [(ctx.suffix_array(t), ctx.encode(t)) for t in texts]
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    for t, (sa0, blk0) in zip(texts, ref):
+        assert np.array_equal(ctx.suffix_array(t), sa0)
+        blk = ctx.encode(t)
+        assert blk["primary"] == blk0["primary"] and blk["final_list"].tolist() == blk0["final_list"].tolist()
+        assert np.array_equal(blk["run_count"], blk0["run_count"]) and np.array_equal(blk["run_value"], blk0["run_value"])
+
+
 def _pack_roundtrip(ctx, sigma, counts, vals):
     import ctypes as C
     import torch
