@@ -286,6 +286,33 @@ def test_path_selectors(ctx, env, monkeypatch):
         assert np.array_equal(blk["run_count"], blk0["run_count"]) and np.array_equal(blk["run_value"], blk0["run_value"])
 
 
+def test_fuzz_small_texts(ctx):
+    """300 pseudo-random short texts (alphabets of 1-40 byte values, copied fragments, runs) against the
+    oracle: suffix array, fused block and its decode."""
+    rng = np.random.default_rng(20261003)
+    for it in range(300):
+        n = int(rng.integers(1, 2500))
+        sigma = int(rng.integers(1, 41))
+        alpha = rng.permutation(256)[:sigma]
+        t = alpha[rng.integers(0, sigma, n)]
+        for _ in range(int(rng.integers(0, 6))):          # repeats: copy a fragment somewhere else
+            ln = int(rng.integers(1, max(2, n // 3)))
+            a0, b0 = int(rng.integers(0, n - ln + 1)), int(rng.integers(0, n - ln + 1))
+            t[b0:b0 + ln] = t[a0:a0 + ln].copy()
+        if rng.random() < 0.3:                            # a long run
+            ln = int(rng.integers(1, n + 1)); a0 = int(rng.integers(0, n - ln + 1))
+            t[a0:a0 + ln] = t[a0]
+        tb = t.astype(np.uint8).tobytes()
+        assert ctx.suffix_array(tb).tolist() == O.suffix_array(tb).tolist(), (it, n, sigma)
+        blk = ctx.encode(tb)
+        _, eprim, sym = _expect_bwt(tb)
+        eidx, efl = O.mtf_encode_arr(sym)
+        ec, ev = O.rle_encode_u32_arr(eidx)
+        assert blk["primary"] == eprim and blk["final_list"].tolist() == efl.tolist(), (it, n, sigma)
+        assert blk["run_count"].tolist() == ec.tolist() and blk["run_value"].tolist() == ev.tolist(), (it, n, sigma)
+        assert ctx.decode(blk) == tb
+
+
 def _pack_roundtrip(ctx, sigma, counts, vals):
     import ctypes as C
     import torch
