@@ -354,23 +354,22 @@ __global__ __launch_bounds__(MTF_NT) void mtf_nib_apply_kernel(Acc acc, u64 N,
     const u64 base = (u64)blockIdx.x * MTF_TILE;
     nib_stage(acc, N, base, s_lut, s_code);
     __syncthreads();
+    // true incoming list of this lane's chunk: tile's incoming list, then the
+    // block-local prefix applied to it.  Wave 0 recovers the tile's list FIRST (a global round
+    // trip) while the other waves already summarise their chunks; the barriers of the block scan
+    // publish it.
+    __shared__ u64 s_in;
+    if (FASTIN && threadIdx.x < 64) {
+        u64 l0 = NIB_IDENT;
+        bool ok = nib_list_before(acc, base, sigma, s_lut, &l0);
+        if (threadIdx.x == 0) {
+            s_in = l0;
+            if (!ok) atomicOr(flag, 1u);
+        }
+    }
     NibSumm mine = nib_chunk_summary(s_code);
     NibSumm agg;
     NibSumm exc = nib_block_excl(mine, s_w, &agg);
-    // true incoming list of this lane's chunk: tile's incoming list, then the
-    // block-local prefix applied to it
-    __shared__ u64 s_in;
-    if (FASTIN) {
-        if (threadIdx.x < 64) {
-            u64 l0 = NIB_IDENT;
-            bool ok = nib_list_before(acc, base, sigma, s_lut, &l0);
-            if (threadIdx.x == 0) {
-                s_in = l0;
-                if (!ok) atomicOr(flag, 1u);
-            }
-        }
-        __syncthreads();
-    }
     NibSumm in = nib_combine(NibSumm{FASTIN ? s_in : t_perm[blockIdx.x], 0u}, exc);
     u64 list = in.perm;
     u32 *cw = reinterpret_cast<u32 *>(s_code + threadIdx.x * MTF_STRIDE);
