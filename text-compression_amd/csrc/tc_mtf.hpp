@@ -367,26 +367,50 @@ __global__ __launch_bounds__(MTF_NT) void mtf_nib_apply_kernel(Acc acc, u64 N,
             if (!ok) atomicOr(flag, 1u);
         }
     }
-    NibSumm mine = nib_chunk_summary(s_code);
-    NibSumm agg;
-    NibSumm exc = nib_block_excl(mine, s_w, &agg);
-    NibSumm in = nib_combine(NibSumm{FASTIN ? s_in : t_perm[blockIdx.x], 0u}, exc);
-    u64 list = in.perm;
+    // ONE full pass per chunk, from the identity list.  The rank of a symbol that already occurred
+    // in the chunk does not depend on the incoming list (everything in front of it was used since),
+    // so it is final; only the FIRST occurrence of each code (at most sigma per chunk) needs the
+    // true list -- those are recorded (code, position) and replayed below, a handful of steps
+    // instead of a second pass over all 64 symbols.
     u32 *cw = reinterpret_cast<u32 *>(s_code + threadIdx.x * MTF_STRIDE);
+    NibSumm mine{NIB_IDENT, 0u};
+    u64 ev_code = 0, ev_pos0 = 0, ev_pos1 = 0;
+    u32 nev = 0;
 #pragma unroll 4
     for (int q = 0; q < MTF_CH / 4; q++) {
         u32 wv = cw[q], ov = 0;
 #pragma unroll
         for (int b = 0; b < 4; b++) {
-            u32 c = (wv >> (8 * b)) & 0xff;
-            u32 pos = 0;
+            const u32 c = (wv >> (8 * b)) & 0xff;
             if (c != 0xFF) {
-                pos = nib_find(list, c);
-                list = nib_front(list, pos, c);
+                const u32 pos = nib_find(mine.perm, c);
+                mine.perm = nib_front(mine.perm, pos, c);
+                ov |= pos << (8 * b);
+                if (!((mine.mask >> c) & 1u)) {
+                    mine.mask |= 1u << c;
+                    ev_code |= (u64)c << (4 * nev);
+                    const u64 pp = (u64)(4 * q + b);
+                    if (nev < 8) ev_pos0 |= pp << (8 * nev);
+                    else ev_pos1 |= pp << (8 * (nev - 8));
+                    nev++;
+                }
             }
-            ov |= pos << (8 * b);
         }
-        cw[q] = ov;  // indices overwrite the codes in place
+        cw[q] = ov;  // ranks overwrite the codes in place
+    }
+    NibSumm agg;
+    NibSumm exc = nib_block_excl(mine, s_w, &agg);
+    NibSumm in = nib_combine(NibSumm{FASTIN ? s_in : t_perm[blockIdx.x], 0u}, exc);
+    {
+        u64 list = in.perm;
+        u8 *cb = s_code + threadIdx.x * MTF_STRIDE;
+        for (u32 e = 0; e < nev; e++) {
+            const u32 c = (u32)(ev_code >> (4 * e)) & 15u;
+            const u32 pp = (u32)((e < 8 ? ev_pos0 >> (8 * e) : ev_pos1 >> (8 * (e - 8))) & 255u);
+            const u32 pos = nib_find(list, c);
+            list = nib_front(list, pos, c);
+            cb[pp] = (u8)pos;
+        }
     }
     __syncthreads();
     if ((((uintptr_t)(idx + base)) & 3) == 0) {
