@@ -772,16 +772,27 @@ __global__ __launch_bounds__(GM_NT) void mtf_gm_kernel(Acc acc, GmArgs a) {
         }
         lst[d] = v;
     }
+    // (APPLY) the rank of a symbol that already occurred in the chunk does not depend on the
+    // incoming list, so pass 1 writes it at once; first occurrences keep their code and are
+    // flagged in `firsts` (bit p of word p / 32) for the replay of pass 2
     u32 nseen = 0;
+    u32 firsts[GM_CH / 32] = {};
     for (u32 q4 = 0; q4 < GM_CH / 4; q4++) {
         const u32 wv = cw[q4];
+        u32 ov = wv;
 #pragma unroll
         for (int b = 0; b < 4; b++) {
             if (4 * q4 + b < nvalid) {
                 const u32 r = gm_step(lst, (wv >> (8 * b)) & 0xffu, ls);
-                if (r >= nseen) nseen++;
+                if (r >= nseen) {
+                    nseen++;
+                    if (APPLY) firsts[q4 >> 3] |= 1u << (((q4 & 7u) << 2) + b);
+                } else if (APPLY) {
+                    ov = (ov & ~(0xffu << (8 * b))) | (r << (8 * b));
+                }
             }
         }
+        if (APPLY) cw[q4] = ov;
     }
     wave_fence();
     u8 *wave_lists = reinterpret_cast<u8 *>(s_list + (size_t)(w * 64) * ls);
@@ -821,15 +832,18 @@ __global__ __launch_bounds__(GM_NT) void mtf_gm_kernel(Acc acc, GmArgs a) {
     }
     gm_wave_pass<ROWS, true>(S, Sd, wave_lists, ls, nseen, sigma, s_in + w * 256, s_new + w * 256);
     wave_fence();
-    // pass 2: replay from the true incoming list; ranks overwrite the codes
-    for (u32 q4 = 0; q4 < GM_CH / 4; q4++) {
-        const u32 wv = cw[q4];
-        u32 ov = 0;
+    // pass 2: only the first occurrences are replayed from the true incoming list
+    {
+        u8 *cb = s_code + (size_t)tid * GM_STRIDE;
 #pragma unroll
-        for (int b = 0; b < 4; b++) {
-            if (4 * q4 + b < nvalid) ov |= gm_step(lst, (wv >> (8 * b)) & 0xffu, ls) << (8 * b);
+        for (int wd = 0; wd < GM_CH / 32; wd++) {
+            u32 m = firsts[wd];
+            while (m) {
+                const u32 p = 32u * wd + (u32)__builtin_ctz(m);
+                m &= m - 1;
+                cb[p] = (u8)gm_step(lst, (u32)cb[p], ls);
+            }
         }
-        cw[q4] = ov;
     }
     __syncthreads();
     if ((((uintptr_t)(a.idx + base)) & 15) == 0) {
