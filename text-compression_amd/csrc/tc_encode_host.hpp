@@ -595,9 +595,11 @@ static void mtf_lane_launch(tc_ctx *ctx, Acc acc, u64 N, const Alphabet &al, u16
 }
 
 // seqToMTF on the device.  counts257 (host) may be null: then it is measured here.
+// d_idx8 (optional): for sigma <= 16 the indices are written THERE, one byte each (*used8 = true)
 template <class Acc>
 static void mtf_encode_device(tc_ctx *ctx, Arena &A, Acc acc, u64 N, const u32 *counts257,
-                              u16 *d_idx, i16 *final_list, u32 *sigma, bool dry) {
+                              u16 *d_idx, i16 *final_list, u32 *sigma, bool dry, u8 *d_idx8 = nullptr,
+                              bool *used8 = nullptr) {
     const u32 tiles = tc_cdiv(N, MTF_TILE);
     const u32 chunks = tc_cdiv(N, MTFG_CH);
     u32 *d_counts = A.get<u32>(260);
@@ -624,7 +626,8 @@ static void mtf_encode_device(tc_ctx *ctx, Arena &A, Acc acc, u64 N, const u32 *
         if (env_int("TC_MTF_FASTIN", 1) != 0) {
             u32 *flag = reinterpret_cast<u32 *>(ctx->d_scalars + 15);
             tc_memset_async(ctx, flag, 0, sizeof(u64));
-            mtf_nib_apply_kernel<Acc, true><<<tiles, MTF_NT, 0, s>>>(acc, N, lut, t_perm, d_idx, al.sigma, flag);
+            if (d_idx8) mtf_nib_apply_kernel<Acc, true, u8><<<tiles, MTF_NT, 0, s>>>(acc, N, lut, t_perm, d_idx8, al.sigma, flag);
+            else mtf_nib_apply_kernel<Acc, true><<<tiles, MTF_NT, 0, s>>>(acc, N, lut, t_perm, d_idx, al.sigma, flag);
             TC_LAUNCH_CHECK(ctx);
             mtf_nib_final_kernel<Acc><<<1, 64, 0, s>>>(acc, N, lut, al.sigma, t_perm + tiles, flag);
             TC_LAUNCH_CHECK(ctx);
@@ -638,13 +641,15 @@ static void mtf_encode_device(tc_ctx *ctx, Arena &A, Acc acc, u64 N, const u32 *
             TC_LAUNCH_CHECK(ctx);
             mtf_nib_scan_kernel<<<1, MTF_NT, 0, s>>>(t_perm, t_mask, tiles);
             TC_LAUNCH_CHECK(ctx);
-            mtf_nib_apply_kernel<Acc, false><<<tiles, MTF_NT, 0, s>>>(acc, N, lut, t_perm, d_idx, al.sigma, nullptr);
+            if (d_idx8) mtf_nib_apply_kernel<Acc, false, u8><<<tiles, MTF_NT, 0, s>>>(acc, N, lut, t_perm, d_idx8, al.sigma, nullptr);
+            else mtf_nib_apply_kernel<Acc, false><<<tiles, MTF_NT, 0, s>>>(acc, N, lut, t_perm, d_idx, al.sigma, nullptr);
             TC_LAUNCH_CHECK(ctx);
             tc_d2h(ctx, &ctx->h_scalars[8], t_perm + tiles, sizeof(u64));
             TC_HIP(ctx, hipStreamSynchronize(s));
         }
         u64 perm = ctx->h_scalars[8];
         for (u32 i = 0; i < al.sigma; i++) final_list[i] = al.sym_of_code[(perm >> (4 * i)) & 15];
+        if (used8) *used8 = d_idx8 != nullptr;
     } else {
         Lut16 lut;
         for (int v = 0; v < 257; v++) lut.v[v] = al.code_of_sym[v];
@@ -675,7 +680,7 @@ static void mtf_encode_device(tc_ctx *ctx, Arena &A, Acc acc, u64 N, const u32 *
 template <class Acc, class SymT>
 static void rle_encode_device(tc_ctx *ctx, Arena &A, Acc acc, u64 N, u32 *d_counts, SymT *d_syms,
                               u64 cap, u64 *total, bool dry) {
-    const bool idx_stream = std::is_same<Acc, U16Acc>::value;
+    const bool idx_stream = std::is_same<Acc, U16Acc>::value || std::is_same<Acc, U8Acc>::value;
     const u32 tiles = tc_cdiv(N, idx_stream ? RLE16_TILE : RLE_TILE);
     u64 *status = A.get<u64>(2 * (size_t)tiles + 4);
     if (dry) return;
@@ -687,9 +692,13 @@ static void rle_encode_device(tc_ctx *ctx, Arena &A, Acc acc, u64 N, u32 *d_coun
     a.scalars = ctx->d_scalars; a.err = ctx->d_err;
     a.diag = env_int("TC_RLE_DIAG", 0);
     if constexpr (std::is_same<Acc, U16Acc>::value) {
-        u32 grid = tc_persistent_grid_for(ctx, rle_encode_u16_kernel, RLE_NT, 2);
+        u32 grid = tc_persistent_grid_for(ctx, rle_encode_idx_kernel<u16>, RLE_NT, 2);
         if (grid > tiles) grid = tiles;
-        rle_encode_u16_kernel<<<grid, RLE_NT, 0, ctx->stream>>>(acc, a);
+        rle_encode_idx_kernel<u16><<<grid, RLE_NT, 0, ctx->stream>>>(acc.v, a);
+    } else if constexpr (std::is_same<Acc, U8Acc>::value) {
+        u32 grid = tc_persistent_grid_for(ctx, rle_encode_idx_kernel<u8>, RLE_NT, 2);
+        if (grid > tiles) grid = tiles;
+        rle_encode_idx_kernel<u8><<<grid, RLE_NT, 0, ctx->stream>>>(acc.v, a);
     } else {
         u32 grid = tc_persistent_grid_for(ctx, rle_encode_kernel<Acc, SymT>, RLE_NT, 2);
         if (grid > tiles) grid = tiles;
@@ -727,12 +736,19 @@ static void encode_device(tc_ctx *ctx, const u8 *d_text, u64 n, tc_block *out, u
             for (int b = 0; b < 256; b++) counts257[1 + b] = counts[b];
         }
         BwtAcc acc{d_L, (i64)primary};
+        // small alphabets: the index stream between the two stages is one byte per symbol (the
+        // same buffer, half used)
+        bool idx8 = false;
         mtf_encode_device<BwtAcc>(ctx, A, acc, N, dry ? nullptr : counts257, d_idx,
-                                  out->final_list, &sigma, dry);
+                                  out->final_list, &sigma, dry, reinterpret_cast<u8 *>(d_idx), &idx8);
         if (!dry) TC_HIP(ctx, hipEventRecord(ctx->ev[2], s));
-        U16Acc iacc{d_idx};
-        rle_encode_device<U16Acc, u16>(ctx, A, iacc, N, out->run_count, out->run_value, cap,
-                                       &total, dry);
+        if (idx8) {
+            U8Acc iacc{reinterpret_cast<const u8 *>(d_idx)};
+            rle_encode_device<U8Acc, u16>(ctx, A, iacc, N, out->run_count, out->run_value, cap, &total, dry);
+        } else {
+            U16Acc iacc{d_idx};
+            rle_encode_device<U16Acc, u16>(ctx, A, iacc, N, out->run_count, out->run_value, cap, &total, dry);
+        }
         if (!dry) TC_HIP(ctx, hipEventRecord(ctx->ev[3], s));
         if (A.off < end_sa) A.off = end_sa;
     };

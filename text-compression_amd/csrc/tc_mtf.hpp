@@ -32,6 +32,10 @@ struct U16Acc {  // plain integers (MTF index stream); never Nothing
     const u16 *v;
     __device__ __forceinline__ int operator()(u64 j) const { return (int)v[j]; }
 };
+struct U8Acc {   // MTF index stream of a small alphabet (fused encode: ranks < 16), one byte each
+    const u8 *v;
+    __device__ __forceinline__ int operator()(u64 j) const { return (int)v[j]; }
+};
 // value of a staged int16 slot as the accessor would have returned it
 template <class Acc>
 __device__ __forceinline__ int staged_value(i16 raw) { return (int)raw; }
@@ -340,11 +344,11 @@ __global__ __launch_bounds__(MTF_NT) void mtf_nib_scan_kernel(u64 *t_perm, u32 *
 
 // FASTIN: the tile's incoming list is recovered in-kernel by nib_list_before (no summary /
 // scan launches); `flag` is raised when that fails and the host reruns the 3-kernel path.
-template <class Acc, bool FASTIN>
+template <class Acc, bool FASTIN, class OT = u16>
 __global__ __launch_bounds__(MTF_NT) void mtf_nib_apply_kernel(Acc acc, u64 N,
                                                                 Lut8 lut,
                                                                 const u64 *__restrict__ t_perm,
-                                                                u16 *__restrict__ idx, u32 sigma,
+                                                                OT *__restrict__ idx, u32 sigma,
                                                                 u32 *flag) {
     __shared__ __attribute__((aligned(16))) u8 s_code[MTF_NT * MTF_STRIDE];
     __shared__ u8 s_lut[260];
@@ -413,17 +417,38 @@ __global__ __launch_bounds__(MTF_NT) void mtf_nib_apply_kernel(Acc acc, u64 N,
         }
     }
     __syncthreads();
+    if constexpr (sizeof(OT) == 1) {
+        // byte stream (fused encode): 16 ranks per store, straight from the LDS image
+        if ((((uintptr_t)(idx + base)) & 15) == 0) {
+            uint4 *o = reinterpret_cast<uint4 *>(idx + base);
+            for (u32 g = threadIdx.x; g < MTF_TILE / 16; g += MTF_NT) {
+                const u32 p = 16 * g;
+                const u32 *sc = reinterpret_cast<const u32 *>(s_code + (p / MTF_CH) * MTF_STRIDE + (p % MTF_CH));
+                if (base + p + 16 <= N) {
+                    o[g] = make_uint4(sc[0], sc[1], sc[2], sc[3]);
+                } else {
+                    const u8 *sb = reinterpret_cast<const u8 *>(sc);
+                    for (u32 q = 0; q < 16; q++)
+                        if (base + p + q < N) idx[base + p + q] = (OT)sb[q];
+                }
+            }
+        } else {
+            for (u32 p = threadIdx.x; p < MTF_TILE; p += MTF_NT)
+                if (base + p < N) idx[base + p] = (OT)s_code[(p / MTF_CH) * MTF_STRIDE + (p % MTF_CH)];
+        }
+        return;
+    }
     if ((((uintptr_t)(idx + base)) & 3) == 0) {
         u32 *o32 = reinterpret_cast<u32 *>(idx + base);
         for (u32 c = threadIdx.x; c < MTF_TILE / 2; c += MTF_NT) {
             const u32 p = 2 * c;
             const u8 *sc = s_code + (p / MTF_CH) * MTF_STRIDE + (p % MTF_CH);
             if (base + p + 2 <= N) o32[c] = (u32)sc[0] | ((u32)sc[1] << 16);
-            else if (base + p < N) idx[base + p] = (u16)sc[0];
+            else if (base + p < N) idx[base + p] = (OT)sc[0];
         }
     } else {
         for (u32 p = threadIdx.x; p < MTF_TILE; p += MTF_NT)
-            if (base + p < N) idx[base + p] = (u16)s_code[(p / MTF_CH) * MTF_STRIDE + (p % MTF_CH)];
+            if (base + p < N) idx[base + p] = (OT)s_code[(p / MTF_CH) * MTF_STRIDE + (p % MTF_CH)];
     }
 }
 

@@ -189,12 +189,14 @@ __global__ __launch_bounds__(RLE_NT, 4) void rle_encode_kernel(Acc acc, RleArgs 
 #undef RLE16_TILE
 #define RLE16_TILE (RLE16_SUB * RLE16_SUBTILE)
 
-__global__ __launch_bounds__(RLE_NT, 4) void rle_encode_u16_kernel(U16Acc acc, RleArgs a) {
+// IT = u16 (any index stream) or u8 (fused encode of a small alphabet: half the bytes in)
+template <class IT>
+__global__ __launch_bounds__(RLE_NT, 4) void rle_encode_idx_kernel(const IT *__restrict__ src, RleArgs a) {
     constexpr int NW = RLE_NT / 64, NSEG = RLE16_SUB * NW;
     __shared__ u32 s_wh[NSEG], s_ws[NSEG];
     __shared__ u64 s_pref[2];
     __shared__ u32 s_tile, s_edge[2];
-    __shared__ __attribute__((aligned(16))) i16 s_x[RLE16_TILE];
+    __shared__ __attribute__((aligned(16))) IT s_x[RLE16_TILE];
     const int tid = threadIdx.x, w = tid >> 6, l = tid & 63;
     const u64 N = a.N;
     const u32 ntiles = (u32)((N + RLE16_TILE - 1) / RLE16_TILE);
@@ -207,18 +209,34 @@ __global__ __launch_bounds__(RLE_NT, 4) void rle_encode_u16_kernel(U16Acc acc, R
         if (tile >= ntiles) break;
         const u64 tbase = (u64)tile * RLE16_TILE;
         if (tid == 0) {  // values just outside the tile; 0x10000 = impossible value (forces head / tail)
-            s_edge[0] = tbase > 0 ? (u32)acc(tbase - 1) : 0x10000u;
-            s_edge[1] = tbase + RLE16_TILE < N ? (u32)acc(tbase + RLE16_TILE) : 0x10000u;
+            s_edge[0] = tbase > 0 ? (u32)src[tbase - 1] : 0x10000u;
+            s_edge[1] = tbase + RLE16_TILE < N ? (u32)src[tbase + RLE16_TILE] : 0x10000u;
         }
-        stage_syms<RLE16_TILE, RLE_NT>(acc, tbase, N, s_x);  // ends with a barrier
+        {   // stage the tile, 16 bytes per lane per load
+            constexpr u32 PER = 16 / sizeof(IT);
+            const IT *tsrc = src + tbase;
+            if ((((uintptr_t)tsrc) & 15) == 0) {
+                for (u32 c = tid; c < RLE16_TILE / PER; c += RLE_NT) {
+                    const u64 p0 = tbase + (u64)c * PER;
+                    if (p0 + PER <= N) {
+                        *reinterpret_cast<uint4 *>(s_x + c * PER) = *reinterpret_cast<const uint4 *>(tsrc + (u64)c * PER);
+                    } else {
+                        for (u32 q = 0; q < PER; q++) s_x[c * PER + q] = p0 + q < N ? tsrc[(u64)c * PER + q] : (IT)0;
+                    }
+                }
+            } else {
+                for (u32 c = tid; c < RLE16_TILE; c += RLE_NT) s_x[c] = tbase + c < N ? tsrc[c] : (IT)0;
+            }
+            __syncthreads();
+        }
         // interior tiles (neither the first nor the last): every position is valid and has both
         // neighbours, the stream-edge tests drop out (block-uniform)
         const bool inner = tile > 0 && tbase + RLE16_TILE < N;
         auto item = [&](int sub, int k, u64 &hbk, u64 &pbk, u32 &xv) {
             const u32 p = (u32)sub * RLE16_SUBTILE + (u32)w * 512 + (u32)k * 64 + (u32)l;
-            xv = (u32)(u16)s_x[p];
-            const u32 xp = p > 0 ? (u32)(u16)s_x[p - 1] : s_edge[0];
-            const u32 xn = p + 1 < RLE16_TILE ? (u32)(u16)s_x[p + 1] : s_edge[1];
+            xv = (u32)s_x[p];
+            const u32 xp = p > 0 ? (u32)s_x[p - 1] : s_edge[0];
+            const u32 xn = p + 1 < RLE16_TILE ? (u32)s_x[p + 1] : s_edge[1];
             if (inner) {
                 hbk = __ballot(xp != xv);
                 pbk = __ballot(xn != xv);
