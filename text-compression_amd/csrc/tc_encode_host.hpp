@@ -283,7 +283,8 @@ static void sa_run(tc_ctx *ctx, SaBuffers &b, const u8 *d_text, u64 n, u32 *d_sa
                          /*xcd_group=*/!ctx->safe_tickets && env_int("TC_XCD_GROUP", 1) != 0);
     };
     const int rbits = ceil_log2_u64(N);
-    const int keybits = (int)(cfg.P * cfg.w);
+    int keybits = (int)(cfg.P * cfg.w);
+    const u32 P_full = cfg.P;   // fields chosen for the full path (every field is a pass there)
     u32 *sa = va;
     const u64 *skeys = nullptr;
     const u64 *tkeys = nullptr;
@@ -320,6 +321,18 @@ static void sa_run(tc_ctx *ctx, SaBuffers &b, const u8 *d_text, u64 n, u32 *d_sa
             hopeless = st.sample_dups > SAMP_N / 10;
         }
         if (keybits - topbits <= 32 && !hopeless) {
+            // fields beyond the globally sorted ones cost no pass here (the finish pass ranks by all
+            // remaining bits at once), so take as many as fit: fewer suffixes stay tied
+            if (env_int("TC_SA_FIELDS", 0) == 0) {
+                u32 pf = (u32)((topbits + 32) / (int)cfg.w);
+                if (pf > 56 / cfg.w) pf = 56 / cfg.w;
+                if (pf > cfg.P) {
+                    cfg.P = pf;
+                    cfg.h0 = cfg.P * cfg.s;
+                    keybits = (int)(cfg.P * cfg.w);
+                    h_start = cfg.h0;
+                }
+            }
             RadixPlan plan;
             plan.add_range(64 - topbits, 64);
             RadixBuffers rb;
@@ -394,6 +407,10 @@ static void sa_run(tc_ctx *ctx, SaBuffers &b, const u8 *d_text, u64 n, u32 *d_sa
         }
     }
     if (!have_groups) {
+        cfg.P = P_full;
+        cfg.h0 = cfg.P * cfg.s;
+        keybits = (int)(cfg.P * cfg.w);
+        h_start = cfg.h0;
         RadixPlan plan;
         plan.add_range(64 - keybits, 64);
         RadixBuffers rb;

@@ -270,6 +270,10 @@ __global__ __launch_bounds__(RDX_NT, RDX_LB_WAVES(PERSIST)) void radix_pass_kern
                             const u64 hi = ((u64)k_g[q] << 24) | ((u64)k_g[q + 3] << 16) | ((u64)k_g[q + 6] << 8) | (u64)k_g[q + 9];
                             const u64 lo = ((u64)k_g[q + 12] << 8) | (u64)k_g[q + 15];
                             kk = (hi << 32) | (lo << 16);
+                        } else if (kg.P == 7) {
+                            const u64 hi = ((u64)k_g[q] << 24) | ((u64)k_g[q + 3] << 16) | ((u64)k_g[q + 6] << 8) | (u64)k_g[q + 9];
+                            const u64 lo = ((u64)k_g[q + 12] << 16) | ((u64)k_g[q + 15] << 8) | (u64)k_g[q + 18];
+                            kk = (hi << 32) | (lo << 8);
                         } else {
                             kk = 0;
 #pragma unroll
