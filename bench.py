@@ -210,7 +210,7 @@ def main():
                           "rounds": int(st.rounds), "m": [int(st.m[i]) for i in range(st.rounds)],
                           "passes": [int(st.passes[i]) for i in range(st.rounds)], "runs": int(st.runs)},
         }
-        if not a.no_cpu_baseline:
+        if not a.no_cpu_baseline and world == 1:   # the CPU port is timed at N = 1 only
             out["cpu_baseline"] = cpu_baseline(min(a.cpu_sample, n), seed)
         print(json.dumps(out), flush=True)
     if world > 1:
