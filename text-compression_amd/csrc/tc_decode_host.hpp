@@ -52,24 +52,80 @@ __device__ __forceinline__ int ibwt_sym_of_row(const u32 *s_c, const i16 *s_sym,
     return (int)s_sym[lo];
 }
 
-// splitter q = row q*S walks to the next splitter row
+// Splitter q walks to the next splitter row (independent walks, one per lane) and records what it
+// passes: the symbols of its segment go to seg + q * IBWT_SEGCAP, their
+// number to seglen[q].  Flags: bit 0 = the segment is longer than IBWT_SEGCAP (re-walked later by
+// ibwt_walk2_kernel), bit 1 = a Nothing row other than row 0 was met (an error only if the segment
+// turns out to lie on the chain of row e).
+#define IBWT_SEGCAP 2048
 __global__ __launch_bounds__(256) void ibwt_walk1_kernel(const u32 *__restrict__ spos, u32 N, u32 K,
                                                          u32 *__restrict__ nxt,
-                                                         u32 *__restrict__ dist) {
+                                                         u32 *__restrict__ dist, CTable ct,
+                                                         u8 *__restrict__ seg, u32 *__restrict__ seglen,
+                                                         u8 *__restrict__ segflag, u32 force_rewalk) {
+    __shared__ u32 s_c[260];
+    __shared__ i16 s_sym[260];
+    for (int i = threadIdx.x; i < 260; i += 256) {
+        s_c[i] = ct.c[i];
+        s_sym[i] = ct.sym[i];
+    }
+    __syncthreads();
     u32 q = blockIdx.x * 256 + threadIdx.x;
     if (q >= K) return;
     u32 r = ibwt_split_row(q), steps = 0;
     if (r >= N) {  // the last, partial block may not hold its splitter row: inert slot
         nxt[q] = q;
         dist[q] = 0;
+        seglen[q] = 0;
+        segflag[q] = 0;
         return;
     }
-    do {
-        r = spos[r];
+    u8 *out = seg + (u64)q * IBWT_SEGCAP;
+    u32 word = 0;
+    uint4 w4 = make_uint4(0, 0, 0, 0);
+    u32 emitted = 0, flag = force_rewalk ? 1u : 0u;
+    // the load of the NEXT row is issued before this row's symbol is looked up and stored, so the
+    // lookup hides behind the (dependent, random) load; the one load past the last row is harmless
+    r = spos[r];
+    for (;;) {
         steps++;
-    } while (!ibwt_is_splitter(r) && steps <= N);
+        const u32 rn = spos[r];
+        if (r != 0) {
+            const int sym = ibwt_sym_of_row(s_c, s_sym, ct.sigma, r);
+            if (sym < 0) flag |= 2u;
+            if (emitted < IBWT_SEGCAP) {
+                word |= (u32)(u8)sym << (8 * (emitted & 3u));
+                if ((emitted & 3u) == 3u) {   // sixteen symbols per store
+                    const u32 k4 = (emitted >> 2) & 3u;
+                    if (k4 == 0) w4.x = word;
+                    else if (k4 == 1) w4.y = word;
+                    else if (k4 == 2) w4.z = word;
+                    else {
+                        w4.w = word;
+                        reinterpret_cast<uint4 *>(out)[emitted >> 4] = w4;
+                    }
+                    word = 0;
+                }
+            } else {
+                flag |= 1u;
+            }
+            emitted++;
+        }
+        if (ibwt_is_splitter(r) || steps > N) break;
+        r = rn;
+    }
+    if (emitted < IBWT_SEGCAP && (emitted & 15u)) {   // the last, partial group of sixteen
+        const u32 k4 = (emitted >> 2) & 3u;             // words already complete in w4: k4
+        if (k4 == 0) w4.x = word;
+        else if (k4 == 1) w4.y = word;
+        else if (k4 == 2) w4.z = word;
+        else w4.w = word;
+        reinterpret_cast<uint4 *>(out)[emitted >> 4] = w4;
+    }
     nxt[q] = r / IBWT_S;
     dist[q] = steps;
+    seglen[q] = emitted;
+    segflag[q] = (u8)flag;
 }
 
 // keep splitter 0's real successor aside and make it the terminal of the chain
@@ -98,12 +154,13 @@ __global__ void ibwt_len_kernel(const u32 *nxt, const u32 *dist, u64 *scalars, u
     scalars[6] = (u64)d0 + (n0 == 0 ? 0u : dist[n0]);
 }
 
+// second walk, only for on-chain segments that did not fit their buffer: bytes at final offsets
 __global__ __launch_bounds__(256) void ibwt_walk2_kernel(const u32 *__restrict__ spos, u32 N, u32 K,
                                                          const u32 *__restrict__ nxt,
                                                          const u32 *__restrict__ dist,
                                                          const u64 *__restrict__ scalars,
                                                          CTable ct, u8 *__restrict__ text,
-                                                         u32 *err) {
+                                                         const u8 *__restrict__ segflag, u32 *err) {
     __shared__ u32 s_c[260];
     __shared__ i16 s_sym[260];
     for (int i = threadIdx.x; i < 260; i += 256) {
@@ -113,6 +170,7 @@ __global__ __launch_bounds__(256) void ibwt_walk2_kernel(const u32 *__restrict__
     __syncthreads();
     u32 q = blockIdx.x * 256 + threadIdx.x;
     if (q >= K) return;
+    if (!(segflag[q] & 1u)) return;     // copied from its buffer by ibwt_copy_kernel
     if (q != 0 && nxt[q] != 0) return;  // not on row e's chain
     const u32 Lc = (u32)scalars[6];
     u32 p = (q == 0) ? 0u : Lc - dist[q];
@@ -130,6 +188,31 @@ __global__ __launch_bounds__(256) void ibwt_walk2_kernel(const u32 *__restrict__
     }
 }
 
+// every splitter on row e's chain copies its recorded segment to its final offset (one wave per
+// splitter, 64 bytes per step)
+__global__ __launch_bounds__(256) void ibwt_copy_kernel(u32 K, const u32 *__restrict__ nxt,
+                                                        const u32 *__restrict__ dist,
+                                                        const u64 *__restrict__ scalars,
+                                                        const u8 *__restrict__ seg,
+                                                        const u32 *__restrict__ seglen,
+                                                        const u8 *__restrict__ segflag,
+                                                        u8 *__restrict__ text, u32 *err) {
+    const u32 q = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (q >= K) return;
+    if (q != 0 && nxt[q] != 0) return;  // not on row e's chain
+    const u32 fl = segflag[q];
+    if (fl & 2u) {
+        if (lane_id() == 0) atomicOr(err, 0x200u);  // fromJust Nothing (BWT/Internal.hs:195)
+        return;
+    }
+    if (fl & 1u) return;                // too long for its buffer: ibwt_walk2_kernel
+    const u32 Lc = (u32)scalars[6];
+    const u32 p0 = (q == 0) ? 0u : Lc - dist[q];
+    const u32 len = seglen[q];
+    const u8 *src = seg + (u64)q * IBWT_SEGCAP;
+    for (u32 i = lane_id(); i < len; i += 64) text[p0 + i] = src[i];
+}
+
 #endif  // __HIPCC__
 
 // Inverse BWT of an accessor stream; d_text receives *n_out bytes (<= N).
@@ -138,7 +221,8 @@ static void ibwt_device(tc_ctx *ctx, Arena &A, Acc acc, u64 N, const u32 *counts
                         u64 *n_out, bool dry) {
     const u32 K = tc_cdiv(N, IBWT_S);
     u32 *d_counts = A.get<u32>(260);
-    u64 *k0 = A.get<u64>(N);
+    // (k0 doubles as the segment record buffer after the sort: K * IBWT_SEGCAP bytes)
+    u64 *k0 = A.get<u64>(N > (u64)K * (IBWT_SEGCAP / 8) ? N : (u64)K * (IBWT_SEGCAP / 8));
     u64 *k1 = A.get<u64>(N);
     u32 *v0 = A.get<u32>(N);
     u32 *v1 = A.get<u32>(N);
@@ -146,6 +230,8 @@ static void ibwt_device(tc_ctx *ctx, Arena &A, Acc acc, u64 N, const u32 *counts
     u64 *rstatus = A.get<u64>(radix_status_words(N));
     u32 *nx[2] = {A.get<u32>(K + 1), A.get<u32>(K + 1)};
     u32 *ds[2] = {A.get<u32>(K + 1), A.get<u32>(K + 1)};
+    u32 *seglen = A.get<u32>(K + 1);
+    u8 *segflag = A.get<u8>(K + 1);
     if (dry) return;
     hipStream_t s = ctx->stream;
     u32 local[257];
@@ -178,8 +264,11 @@ static void ibwt_device(tc_ctx *ctx, Arena &A, Acc acc, u64 N, const u32 *counts
     rb.hist = hist; rb.status = rstatus;
     radix_sort_pairs(ctx, rb, (u32)N, plan, /*gen_idx=*/true, /*hist_ready=*/false);
     const u32 *spos = rb.vals;
-    // 2. splitter walks, chain ranking, output walks
-    ibwt_walk1_kernel<<<tc_cdiv(K, 256), 256, 0, s>>>(spos, (u32)N, K, nx[0], ds[0]);
+    // the sort keys are dead: k0 now holds the segment records (K * IBWT_SEGCAP ~ 8 N bytes)
+    u8 *seg = reinterpret_cast<u8 *>(k0);
+    // 2. splitter walks (recording the symbols passed), chain ranking, copy-out
+    ibwt_walk1_kernel<<<tc_cdiv(K, 256), 256, 0, s>>>(spos, (u32)N, K, nx[0], ds[0], ct, seg, seglen, segflag,
+                                                     (u32)env_int("TC_IBWT_REWALK", 0));
     TC_LAUNCH_CHECK(ctx);
     ibwt_terminal_kernel<<<1, 1, 0, s>>>(nx[0], ds[0], ctx->d_scalars);
     TC_LAUNCH_CHECK(ctx);
@@ -191,8 +280,11 @@ static void ibwt_device(tc_ctx *ctx, Arena &A, Acc acc, u64 N, const u32 *counts
     }
     ibwt_len_kernel<<<1, 1, 0, s>>>(nx[cur], ds[cur], ctx->d_scalars, ctx->d_err);
     TC_LAUNCH_CHECK(ctx);
+    ibwt_copy_kernel<<<tc_cdiv(K, 4), 256, 0, s>>>(K, nx[cur], ds[cur], ctx->d_scalars, seg, seglen, segflag,
+                                                  d_text, ctx->d_err);
+    TC_LAUNCH_CHECK(ctx);
     ibwt_walk2_kernel<<<tc_cdiv(K, 256), 256, 0, s>>>(spos, (u32)N, K, nx[cur], ds[cur],
-                                                     ctx->d_scalars, ct, d_text, ctx->d_err);
+                                                     ctx->d_scalars, ct, d_text, segflag, ctx->d_err);
     TC_LAUNCH_CHECK(ctx);
     tc_d2h(ctx, &ctx->h_scalars[6], ctx->d_scalars + 6, sizeof(u64));
     TC_HIP(ctx, hipStreamSynchronize(s));
