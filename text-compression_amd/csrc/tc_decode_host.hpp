@@ -359,33 +359,31 @@ template <class SymT>
 static void rle_decode_device(tc_ctx *ctx, Arena &A, const u32 *d_counts, const SymT *d_syms,
                               u64 nruns, bool has_nothing, SymT *d_out, u64 cap, u64 *N_out,
                               bool dry) {
-    const u64 tiles = tc_cdiv(nruns, SCAN_TILE);
-    u64 *len = A.get<u64>(nruns + 1);
-    u64 *offs = A.get<u64>(nruns + 1);
-    u64 *tsum = A.get<u64>(tiles + 2);
+    const u32 ntiles = tc_cdiv(nruns, RLD_TILE);
+    u64 *status = A.get<u64>((size_t)ntiles + 4);
     const u32 huge_cap = (u32)(cap / RLE_HUGE + 2);
     HugeRun *huge = A.get<HugeRun>(huge_cap);
     u32 *nhuge = A.get<u32>(4);
     if (dry) return;
     hipStream_t s = ctx->stream;
     tc_memset_async(ctx, nhuge, 0, 4 * sizeof(u32));
-    rle_len_kernel<SymT><<<tc_cdiv(nruns, 256), 256, 0, s>>>(d_counts, d_syms, nruns, has_nothing, len);
-    TC_LAUNCH_CHECK(ctx);
-    scan64_reduce_kernel<<<(u32)tiles, SCAN_NT, 0, s>>>(len, nruns, tsum);
-    TC_LAUNCH_CHECK(ctx);
-    scan64_spine_kernel<<<1, 1024, 0, s>>>(tsum, tiles);
-    TC_LAUNCH_CHECK(ctx);
-    scan64_down_kernel<<<(u32)tiles, SCAN_NT, 0, s>>>(len, nruns, tsum, offs);
-    TC_LAUNCH_CHECK(ctx);
-    tc_d2h(ctx, &ctx->h_scalars[7], tsum + tiles, sizeof(u64));
-    TC_HIP(ctx, hipStreamSynchronize(s));
-    *N_out = ctx->h_scalars[7];
-    if (*N_out > cap) return;  // caller reports TC_ERR_CAPACITY
-    rle_fill_kernel<SymT><<<tc_cdiv(nruns, 256), 256, 0, s>>>(offs, d_counts, d_syms, nruns,
-                                                              has_nothing, cap, d_out, huge, nhuge, huge_cap);
+    tc_memset_async(ctx, status, 0, ((size_t)ntiles + 4) * sizeof(u64));
+    tc_memset_async(ctx, ctx->d_scalars + 7, 0, sizeof(u64));
+    RleDecArgs a;
+    a.counts = d_counts; a.syms = d_syms; a.nruns = nruns; a.has_nothing = has_nothing ? 1 : 0;
+    a.cap = cap; a.out = d_out; a.status = status;
+    a.ticket = reinterpret_cast<u32 *>(status + ntiles + 2);
+    a.total = ctx->d_scalars + 7; a.err = ctx->d_err;
+    a.huge = huge; a.nhuge = nhuge; a.huge_cap = huge_cap; a.ntiles = ntiles;
+    u32 grid = tc_persistent_grid_for(ctx, rle_decode_fused_kernel<SymT>, RLD_NT, 8);
+    if (grid > ntiles) grid = ntiles;
+    rle_decode_fused_kernel<SymT><<<grid, RLD_NT, 0, s>>>(a);
     TC_LAUNCH_CHECK(ctx);
     rle_fill_huge_kernel<SymT><<<tc_persistent_grid(ctx, 4), 256, 0, s>>>(huge, nhuge, huge_cap, cap, d_out);
     TC_LAUNCH_CHECK(ctx);
+    tc_d2h(ctx, &ctx->h_scalars[7], ctx->d_scalars + 7, sizeof(u64));
+    TC_HIP(ctx, hipStreamSynchronize(s));
+    *N_out = ctx->h_scalars[7];   // > cap: the caller reports TC_ERR_CAPACITY (nothing past cap was written)
 }
 
 // ---- fused decode: runs -> MTF indices -> BWT symbols -> text -------------------

@@ -319,18 +319,9 @@ __global__ __launch_bounds__(RLE_NT, 4) void rle_encode_idx_kernel(const IT *__r
 }
 
 // ---- decode: seqFromRLE (RLE/Internal.hs:155-189) -------------------------------
-// (count, Nothing) => exactly one Nothing; else `count` copies.  Exclusive scan of
-// the output lengths, then each run fills its slice.
-template <class SymT>
-__global__ __launch_bounds__(256) void rle_len_kernel(const u32 *__restrict__ counts,
-                                                      const SymT *__restrict__ syms, u64 nruns,
-                                                      bool has_nothing, u64 *__restrict__ len) {
-    u64 k = (u64)blockIdx.x * 256 + threadIdx.x;
-    if (k >= nruns) return;
-    bool nothing = has_nothing && (syms[k] == (SymT)-1);
-    len[k] = nothing ? 1ull : (u64)counts[k];
-}
-
+// (count, Nothing) => exactly one Nothing; else `count` copies.  One pass: a tile of 2048 runs
+// computes its output lengths, scans them (block scan + decoupled look-back for the tile's offset)
+// and fills its slice at once -- no length / offset arrays in HBM.
 // generic device exclusive scan of u64 (three small kernels; run counts only)
 #define SCAN_NT 256
 #define SCAN_ITEMS 8
@@ -411,38 +402,117 @@ struct HugeRun {
     u64 off, len;
     u32 sym, pad;
 };
+#define RLD_NT 256
+#define RLD_RPT 8
+#define RLD_TILE (RLD_NT * RLD_RPT)
+struct RleDecArgs {
+    const u32 *counts;
+    const void *syms;
+    u64 nruns;
+    int has_nothing;
+    u64 cap;
+    void *out;
+    u64 *status;
+    u32 *ticket;
+    u64 *total;   // receives the expanded length
+    u32 *err;
+    HugeRun *huge;
+    u32 *nhuge;
+    u32 huge_cap;
+    u32 ntiles;
+};
+__device__ __forceinline__ u64 wave_incl_sum64(u64 v) {
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        u64 t = __shfl_up(v, d, 64);
+        if ((int)lane_id() >= d) v += t;
+    }
+    return v;
+}
 template <class SymT>
-__global__ __launch_bounds__(256) void rle_fill_kernel(const u64 *__restrict__ offs,
-                                                       const u32 *__restrict__ counts,
-                                                       const SymT *__restrict__ syms, u64 nruns,
-                                                       bool has_nothing, u64 cap,
-                                                       SymT *__restrict__ out, HugeRun *huge, u32 *nhuge,
-                                                       u32 huge_cap) {
-    u64 k = (u64)blockIdx.x * 256 + threadIdx.x;
-    bool in = k < nruns;
-    u64 o = in ? offs[k] : 0;
-    SymT s = in ? syms[k] : (SymT)0;
-    u64 len = 0;
-    if (in) len = (has_nothing && s == (SymT)-1) ? 1ull : (u64)counts[k];
-    const u64 LONG = 32;
-    if (in && len < LONG)
-        for (u64 q = 0; q < len; q++)
-            if (o + q < cap) out[o + q] = s;
-    u64 longmask = __ballot(in && len >= LONG);
-    while (longmask) {
-        int src = __builtin_ctzll(longmask);
-        longmask &= longmask - 1;
-        u64 lo = __shfl(o, src, 64), ll = __shfl(len, src, 64);
-        SymT ss = (SymT)__shfl((int)s, src, 64);
-        if (ll >= RLE_HUGE) {
-            if (lane_id() == 0) {
-                u32 slot = atomicAdd(nhuge, 1u);
-                if (slot < huge_cap) huge[slot] = HugeRun{lo, ll, (u32)(u16)ss, 0u};
+__global__ __launch_bounds__(RLD_NT) void rle_decode_fused_kernel(RleDecArgs a) {
+    __shared__ u64 s_w[RLD_NT / 64];
+    __shared__ u64 s_excl;
+    __shared__ u32 s_tile;
+    const int tid = threadIdx.x, w = tid >> 6, l = tid & 63;
+    const SymT *syms = reinterpret_cast<const SymT *>(a.syms);
+    SymT *out = reinterpret_cast<SymT *>(a.out);
+    for (;;) {
+        __syncthreads();
+        if (tid == 0) s_tile = atomicAdd(a.ticket, 1u);
+        __syncthreads();
+        const u32 tile = s_tile;
+        if (tile >= a.ntiles) break;
+        const u64 r0 = (u64)tile * RLD_TILE + (u64)tid * RLD_RPT;
+        u32 c[RLD_RPT];
+        SymT sv[RLD_RPT];
+        if (r0 + RLD_RPT <= a.nruns && ((((uintptr_t)a.counts) | ((uintptr_t)syms)) & 15) == 0) {
+            const uint4 *pc = reinterpret_cast<const uint4 *>(a.counts + r0);
+            const uint4 t0 = pc[0], t1 = pc[1];
+            c[0] = t0.x; c[1] = t0.y; c[2] = t0.z; c[3] = t0.w;
+            c[4] = t1.x; c[5] = t1.y; c[6] = t1.z; c[7] = t1.w;
+            const uint4 ts = *reinterpret_cast<const uint4 *>(syms + r0);
+            const u32 xs[4] = {ts.x, ts.y, ts.z, ts.w};
+#pragma unroll
+            for (int k = 0; k < RLD_RPT; k++) sv[k] = (SymT)((xs[k >> 1] >> (16 * (k & 1))) & 0xffffu);
+        } else {
+#pragma unroll
+            for (int k = 0; k < RLD_RPT; k++) {
+                const bool ok = r0 + k < a.nruns;
+                c[k] = ok ? a.counts[r0 + k] : 0u;
+                sv[k] = ok ? syms[r0 + k] : (SymT)0;
             }
-            continue;
         }
-        for (u64 q = lane_id(); q < ll; q += 64)
-            if (lo + q < cap) out[lo + q] = ss;
+        u64 len[RLD_RPT], mine = 0;
+#pragma unroll
+        for (int k = 0; k < RLD_RPT; k++) {
+            const bool ok = r0 + k < a.nruns;
+            len[k] = !ok ? 0ull : ((a.has_nothing && sv[k] == (SymT)-1) ? 1ull : (u64)c[k]);
+            mine += len[k];
+        }
+        const u64 inc = wave_incl_sum64(mine);
+        if (l == 63) s_w[w] = inc;
+        __syncthreads();
+        u64 wbase = 0, tot = 0;
+#pragma unroll
+        for (int i = 0; i < RLD_NT / 64; i++) {
+            if (i < w) wbase += s_w[i];
+            tot += s_w[i];
+        }
+        if (w == 0) {
+            const u64 e = lb_exclusive<OpSum>(a.status, tile, tot, a.err);
+            if (l == 0) {
+                s_excl = e;
+                if (tile + 1 == a.ntiles) *a.total = e + tot;
+            }
+        }
+        __syncthreads();
+        u64 o = s_excl + wbase + inc - mine;
+#pragma unroll
+        for (int k = 0; k < RLD_RPT; k++) {
+            const u64 ln = len[k];
+            const SymT sk = sv[k];
+            if (ln && ln < 32)
+                for (u64 q = 0; q < ln; q++)
+                    if (o + q < a.cap) out[o + q] = sk;
+            u64 longmask = __ballot(ln >= 32);
+            while (longmask) {
+                const int src = __builtin_ctzll(longmask);
+                longmask &= longmask - 1;
+                const u64 lo = __shfl(o, src, 64), ll = __shfl(ln, src, 64);
+                const SymT ss = (SymT)__shfl((int)sk, src, 64);
+                if (ll >= RLE_HUGE) {
+                    if (l == 0) {
+                        const u32 slot = atomicAdd(a.nhuge, 1u);
+                        if (slot < a.huge_cap) a.huge[slot] = HugeRun{lo, ll, (u32)(u16)ss, 0u};
+                    }
+                    continue;
+                }
+                for (u64 q = l; q < ll; q += 64)
+                    if (lo + q < a.cap) out[lo + q] = ss;
+            }
+            o += ln;
+        }
     }
 }
 template <class SymT>
