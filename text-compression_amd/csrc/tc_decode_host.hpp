@@ -52,6 +52,114 @@ __device__ __forceinline__ int ibwt_sym_of_row(const u32 *s_c, const i16 *s_sym,
     return (int)s_sym[lo];
 }
 
+// Stable counting sort of the positions by symbol in ONE dedicated pass (sigma <= 256): the keys are
+// the symbols themselves, so nothing but the position array is written -- 2 bytes read and 4 written
+// per symbol instead of a key-building launch plus a generic (key, value) radix pass (30 bytes).
+// Same scheme as radix_pass_kernel: 4096-position tiles from an atomic ticket, wave-striped stable
+// ranking through per-wave LDS match masks, per-code decoupled look-back, LDS staging, coalesced
+// write-out.  cbase[c] = first sorted row of code c.
+#define ISC_NT 256
+#define ISC_ITEMS 16
+#define ISC_TILE (ISC_NT * ISC_ITEMS)
+template <class Acc>
+__global__ __launch_bounds__(ISC_NT) void ibwt_scatter_kernel(Acc acc, u32 N, Lut16 lut, CTable ct,
+                                                             u32 *__restrict__ spos, u64 *status,
+                                                             u32 *ticket, u32 *err) {
+    constexpr int NW = ISC_NT / 64;
+    __shared__ u32 s_hist[NW * 256];
+    __shared__ u64 s_mask[NW * 256];
+    __shared__ u32 s_vals[ISC_TILE];
+    __shared__ u8 s_dig[ISC_TILE];
+    __shared__ u32 s_dbase[256], s_gbase[256];
+    __shared__ u16 s_lut[260];
+    __shared__ u32 s_scan[NW + 1];
+    __shared__ u32 s_tile;
+    const int tid = threadIdx.x, w = tid >> 6, l = tid & 63;
+    for (int i = tid; i < 257; i += ISC_NT) s_lut[i] = lut.v[i];
+    if (tid == 0) s_tile = atomicAdd(ticket, 1u);
+    for (int i = tid; i < NW * 256; i += ISC_NT) {
+        s_hist[i] = 0;
+        s_mask[i] = 0ull;
+    }
+    __syncthreads();
+    const u32 tile = s_tile;
+    const u64 base = (u64)tile * ISC_TILE;
+    const u32 valid = (N - base) < (u64)ISC_TILE ? (u32)(N - base) : (u32)ISC_TILE;
+    const u32 wofs = w * 64 * ISC_ITEMS;
+    u32 *wh = s_hist + w * 256;
+    u64 *wm = s_mask + w * 256;
+    const u64 mybit = 1ull << l;
+    u32 dig[ISC_ITEMS], rnk[ISC_ITEMS];
+#pragma unroll
+    for (int k = 0; k < ISC_ITEMS; k++) {
+        const u32 p = wofs + k * 64 + l;
+        const u32 d = p < valid ? (u32)s_lut[acc(base + p) + 1] : 255u;   // pads: last code, last
+        dig[k] = d;
+        atomicOr((unsigned long long *)&wm[d], (unsigned long long)mybit);
+        __builtin_amdgcn_wave_barrier();
+        const u64 m = wm[d];
+        const u32 old = wh[d];
+        const u32 prior = __popcll(m & (mybit - 1ull));
+        __builtin_amdgcn_wave_barrier();
+        if (prior == 0) {
+            wh[d] = old + __popcll(m);
+            wm[d] = 0ull;
+        }
+        __builtin_amdgcn_wave_barrier();
+        rnk[k] = old + prior;
+    }
+    __syncthreads();
+    u32 tot = 0;
+#pragma unroll
+    for (int i = 0; i < NW; i++) {   // one owner thread per code (ISC_NT == 256 codes)
+        const u32 c = s_hist[i * 256 + tid];
+        s_hist[i * 256 + tid] = tot;
+        tot += c;
+    }
+    u32 tot_real = tot;
+    if (tid == 255) tot_real = tot - (ISC_TILE - valid);
+    u64 *st = status + (u64)tile * 256 + tid;
+    lb_store(st, (tile == 0 ? LB_FLAG_INC : LB_FLAG_AGG) | (u64)tot_real);
+    u32 dtot;
+    const u32 dbase = block_excl_sum<ISC_NT>(tot, s_scan, &dtot);
+    s_dbase[tid] = dbase;
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < ISC_ITEMS; k++) {
+        const u32 pos = s_dbase[dig[k]] + wh[dig[k]] + rnk[k];
+        s_vals[pos] = (u32)base + wofs + k * 64 + l;
+        s_dig[pos] = (u8)dig[k];
+    }
+    u32 excl = 0;
+    if (tile > 0) {
+        i64 t = (i64)tile - 1;
+        u32 spins = 0;
+        for (;;) {
+            const u64 sv = lb_load(status + (u64)t * 256 + tid);
+            const u32 f = (u32)(sv >> 62);
+            if (f == 0) {
+                if (++spins > LB_SPIN_LIMIT) {
+                    atomicOr(err, 2u);
+                    break;
+                }
+                __builtin_amdgcn_s_sleep(1);
+                continue;
+            }
+            excl += (u32)LB_VALUE(sv);
+            if (f == 2 || t == 0) break;
+            t--;
+        }
+        lb_store(st, LB_FLAG_INC | (u64)(excl + tot_real));
+    }
+    s_gbase[tid] = ct.c[tid] + excl - dbase;
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < ISC_ITEMS; k++) {
+        const u32 p = tid + k * ISC_NT;
+        if (p < valid) spos[s_gbase[s_dig[p]] + p] = s_vals[p];
+    }
+}
+
 // Splitter q walks to the next splitter row (independent walks, one per lane) and records what it
 // passes: the symbols of its segment go to seg + q * IBWT_SEGCAP, their
 // number to seglen[q].  Flags: bit 0 = the segment is longer than IBWT_SEGCAP (re-walked later by
@@ -255,15 +363,26 @@ static void ibwt_device(tc_ctx *ctx, Arena &A, Acc acc, u64 N, const u32 *counts
     ct.c[al.sigma] = (u32)N;
     ct.sigma = al.sigma;
     // 1. sorted (symbol, position): spos
-    ibwt_keys_kernel<Acc><<<tc_cdiv(N, 256), 256, 0, s>>>(acc, (u32)N, lut, k0);
-    TC_LAUNCH_CHECK(ctx);
-    RadixPlan plan;
-    plan.add_range(0, ceil_log2_u64(al.sigma) > 0 ? ceil_log2_u64(al.sigma) : 1);
-    RadixBuffers rb;
-    rb.keys = k0; rb.keys_alt = k1; rb.vals = v0; rb.vals_alt = v1;
-    rb.hist = hist; rb.status = rstatus;
-    radix_sort_pairs(ctx, rb, (u32)N, plan, /*gen_idx=*/true, /*hist_ready=*/false);
-    const u32 *spos = rb.vals;
+    const u32 *spos = nullptr;
+    if (al.sigma <= 256 && env_int("TC_IBWT_SCATTER", 1) != 0) {
+        for (u32 c = al.sigma; c < 260; c++) ct.c[c] = (u32)N;   // codes that do not occur
+        const u32 stiles = tc_cdiv(N, ISC_TILE);
+        u32 *sticket = reinterpret_cast<u32 *>(rstatus + (size_t)stiles * 256);
+        tc_memset_async(ctx, rstatus, 0, ((size_t)stiles * 256 + 2) * sizeof(u64));
+        ibwt_scatter_kernel<Acc><<<stiles, ISC_NT, 0, s>>>(acc, (u32)N, lut, ct, v0, rstatus, sticket, ctx->d_err);
+        TC_LAUNCH_CHECK(ctx);
+        spos = v0;
+    } else {
+        ibwt_keys_kernel<Acc><<<tc_cdiv(N, 256), 256, 0, s>>>(acc, (u32)N, lut, k0);
+        TC_LAUNCH_CHECK(ctx);
+        RadixPlan plan;
+        plan.add_range(0, ceil_log2_u64(al.sigma) > 0 ? ceil_log2_u64(al.sigma) : 1);
+        RadixBuffers rb;
+        rb.keys = k0; rb.keys_alt = k1; rb.vals = v0; rb.vals_alt = v1;
+        rb.hist = hist; rb.status = rstatus;
+        radix_sort_pairs(ctx, rb, (u32)N, plan, /*gen_idx=*/true, /*hist_ready=*/false);
+        spos = rb.vals;
+    }
     // the sort keys are dead: k0 now holds the segment records (K * IBWT_SEGCAP ~ 8 N bytes)
     u8 *seg = reinterpret_cast<u8 *>(k0);
     // 2. splitter walks (recording the symbols passed), chain ranking, copy-out
