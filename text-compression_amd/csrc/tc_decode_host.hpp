@@ -162,15 +162,16 @@ __global__ __launch_bounds__(ISC_NT) void ibwt_scatter_kernel(Acc acc, u32 N, Lu
 
 // Splitter q walks to the next splitter row (independent walks, one per lane) and records what it
 // passes: the symbols of its segment go to seg + q * IBWT_SEGCAP, their
-// number to seglen[q].  Flags: bit 0 = the segment is longer than IBWT_SEGCAP (re-walked later by
+// number to seglen[q].  Flags: bit 0 = the segment is longer than IBWT_SEGCAP (listed, re-walked by
 // ibwt_walk2_kernel), bit 1 = a Nothing row other than row 0 was met (an error only if the segment
 // turns out to lie on the chain of row e).
-#define IBWT_SEGCAP 2048
+#define IBWT_SEGCAP 4096   // segment lengths are geometric with mean 256: one in 10^7 is longer
 __global__ __launch_bounds__(256) void ibwt_walk1_kernel(const u32 *__restrict__ spos, u32 N, u32 K,
                                                          u32 *__restrict__ nxt,
                                                          u32 *__restrict__ dist, CTable ct,
                                                          u8 *__restrict__ seg, u32 *__restrict__ seglen,
-                                                         u8 *__restrict__ segflag, u32 force_rewalk) {
+                                                         u8 *__restrict__ segflag, u32 force_rewalk,
+                                                         u32 *__restrict__ noverflow, u32 *__restrict__ ovlist) {
     __shared__ u32 s_c[260];
     __shared__ i16 s_sym[260];
     for (int i = threadIdx.x; i < 260; i += 256) {
@@ -234,6 +235,7 @@ __global__ __launch_bounds__(256) void ibwt_walk1_kernel(const u32 *__restrict__
     dist[q] = steps;
     seglen[q] = emitted;
     segflag[q] = (u8)flag;
+    if (flag & 1u) ovlist[atomicAdd(noverflow, 1u)] = q;   // rare: re-walked by ibwt_walk2_kernel
 }
 
 // keep splitter 0's real successor aside and make it the terminal of the chain
@@ -268,7 +270,7 @@ __global__ __launch_bounds__(256) void ibwt_walk2_kernel(const u32 *__restrict__
                                                          const u32 *__restrict__ dist,
                                                          const u64 *__restrict__ scalars,
                                                          CTable ct, u8 *__restrict__ text,
-                                                         const u8 *__restrict__ segflag, u32 *err) {
+                                                         const u32 *__restrict__ ovlist, u32 nov, u32 *err) {
     __shared__ u32 s_c[260];
     __shared__ i16 s_sym[260];
     for (int i = threadIdx.x; i < 260; i += 256) {
@@ -276,10 +278,10 @@ __global__ __launch_bounds__(256) void ibwt_walk2_kernel(const u32 *__restrict__
         s_sym[i] = ct.sym[i];
     }
     __syncthreads();
-    u32 q = blockIdx.x * 256 + threadIdx.x;
-    if (q >= K) return;
-    if (!(segflag[q] & 1u)) return;     // copied from its buffer by ibwt_copy_kernel
-    if (q != 0 && nxt[q] != 0) return;  // not on row e's chain
+    const u32 i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= nov) return;
+    const u32 q = ovlist[i];            // a segment that did not fit its record buffer
+    if (q >= K || (q != 0 && nxt[q] != 0)) return;  // not on row e's chain
     const u32 Lc = (u32)scalars[6];
     u32 p = (q == 0) ? 0u : Lc - dist[q];
     u32 r = ibwt_split_row(q), steps = 0;
@@ -340,6 +342,7 @@ static void ibwt_device(tc_ctx *ctx, Arena &A, Acc acc, u64 N, const u32 *counts
     u32 *ds[2] = {A.get<u32>(K + 1), A.get<u32>(K + 1)};
     u32 *seglen = A.get<u32>(K + 1);
     u8 *segflag = A.get<u8>(K + 1);
+    u32 *ovlist = A.get<u32>(K + 1);
     if (dry) return;
     hipStream_t s = ctx->stream;
     u32 local[257];
@@ -383,11 +386,13 @@ static void ibwt_device(tc_ctx *ctx, Arena &A, Acc acc, u64 N, const u32 *counts
         radix_sort_pairs(ctx, rb, (u32)N, plan, /*gen_idx=*/true, /*hist_ready=*/false);
         spos = rb.vals;
     }
-    // the sort keys are dead: k0 now holds the segment records (K * IBWT_SEGCAP ~ 8 N bytes)
+    // k0 holds the segment records (K * IBWT_SEGCAP ~ 16 N bytes; in the scatter path it is not used for keys at all)
     u8 *seg = reinterpret_cast<u8 *>(k0);
     // 2. splitter walks (recording the symbols passed), chain ranking, copy-out
+    tc_memset_async(ctx, ctx->d_scalars + 17, 0, sizeof(u64));
     ibwt_walk1_kernel<<<tc_cdiv(K, 256), 256, 0, s>>>(spos, (u32)N, K, nx[0], ds[0], ct, seg, seglen, segflag,
-                                                     (u32)env_int("TC_IBWT_REWALK", 0));
+                                                     (u32)env_int("TC_IBWT_REWALK", 0),
+                                                     reinterpret_cast<u32 *>(ctx->d_scalars + 17), ovlist);
     TC_LAUNCH_CHECK(ctx);
     ibwt_terminal_kernel<<<1, 1, 0, s>>>(nx[0], ds[0], ctx->d_scalars);
     TC_LAUNCH_CHECK(ctx);
@@ -402,11 +407,16 @@ static void ibwt_device(tc_ctx *ctx, Arena &A, Acc acc, u64 N, const u32 *counts
     ibwt_copy_kernel<<<tc_cdiv(K, 4), 256, 0, s>>>(K, nx[cur], ds[cur], ctx->d_scalars, seg, seglen, segflag,
                                                   d_text, ctx->d_err);
     TC_LAUNCH_CHECK(ctx);
-    ibwt_walk2_kernel<<<tc_cdiv(K, 256), 256, 0, s>>>(spos, (u32)N, K, nx[cur], ds[cur],
-                                                     ctx->d_scalars, ct, d_text, segflag, ctx->d_err);
-    TC_LAUNCH_CHECK(ctx);
     tc_d2h(ctx, &ctx->h_scalars[6], ctx->d_scalars + 6, sizeof(u64));
+    tc_d2h(ctx, &ctx->h_scalars[17], ctx->d_scalars + 17, sizeof(u64));
     TC_HIP(ctx, hipStreamSynchronize(s));
+    if ((u32)ctx->h_scalars[17]) {   // some segments did not fit their record buffer: walk them again
+        const u32 nov = (u32)ctx->h_scalars[17];
+        ibwt_walk2_kernel<<<tc_cdiv(nov, 256), 256, 0, s>>>(spos, (u32)N, K, nx[cur], ds[cur],
+                                                           ctx->d_scalars, ct, d_text, ovlist, nov, ctx->d_err);
+        TC_LAUNCH_CHECK(ctx);
+        TC_HIP(ctx, hipStreamSynchronize(s));
+    }
     u64 Lc = ctx->h_scalars[6];
     *n_out = Lc ? Lc - 1 : 0;
 }
