@@ -405,6 +405,7 @@ struct HugeRun {
 #define RLD_NT 256
 #define RLD_RPT 8
 #define RLD_TILE (RLD_NT * RLD_RPT)
+#define RLD_STAGE 8192   // symbols a tile may expand to and still go through LDS
 struct RleDecArgs {
     const u32 *counts;
     const void *syms;
@@ -434,6 +435,7 @@ __global__ __launch_bounds__(RLD_NT) void rle_decode_fused_kernel(RleDecArgs a) 
     __shared__ u64 s_w[RLD_NT / 64];
     __shared__ u64 s_excl;
     __shared__ u32 s_tile;
+    __shared__ SymT s_stage[RLD_STAGE];
     const int tid = threadIdx.x, w = tid >> 6, l = tid & 63;
     const SymT *syms = reinterpret_cast<const SymT *>(a.syms);
     SymT *out = reinterpret_cast<SymT *>(a.out);
@@ -487,6 +489,21 @@ __global__ __launch_bounds__(RLD_NT) void rle_decode_fused_kernel(RleDecArgs a) 
             }
         }
         __syncthreads();
+        if (tot <= RLD_STAGE) {
+            // the usual case (short runs): expand into LDS, then write the tile's slice coalesced
+            u32 lo = (u32)(wbase + inc - mine);
+#pragma unroll
+            for (int k = 0; k < RLD_RPT; k++) {
+                const u32 ln = (u32)len[k];
+                for (u32 q = 0; q < ln; q++) s_stage[lo + q] = sv[k];
+                lo += ln;
+            }
+            __syncthreads();
+            const u64 ob = s_excl;
+            for (u32 i = tid; i < (u32)tot; i += RLD_NT)
+                if (ob + i < a.cap) out[ob + i] = s_stage[i];
+            continue;
+        }
         u64 o = s_excl + wbase + inc - mine;
 #pragma unroll
         for (int k = 0; k < RLD_RPT; k++) {
