@@ -210,6 +210,24 @@ int tc_encode_container(tc_ctx *ctx, const uint8_t *text, uint64_t n, uint8_t *o
 int tc_container_info(tc_ctx *ctx, const uint8_t *container, uint64_t bytes, uint64_t *n, uint64_t *nruns);
 int tc_decode_container(tc_ctx *ctx, const uint8_t *container, uint64_t bytes, uint8_t *text, uint64_t *n_out);
 
+/* ---- chunked stream (texts longer than one record / than HBM) ------------- */
+/* A text of any length is cut into records of block_bytes (0 = TC_STREAM_BLOCK_DEFAULT; at most
+ * TC_MAX_N; the last record is the remainder; an empty text is one empty record); every record is
+ * encoded on its own -- the BWT is global within a record only, as with bzip2's blocks -- and the
+ * stream is the records' containers back to back.  Host buffers; record k+1 is copied in and
+ * container k-1 copied out while the device encodes record k.  *bytes: in = capacity of `out`,
+ * out = bytes used (TC_ERR_CAPACITY: *bytes = tc_stream_bound, always enough).  A stream of one
+ * record is byte-identical to tc_encode_container's output. */
+#define TC_STREAM_BLOCK_DEFAULT ((uint64_t)1 << 30)
+uint64_t tc_stream_bound(uint64_t n, uint64_t block_bytes);
+int tc_encode_stream(tc_ctx *ctx, const uint8_t *text, uint64_t n, uint64_t block_bytes, uint8_t *out,
+                     uint64_t *bytes);
+/* total text length and number of records of a stream in HOST memory (headers only) */
+int tc_stream_info(tc_ctx *ctx, const uint8_t *stream, uint64_t bytes, uint64_t *n_total, uint64_t *nblocks);
+/* *n_out: in = capacity of `text`, out = bytes written (TC_ERR_CAPACITY: bytes needed); every
+ * container's checksum is verified (TC_ERR_MALFORMED). */
+int tc_decode_stream(tc_ctx *ctx, const uint8_t *stream, uint64_t bytes, uint8_t *text, uint64_t *n_out);
+
 /* ---- Data.FMIndex -------------------------------------------------------- */
 /* bytestringToBWTToFMIndexB (FMIndex.hs:108-111,162-183): C[c] (seqToCc,
  * FMIndex/Internal.hs:275-316), Occ (seqToOccCK :195-259, kept as rank

@@ -87,3 +87,52 @@ def test_container_detects_corruption(ctx):
     with pytest.raises(textcomp.TcError) as e:
         ctx.encode_container(t, cap=1000)                 # too small: capacity error
     assert e.value.code == -2
+
+
+# ------------------------------------------------------------------ chunked stream (8f-4)
+@pytest.mark.parametrize("n,block", [(0, 1000), (1, 1000), (999, 1000), (1000, 1000), (1001, 1000),
+                                     (250000, 65536), (300000, 100000), (1 << 20, 0), (70001, 7)])
+def test_stream_roundtrip(ctx, n, block):
+    """A text cut into records of `block` bytes: every record is the container of that slice on its
+    own (same bytes as tc_encode_container gives), the stream decodes to the text."""
+    if block == 7:
+        n = 700                                        # 100 tiny records
+    t = O.gen_acgtn(41, n).tobytes() if n % 2 == 0 else O.gen_ascii(42, n).tobytes()
+    blob = ctx.encode_stream(t, block)
+    b = block or (1 << 30)
+    nb = max(1, -(-n // b))
+    assert ctx.stream_info(blob) == (n, nb)
+    exp = b"".join(ctx.encode_container(t[k * b:(k + 1) * b]) for k in range(nb))
+    assert blob == exp
+    assert ctx.decode_stream(blob) == t
+
+
+def test_stream_capacity_and_corruption(ctx):
+    import textcomp
+    lib = ctx.lib
+    t = np.frombuffer(O.gen_acgtn(43, 200000).tobytes(), np.uint8).copy()
+    blob = ctx.encode_stream(t.tobytes(), 50000)
+    out = np.empty(len(blob), np.uint8)
+    used = C.c_uint64(len(blob) - 1)                       # one byte short: the last container does not fit
+    rc = lib.tc_encode_stream(ctx.handle, C.c_void_p(t.ctypes.data), len(t), 50000, C.c_void_p(out.ctypes.data), C.byref(used))
+    assert rc == -2 and used.value == lib.tc_stream_bound(len(t), 50000) >= len(blob)
+    used = C.c_uint64(len(blob))
+    rc = lib.tc_encode_stream(ctx.handle, C.c_void_p(t.ctypes.data), len(t), 50000, C.c_void_p(out.ctypes.data), C.byref(used))
+    assert rc == 0 and out[:used.value].tobytes() == blob
+    # decode: text buffer too small -> bytes needed
+    b = np.frombuffer(blob, np.uint8)
+    txt = np.empty(len(t), np.uint8)
+    got = C.c_uint64(len(t) - 1)
+    assert lib.tc_decode_stream(ctx.handle, C.c_void_p(b.ctypes.data), len(b), C.c_void_p(txt.ctypes.data), C.byref(got)) == -2
+    assert got.value == len(t)
+    # a flipped payload byte in the third record, a truncated stream, a broken magic
+    bad = bytearray(blob)
+    third = 2 * (len(blob) // 4) + 700
+    bad[third] ^= 0x10
+    with pytest.raises(textcomp.TcMalformed):
+        ctx.decode_stream(bytes(bad))
+    with pytest.raises(textcomp.TcMalformed):
+        ctx.decode_stream(blob[:-4])
+    with pytest.raises(textcomp.TcMalformed):
+        ctx.decode_stream(b"XX" + blob[2:])
+    assert lib.tc_encode_stream(ctx.handle, C.c_void_p(t.ctypes.data), len(t), 1 << 31, C.c_void_p(out.ctypes.data), C.byref(used)) == -1

@@ -108,6 +108,24 @@ def test_rle_decode_long_runs(ctx):
     assert ctx.decode(ctx.encode(t)) == t
 
 
+@pytest.mark.parametrize("env", [{"TC_IBWT_SCATTER": "0"}, {"TC_IBWT_REWALK": "1"},
+                                 {"TC_IBWT_SCATTER": "0", "TC_IBWT_REWALK": "1"}],
+                         ids=lambda e: ",".join("%s=%s" % kv for kv in e.items()))
+def test_ibwt_path_selectors(ctx, env, monkeypatch):
+    """The alternatives inside the inverse BWT (generic radix sort of the positions instead of the
+    dedicated scatter; every recorded segment treated as overflowed and walked again) decode to
+    the same text."""
+    rng = np.random.default_rng(5)
+    texts = [O.gen_acgtn(31, 1 << 20).tobytes(), O.gen_ascii(32, 200000).tobytes(),
+             bytes(rng.integers(0, 256, 100000, dtype=np.uint8)),
+             bytes(rng.choice(list(b"ACGT"), 1000).astype(np.uint8)) * 300]
+    blks = [ctx.encode(t) for t in texts]
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    for t, blk in zip(texts, blks):
+        assert ctx.decode(blk) == t
+
+
 def test_fused_decode_rejects_inconsistent_block(ctx):
     import textcomp
     blk = ctx.encode(b"mississippi" * 50)

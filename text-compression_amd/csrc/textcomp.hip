@@ -1,5 +1,8 @@
 // textcomp.hip -- libtextcomp.so: C ABI (include/textcomp.h) over the HIP kernels.
 // Single translation unit for gfx950: hipcc --offload-arch=gfx950 -shared -fPIC.
+#include <thread>
+#include <vector>
+
 #include "tc_common.hpp"
 #include "tc_encode_host.hpp"
 #include "tc_decode_host.hpp"
@@ -1031,6 +1034,235 @@ int tc_decode_container(tc_ctx *ctx, const uint8_t *container, uint64_t bytes, u
     if (d_text) (void)hipFree(d_text);
     if (d_count) (void)hipFree(d_count);
     if (d_value) (void)hipFree(d_value);
+    if (rc != TC_OK) throw TcFail{rc};
+    TC_API_END(ctx)
+}
+
+// ================================================== chunked stream of containers
+// A text of any length as independent records of block_bytes each (every record is its own
+// BWT -> MTF -> RLE block, as bzip2 does with its blocks), written as containers back to back.
+// The device works on record k while one helper thread copies record k+1 in and another copies
+// container k-1 out, each on its own stream.
+struct CopyJob {
+    std::thread th;
+    hipError_t err = hipSuccess;
+    void start(int device, hipStream_t s, void *dst, const void *src, size_t bytes, hipMemcpyKind kind) {
+        err = hipSuccess;
+        if (!bytes) return;
+        th = std::thread([this, device, s, dst, src, bytes, kind] {
+            hipError_t e = hipSetDevice(device);
+            if (e == hipSuccess) e = hipMemcpyAsync(dst, src, bytes, kind, s);
+            if (e == hipSuccess) e = hipStreamSynchronize(s);
+            err = e;
+        });
+    }
+    hipError_t join() {
+        if (th.joinable()) th.join();
+        return err;
+    }
+    ~CopyJob() { (void)join(); }
+};
+
+static u64 stream_blocks(u64 n, u64 block) { return n ? (n + block - 1) / block : 1; }
+static u64 container_bound_any(u64 n) {
+    u64 b = 0;
+    for (u32 sg : {6u, 16u, 257u}) {
+        const u64 v = tc_container_bound(n + 2, sg);
+        if (v > b) b = v;
+    }
+    return b;
+}
+
+uint64_t tc_stream_bound(uint64_t n, uint64_t block_bytes) {
+    if (block_bytes == 0) block_bytes = TC_STREAM_BLOCK_DEFAULT;
+    if (block_bytes > TC_MAX_N) block_bytes = TC_MAX_N;
+    const u64 nb = stream_blocks(n, block_bytes);
+    const u64 last = n - (nb - 1) * block_bytes;
+    return (nb - 1) * container_bound_any(block_bytes) + container_bound_any(last);
+}
+
+int tc_encode_stream(tc_ctx *ctx, const uint8_t *text, uint64_t n, uint64_t block_bytes, uint8_t *out,
+                     uint64_t *bytes) {
+    TC_API_BEGIN(ctx)
+    if (block_bytes == 0) block_bytes = TC_STREAM_BLOCK_DEFAULT;
+    if (!bytes || !out || (n && !text) || block_bytes > TC_MAX_N) TC_FAIL(ctx, TC_ERR_ARG, "bad argument");
+    const u64 cap = *bytes;
+    *bytes = 0;
+    const u64 nb = stream_blocks(n, block_bytes);
+    const u64 bmax = n < block_bytes ? n : block_bytes;      // longest record
+    const u64 runs_cap = bmax + 2;
+    const u64 cont_cap = container_bound_any(bmax);
+    u8 *d_text[2] = {nullptr, nullptr}, *d_out[2] = {nullptr, nullptr};
+    u32 *d_count = nullptr;
+    u16 *d_value = nullptr;
+    hipStream_t s_in = nullptr, s_out = nullptr;
+    int rc = TC_OK;
+    {
+        CopyJob in, outj;
+        try {
+            TC_HIP(ctx, hipStreamCreateWithFlags(&s_in, hipStreamNonBlocking));
+            TC_HIP(ctx, hipStreamCreateWithFlags(&s_out, hipStreamNonBlocking));
+            for (int i = 0; i < (nb > 1 ? 2 : 1); i++) {
+                TC_HIP(ctx, hipMalloc((void **)&d_text[i], bmax + 16));
+                TC_HIP(ctx, hipMalloc((void **)&d_out[i], cont_cap + 16));
+            }
+            TC_HIP(ctx, hipMalloc((void **)&d_count, (runs_cap + 1) * sizeof(u32)));
+            TC_HIP(ctx, hipMalloc((void **)&d_value, (runs_cap + 1) * sizeof(u16)));
+            auto len_of = [&](u64 k) { return k + 1 < nb ? block_bytes : n - (nb - 1) * block_bytes; };
+            in.start(ctx->device, s_in, d_text[0], text, len_of(0), hipMemcpyHostToDevice);
+            u64 off = 0;          // bytes of `out` written or being written
+            for (u64 k = 0; k < nb; k++) {
+                const int sl = (int)(k & 1);
+                const u64 nk = len_of(k);
+                TC_HIP(ctx, in.join());
+                if (k + 1 < nb)
+                    in.start(ctx->device, s_in, d_text[sl ^ 1], text + (k + 1) * block_bytes, len_of(k + 1),
+                             hipMemcpyHostToDevice);
+                tc_block dev;
+                memset(&dev, 0, sizeof dev);
+                dev.nruns = runs_cap; dev.run_count = d_count; dev.run_value = d_value;
+                if (nk) encode_device(ctx, d_text[sl], nk, &dev, runs_cap);
+                else dev.nruns = 0;
+                // d_out[sl] was last read by the copy of container k-2, joined before container k-1 started
+                u64 used = cont_cap;
+                container_write_device(ctx, &dev, d_out[sl], &used);
+                TC_HIP(ctx, outj.join());
+                if (off + used > cap) {
+                    *bytes = tc_stream_bound(n, block_bytes);
+                    TC_FAIL(ctx, TC_ERR_CAPACITY, "stream needs more than %llu bytes (bound %llu)",
+                            (unsigned long long)cap, (unsigned long long)*bytes);
+                }
+                outj.start(ctx->device, s_out, out + off, d_out[sl], used, hipMemcpyDeviceToHost);
+                off += used;
+            }
+            TC_HIP(ctx, outj.join());
+            *bytes = off;
+        } catch (const TcFail &f) {
+            rc = f.code;
+        }
+        (void)in.join();
+        (void)outj.join();
+    }
+    (void)hipStreamSynchronize(ctx->stream);
+    for (int i = 0; i < 2; i++) {
+        if (d_text[i]) (void)hipFree(d_text[i]);
+        if (d_out[i]) (void)hipFree(d_out[i]);
+    }
+    if (d_count) (void)hipFree(d_count);
+    if (d_value) (void)hipFree(d_value);
+    if (s_in) (void)hipStreamDestroy(s_in);
+    if (s_out) (void)hipStreamDestroy(s_out);
+    if (rc != TC_OK) throw TcFail{rc};
+    TC_API_END(ctx)
+}
+
+// walks the containers of a stream in HOST memory: offsets, total text length, largest record
+struct StreamIndex {
+    std::vector<u64> off, len, n, nruns;
+    u64 n_total = 0, n_max = 0, len_max = 0, nruns_max = 0;
+};
+static StreamIndex stream_index(tc_ctx *ctx, const u8 *stream, u64 bytes) {
+    StreamIndex ix;
+    if (!stream || bytes < TC_CONTAINER_HEADER) TC_FAIL(ctx, TC_ERR_MALFORMED, "stream shorter than one container header");
+    u64 off = 0;
+    while (off < bytes) {
+        if (bytes - off < TC_CONTAINER_HEADER) TC_FAIL(ctx, TC_ERR_MALFORMED, "stream ends inside a container header");
+        ContainerHeader h;
+        memcpy(&h, stream + off, sizeof h);
+        if (memcmp(h.magic, kContainerMagic, 8) != 0) TC_FAIL(ctx, TC_ERR_MALFORMED, "not a textcomp container");
+        if (h.n > TC_MAX_N || h.nruns > (u64)TC_MAX_N + 2 || h.body_bytes > bytes - off - TC_CONTAINER_HEADER)
+            TC_FAIL(ctx, TC_ERR_MALFORMED, "container header is inconsistent");
+        const u64 len = TC_CONTAINER_HEADER + h.body_bytes;
+        ix.off.push_back(off); ix.len.push_back(len); ix.n.push_back(h.n); ix.nruns.push_back(h.nruns);
+        ix.n_total += h.n;
+        if (h.n > ix.n_max) ix.n_max = h.n;
+        if (len > ix.len_max) ix.len_max = len;
+        if (h.nruns > ix.nruns_max) ix.nruns_max = h.nruns;
+        off += len;
+    }
+    return ix;
+}
+
+int tc_stream_info(tc_ctx *ctx, const uint8_t *stream, uint64_t bytes, uint64_t *n_total, uint64_t *nblocks) {
+    if (!ctx) return TC_ERR_ARG;
+    try {
+        const StreamIndex ix = stream_index(ctx, stream, bytes);
+        if (n_total) *n_total = ix.n_total;
+        if (nblocks) *nblocks = ix.off.size();
+        return TC_OK;
+    } catch (const TcFail &f) {
+        return f.code;
+    }
+}
+
+int tc_decode_stream(tc_ctx *ctx, const uint8_t *stream, uint64_t bytes, uint8_t *text, uint64_t *n_out) {
+    TC_API_BEGIN(ctx)
+    if (!n_out) TC_FAIL(ctx, TC_ERR_ARG, "bad argument");
+    const u64 cap = *n_out;
+    *n_out = 0;
+    const StreamIndex ix = stream_index(ctx, stream, bytes);
+    if (ix.n_total > cap) {
+        *n_out = ix.n_total;
+        TC_FAIL(ctx, TC_ERR_CAPACITY, "text needs %llu bytes", (unsigned long long)ix.n_total);
+    }
+    if (ix.n_total && !text) TC_FAIL(ctx, TC_ERR_ARG, "null buffer");
+    const u64 nb = ix.off.size();
+    u8 *d_in[2] = {nullptr, nullptr}, *d_text[2] = {nullptr, nullptr};
+    u32 *d_count = nullptr;
+    u16 *d_value = nullptr;
+    hipStream_t s_in = nullptr, s_out = nullptr;
+    int rc = TC_OK;
+    {
+        CopyJob in, outj;
+        try {
+            TC_HIP(ctx, hipStreamCreateWithFlags(&s_in, hipStreamNonBlocking));
+            TC_HIP(ctx, hipStreamCreateWithFlags(&s_out, hipStreamNonBlocking));
+            for (int i = 0; i < (nb > 1 ? 2 : 1); i++) {
+                TC_HIP(ctx, hipMalloc((void **)&d_in[i], ix.len_max + 16));
+                TC_HIP(ctx, hipMalloc((void **)&d_text[i], ix.n_max + 16));
+            }
+            TC_HIP(ctx, hipMalloc((void **)&d_count, (ix.nruns_max + 1) * sizeof(u32)));
+            TC_HIP(ctx, hipMalloc((void **)&d_value, (ix.nruns_max + 1) * sizeof(u16)));
+            in.start(ctx->device, s_in, d_in[0], stream + ix.off[0], ix.len[0], hipMemcpyHostToDevice);
+            u64 toff = 0;
+            for (u64 k = 0; k < nb; k++) {
+                const int sl = (int)(k & 1);
+                TC_HIP(ctx, in.join());
+                if (k + 1 < nb)
+                    in.start(ctx->device, s_in, d_in[sl ^ 1], stream + ix.off[k + 1], ix.len[k + 1],
+                             hipMemcpyHostToDevice);
+                tc_block dev;
+                memset(&dev, 0, sizeof dev);
+                dev.nruns = ix.nruns_max; dev.run_count = d_count; dev.run_value = d_value;
+                container_read_device(ctx, d_in[sl], ix.len[k], &dev);
+                if (dev.n != ix.n[k]) TC_FAIL(ctx, TC_ERR_MALFORMED, "container header changed");
+                // d_text[sl] was last read by the copy of record k-2, joined before record k-1 started
+                if (dev.n) {
+                    if (dev.nruns == 0) TC_FAIL(ctx, TC_ERR_MALFORMED, "container holds no runs");
+                    decode_device(ctx, &dev, d_text[sl]);
+                    TC_HIP(ctx, hipStreamSynchronize(ctx->stream));
+                }
+                TC_HIP(ctx, outj.join());
+                outj.start(ctx->device, s_out, text + toff, d_text[sl], dev.n, hipMemcpyDeviceToHost);
+                toff += dev.n;
+            }
+            TC_HIP(ctx, outj.join());
+            *n_out = toff;
+        } catch (const TcFail &f) {
+            rc = f.code;
+        }
+        (void)in.join();
+        (void)outj.join();
+    }
+    (void)hipStreamSynchronize(ctx->stream);
+    for (int i = 0; i < 2; i++) {
+        if (d_in[i]) (void)hipFree(d_in[i]);
+        if (d_text[i]) (void)hipFree(d_text[i]);
+    }
+    if (d_count) (void)hipFree(d_count);
+    if (d_value) (void)hipFree(d_value);
+    if (s_in) (void)hipStreamDestroy(s_in);
+    if (s_out) (void)hipStreamDestroy(s_out);
     if (rc != TC_OK) throw TcFail{rc};
     TC_API_END(ctx)
 }

@@ -250,6 +250,39 @@ class Context:
         self._check(self._lib.tc_decode_container(self._h, _ptr(b), len(b), _ptr(out), C.byref(got)))
         return out[:got.value].tobytes()
 
+    # ------------------------------------------------------ chunked stream
+    def encode_stream(self, text, block_bytes=0, cap=None):
+        """text of any length -> containers of independent records of block_bytes, back to back
+        (copies overlap the encode); see textcomp.h.  Without `cap` the output buffer starts at
+        2 bytes per input byte and falls back to tc_stream_bound when that is too small."""
+        t = _u8(text)
+        n = len(t)
+        bound = int(self._lib.tc_stream_bound(n, block_bytes))
+        caps = [int(cap)] if cap is not None else sorted({min(bound, 2 * n + 4096 * (1 + n // max(int(block_bytes) or (1 << 30), 1))), bound})
+        for i, c in enumerate(caps):
+            out = np.empty(max(c, 1), np.uint8)
+            used = C.c_uint64(c)
+            rc = self._lib.tc_encode_stream(self._h, _ptr(t), n, int(block_bytes), _ptr(out), C.byref(used))
+            if rc == _lib.TC_ERR_CAPACITY and i + 1 < len(caps):
+                continue
+            self._check(rc)
+            return out[:used.value].tobytes()
+
+    def stream_info(self, blob):
+        """(total text bytes, number of records) of a stream."""
+        b = np.frombuffer(bytes(blob), np.uint8)
+        n, nb = C.c_uint64(), C.c_uint64()
+        self._check(self._lib.tc_stream_info(self._h, _ptr(b), len(b), C.byref(n), C.byref(nb)))
+        return n.value, nb.value
+
+    def decode_stream(self, blob):
+        b = np.frombuffer(bytes(blob), np.uint8)
+        n, _ = self.stream_info(b)
+        out = np.empty(max(n, 1), np.uint8)
+        got = C.c_uint64(n)
+        self._check(self._lib.tc_decode_stream(self._h, _ptr(b), len(b), _ptr(out), C.byref(got)))
+        return out[:got.value].tobytes()
+
     # ----------------------------------------------------------- FM-index
     def fm_build(self, text):
         return FMIndexHandle(self, text)

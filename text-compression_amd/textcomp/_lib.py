@@ -81,6 +81,10 @@ SYMBOLS = [
     ("tc_encode_container", _INT, [_P, _P, _U64, _P, _PU64]),
     ("tc_container_info", _INT, [_P, _P, _U64, _PU64, _PU64]),
     ("tc_decode_container", _INT, [_P, _P, _U64, _P, _PU64]),
+    ("tc_stream_bound", _U64, [_U64, _U64]),
+    ("tc_encode_stream", _INT, [_P, _P, _U64, _U64, _P, _PU64]),
+    ("tc_stream_info", _INT, [_P, _P, _U64, _PU64, _PU64]),
+    ("tc_decode_stream", _INT, [_P, _P, _U64, _P, _PU64]),
     ("tc_fm_build", _INT, [_P, _P, _U64, C.POINTER(_P)]),
     ("tc_fm_free", None, [_P]),
     ("tc_fm_count", _INT, [_P, _P, _P, _P, _U64, _P]),
