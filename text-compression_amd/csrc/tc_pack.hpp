@@ -273,26 +273,65 @@ __global__ __launch_bounds__(UP_NT) void unpack_nib_kernel(UnpackNibArgs a) {
 // ---- byte formats (6 < sigma) ------------------------------------------------------
 // bytes per run: 1 (sigma <= 16) or 2 (value byte, count byte with escape; the ninth value bit
 // of sigma = 257 rides in the count byte's top bit -> counts escape at 127)
+// byte formats.  A block owns PR_TILE consecutive runs (a thread 8 of them); escapes are listed in
+// run order -- pass 1 counts them per block, a scan gives every block its slot, pass 2 writes -- so
+// that the packed bytes are a function of the runs alone.
+#define PR_TILE 2048
+__device__ __forceinline__ bool pr_escapes(int bpr, u32 c) { return bpr == 1 ? c >= 15 : c >= 127; }
+__global__ __launch_bounds__(256) void pack_runs_count_kernel(const u32 *__restrict__ cnt, u64 nruns, int bpr,
+                                                              u64 *__restrict__ tcnt) {
+    __shared__ u32 s[4];
+    const u64 base = (u64)blockIdx.x * PR_TILE;
+    u32 e = 0;
+    for (int k = 0; k < 8; k++) {
+        const u64 i = base + (u64)k * 256 + threadIdx.x;
+        if (i < nruns && pr_escapes(bpr, cnt[i])) e++;
+    }
+    for (int d = 32; d >= 1; d >>= 1) e += __shfl_xor(e, d, 64);
+    if ((threadIdx.x & 63) == 0) s[threadIdx.x >> 6] = e;
+    __syncthreads();
+    if (threadIdx.x == 0) tcnt[blockIdx.x] = (u64)s[0] + s[1] + s[2] + s[3];
+}
 __global__ __launch_bounds__(256) void pack_runs_kernel(const u32 *__restrict__ cnt,
                                                         const u16 *__restrict__ val, u64 nruns,
                                                         int bpr, u8 *__restrict__ out,
-                                                        u32 *__restrict__ esc, u32 *nesc, u64 esc_cap) {
-    for (u64 k = (u64)blockIdx.x * 256 + threadIdx.x; k < nruns; k += (u64)gridDim.x * 256) {
-        const u32 c = cnt[k], v = val[k];
-        bool e;
+                                                        u32 *__restrict__ esc, const u64 *__restrict__ tcnt,
+                                                        u64 esc_cap) {
+    __shared__ u32 s[4];
+    const u64 base = (u64)blockIdx.x * PR_TILE + (u64)threadIdx.x * 8;
+    u32 c[8], ne = 0;
+    for (int k = 0; k < 8; k++) {
+        const u64 i = base + k;
+        c[k] = 0;
+        if (i >= nruns) continue;
+        c[k] = cnt[i];
+        const u32 v = val[i];
+        const bool e = pr_escapes(bpr, c[k]);
+        ne += e;
         if (bpr == 1) {
-            e = c >= 15;
-            out[k] = (u8)((v & 15u) | ((e ? 15u : c) << 4));
+            out[i] = (u8)((v & 15u) | ((e ? 15u : c[k]) << 4));
         } else {
-            e = c >= 127;
-            out[2 * k] = (u8)v;
-            out[2 * k + 1] = (u8)((e ? 127u : c) | ((v >> 8) << 7));
+            out[2 * i] = (u8)v;
+            out[2 * i + 1] = (u8)((e ? 127u : c[k]) | ((v >> 8) << 7));
         }
-        if (e) {
-            u32 slot = atomicAdd(nesc, 1u);
-            if (slot < esc_cap) {
-                esc[2 * (u64)slot] = (u32)k;
-                esc[2 * (u64)slot + 1] = c;
+    }
+    u32 inc = ne;
+    for (int d = 1; d < 64; d <<= 1) {
+        const u32 t = __shfl_up(inc, d, 64);
+        if ((int)(threadIdx.x & 63) >= d) inc += t;
+    }
+    if ((threadIdx.x & 63) == 63) s[threadIdx.x >> 6] = inc;
+    __syncthreads();
+    u64 slot = tcnt[blockIdx.x] + (inc - ne);
+    for (int w = 0; w < (int)(threadIdx.x >> 6); w++) slot += s[w];
+    if (ne) {
+        for (int k = 0; k < 8; k++) {
+            if (base + k < nruns && pr_escapes(bpr, c[k])) {
+                if (slot < esc_cap) {
+                    esc[2 * slot] = (u32)(base + k);
+                    esc[2 * slot + 1] = c[k];
+                }
+                slot++;
             }
         }
     }

@@ -719,16 +719,27 @@ static void block_pack_device(tc_ctx *ctx, const tc_block *blk, uint8_t *d_packe
     }
     const u64 esc_cap = (cap - body) / 8;
     u32 *esc = reinterpret_cast<u32 *>(d_packed + body);
-    u32 *d_nesc = reinterpret_cast<u32 *>(ctx->d_scalars + 14);
-    tc_memset_async(ctx, d_nesc, 0, sizeof(u64));
-    u32 grid = tc_cdiv(nruns, 256 * 8);
-    if (grid > 8192) grid = 8192;
-    pack_runs_kernel<<<grid, 256, 0, ctx->stream>>>(blk->run_count, blk->run_value, nruns, bpr, d_packed,
-                                                   esc, d_nesc, esc_cap);
+    const u32 tiles = tc_cdiv(nruns, PR_TILE);
+    u64 *tcnt = nullptr;
+    {
+        auto carve = [&](Arena &A) { tcnt = A.get<u64>((size_t)tiles + 2); };
+        Arena dry(nullptr);
+        carve(dry);
+        tc_ws_reserve(ctx, dry.off);
+        Arena A(ctx->ws);
+        carve(A);
+    }
+    if (body >= 8) tc_memset_async(ctx, d_packed + body - 8, 0, 8);   // the alignment padding is part of the bytes
+    pack_runs_count_kernel<<<tiles, 256, 0, ctx->stream>>>(blk->run_count, nruns, bpr, tcnt);
     TC_LAUNCH_CHECK(ctx);
-    tc_d2h(ctx, &ctx->h_scalars[14], ctx->d_scalars + 14, sizeof(u64));
+    scan64_spine_kernel<<<1, 1024, 0, ctx->stream>>>(tcnt, tiles);
+    TC_LAUNCH_CHECK(ctx);
+    pack_runs_kernel<<<tiles, 256, 0, ctx->stream>>>(blk->run_count, blk->run_value, nruns, bpr, d_packed,
+                                                    esc, tcnt, esc_cap);
+    TC_LAUNCH_CHECK(ctx);
+    tc_d2h(ctx, &ctx->h_scalars[14], tcnt + tiles, sizeof(u64));
     TC_HIP(ctx, hipStreamSynchronize(ctx->stream));
-    *nesc = (u32)ctx->h_scalars[14];
+    *nesc = ctx->h_scalars[14];
     *packed_bytes = body + 8 * *nesc;
     if (*nesc > esc_cap)
         TC_FAIL(ctx, TC_ERR_CAPACITY, "packed runs need %llu bytes", (unsigned long long)*packed_bytes);
