@@ -115,6 +115,56 @@ def test_mtf_general_sigma(ctx, sigma, monkeypatch):
         assert np.array_equal(dec, sym)
 
 
+def _texts_257():
+    rng = np.random.default_rng(257)
+    out = []
+    for n in (300, 5000, 40000, 300000):
+        t = rng.integers(0, 256, n).astype(np.uint8)
+        t[rng.permutation(n)[:256]] = np.arange(256, dtype=np.uint8)
+        out.append(t.tobytes())
+    # skewed: few values dominate, the others turn up one by one, far apart
+    n = 600000
+    t = rng.choice(np.array([65, 66, 67, 200], np.uint8), n, p=[0.5, 0.3, 0.15, 0.05])
+    pos = np.sort(rng.permutation(n)[:256])
+    t[pos] = rng.permutation(256).astype(np.uint8)
+    out.append(t.tobytes())
+    out.append(bytes(range(256)) * 700)                      # periodic, every value
+    out.append(bytes(range(255, -1, -1)) + b"\x00" * 70000)   # sentinel row near one end of the BWT
+    out.append(b"\xff" * 70000 + bytes(range(256)))
+    return out
+
+
+@pytest.mark.parametrize("t", _texts_257(), ids=lambda t: "n%d" % len(t))
+def test_sigma_257_sentinel_split(ctx, t, monkeypatch):
+    """All 256 byte values + the sentinel: the 256-symbol lane chunks with their fix-ups (encode:
+    +1 at first occurrences; decode: the chain of rows whose rank exceeds the number of values met)
+    give the oracle's block, decode it, and agree with the nine-bit path; a block whose primary does
+    not match its index stream decodes as on the nine-bit path."""
+    _, eprim, sym = _expect_bwt(t)
+    eidx, efl = O.mtf_encode_arr(sym)
+    ec, ev = O.rle_encode_u32_arr(eidx)
+    blk = ctx.encode(t)
+    assert blk["sigma"] == 257 and blk["primary"] == eprim and blk["final_list"].tolist() == efl.tolist()
+    assert np.array_equal(blk["run_count"], ec) and np.array_equal(blk["run_value"], ev)
+    assert ctx.decode(blk) == t
+    bad = dict(blk)
+    bad["primary"] = blk["primary"] - 1 if blk["primary"] > 1 else blk["primary"] + 1
+
+    def outcome(b):
+        import textcomp
+        try:
+            return ctx.decode(b)
+        except textcomp.TcError as e:
+            return ("error", e.args[0])
+    got_bad = outcome(bad)
+    monkeypatch.setenv("TC_MTF_SENTINEL_SPLIT", "0")
+    blk0 = ctx.encode(t)
+    assert blk0["final_list"].tolist() == efl.tolist() and np.array_equal(blk0["run_count"], ec)
+    assert np.array_equal(blk0["run_value"], ev)
+    assert ctx.decode(blk) == t
+    assert outcome(bad) == got_bad
+
+
 @pytest.mark.parametrize("t", TEXTS, ids=_ids)
 def test_rle(ctx, t):
     eL, eprim, sym = _expect_bwt(t)

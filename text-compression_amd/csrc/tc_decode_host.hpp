@@ -457,10 +457,15 @@ static void imtf_lane_launch(tc_ctx *ctx, const u16 *d_idx, u64 N, u32 sigma, u1
 }
 
 // seqFromMTF: initial list = sort(unique(list)) (MTF/Internal.hs:214).
+// primary / d_idx_rw (fused decode only): the row of the one sentinel and the same index buffer,
+// writable -- lets sigma = 257 take the 256-symbol lane chunks (tc_mtf.hpp, "sigma = 257")
 static void mtf_decode_device(tc_ctx *ctx, Arena &A, const u16 *d_idx, u64 N, const i16 *list,
-                              u32 nlist, i16 *d_out, bool dry) {
+                              u32 nlist, i16 *d_out, bool dry, i64 primary = -1, u16 *d_idx_rw = nullptr) {
     const u32 chunks = tc_cdiv(N, MTFG_CH);
     u16 *perms = A.get<u16>(((size_t)chunks + 1) * 320);
+    const u32 tiles257 = tc_cdiv(N, M257_TILE);
+    u16 *tmax = A.get<u16>((size_t)tiles257 + 8);
+    u32 *fix = A.get<u32>(512);
     if (dry) return;
     bool seen[257] = {false};
     for (u32 i = 0; i < nlist; i++) {
@@ -472,6 +477,33 @@ static void mtf_decode_device(tc_ctx *ctx, Arena &A, const u16 *d_idx, u64 N, co
     for (int v = 0; v < 257; v++)
         if (seen[v]) tab.v[sigma++] = (i16)(v - 1);
     for (u32 v = sigma; v < 260; v++) tab.v[v] = 0;
+    if (sigma == 257 && d_idx_rw && primary > 0 && (u64)primary < N && env_int("TC_MTF_WAVE_CHUNKS", 0) == 0 &&
+        env_int("TC_MTF_SENTINEL_SPLIT", 1) != 0) {
+        hipStream_t s = ctx->stream;
+        u64 *res = ctx->d_scalars + 20;
+        tc_memset_async(ctx, res, 0, 3 * sizeof(u64));
+        imtf257_tmax_kernel<<<tiles257, 256, 0, s>>>(d_idx, N, tmax);
+        TC_LAUNCH_CHECK(ctx);
+        imtf257_chain_kernel<<<1, 256, 0, s>>>(d_idx, N, (u64)primary, tmax, fix, res);
+        TC_LAUNCH_CHECK(ctx);
+        u32 grid = tc_cdiv(N, 256 * 16);
+        if (grid > 8192) grid = 8192;
+        imtf257_check_kernel<<<grid, 256, 0, s>>>(d_idx, N, (u64)primary, fix, res);
+        TC_LAUNCH_CHECK(ctx);
+        tc_d2h(ctx, &ctx->h_scalars[20], res, 3 * sizeof(u64));
+        TC_HIP(ctx, hipStreamSynchronize(s));
+        if (ctx->h_scalars[22] == 0) {
+            imtf257_apply_kernel<<<1, 512, 0, s>>>(d_idx_rw, (u64)primary, fix, res);
+            TC_LAUNCH_CHECK(ctx);
+            SymTab bytes;
+            for (int v = 0; v < 260; v++) bytes.v[v] = (i16)(v < 256 ? v : 0);
+            imtf_lane_launch<4>(ctx, d_idx, N, 256, perms, bytes, d_out);
+            imtf257_sentinel_kernel<<<1, 1, 0, s>>>(d_out, (u64)primary);
+            TC_LAUNCH_CHECK(ctx);
+            return;
+        }
+        // not the index stream of a BWT with its sentinel at `primary`: the nine-bit path below
+    }
     if (sigma <= 256 && env_int("TC_MTF_WAVE_CHUNKS", 0) == 0) {
         const u32 rows = (sigma + 63) / 64;
         if (rows <= 1) imtf_lane_launch<1>(ctx, d_idx, N, sigma, perms, tab, d_out);
@@ -532,7 +564,7 @@ static void decode_device(tc_ctx *ctx, const tc_block *blk, u8 *d_text) {
                     (unsigned long long)got, (unsigned long long)N);
         hi = A.off > hi ? A.off : hi;
         A.off = mark;
-        mtf_decode_device(ctx, A, d_idx, N, blk->final_list, blk->sigma, d_sym, dry);
+        mtf_decode_device(ctx, A, d_idx, N, blk->final_list, blk->sigma, d_sym, dry, (i64)blk->primary, d_idx);
         hi = A.off > hi ? A.off : hi;
         A.off = mark;
         SymAcc acc{d_sym};

@@ -621,7 +621,7 @@ static void mtf_encode_device(tc_ctx *ctx, Arena &A, Acc acc, u64 N, const u32 *
     const u32 chunks = tc_cdiv(N, MTFG_CH);
     u32 *d_counts = A.get<u32>(260);
     u64 *t_perm = A.get<u64>(tiles + 1);
-    u32 *t_mask = A.get<u32>(tiles + 1);
+    u32 *t_mask = A.get<u32>(tiles + 1 > 512 ? tiles + 1 : 512);
     u16 *lists = A.get<u16>(((size_t)chunks + 1) * 320);
     u32 *seen = A.get<u32>(chunks + 1);
     if (dry) return;
@@ -672,6 +672,36 @@ static void mtf_encode_device(tc_ctx *ctx, Arena &A, Acc acc, u64 N, const u32 *
         for (int v = 0; v < 257; v++) lut.v[v] = al.code_of_sym[v];
         int rows;
         u32 last;  // slot of the final list
+        if constexpr (std::is_same<Acc, BwtAcc>::value) {
+            // sigma = 257 with the one sentinel of a BWT: 256-symbol lane chunks + fix-ups (tc_mtf.hpp)
+            if (al.sigma == 257 && acc.primary > 0 && (u64)acc.primary < N &&
+                env_int("TC_MTF_WAVE_CHUNKS", 0) == 0 && env_int("TC_MTF_SENTINEL_SPLIT", 1) != 0) {
+                u32 bytes_only[257];
+                memcpy(bytes_only, counts257, sizeof bytes_only);
+                bytes_only[0] = 0;
+                Alphabet ab;
+                ab.build(bytes_only);   // 256 symbols, code = byte value
+                BwtAcc dup = acc;
+                dup.dup = 1;
+                mtf_lane_launch<BwtAcc, 4>(ctx, dup, N, ab, lists, seen, d_idx);
+                u32 *first = t_mask;    // 512 words (tiles + 1 >= 1: sized below)
+                tc_memset_async(ctx, first, 0xff, 512 * sizeof(u32));
+                u32 grid = tc_cdiv(N, 256 * 64);
+                if (grid > 4096) grid = 4096;
+                mtf257_first_kernel<<<grid, 256, 0, s>>>(acc.L, N, (u64)acc.primary, first);
+                TC_LAUNCH_CHECK(ctx);
+                mtf257_fix_kernel<<<1, 512, 0, s>>>(d_idx, first, (u64)acc.primary, ctx->d_scalars + 20);
+                TC_LAUNCH_CHECK(ctx);
+                std::vector<u16> fl(256);
+                tc_d2h(ctx, fl.data(), lists + (size_t)tc_cdiv(N, GM_TILE) * 256, 256 * sizeof(u16));
+                tc_d2h(ctx, &ctx->h_scalars[20], ctx->d_scalars + 20, 2 * sizeof(u64));
+                TC_HIP(ctx, hipStreamSynchronize(s));
+                const u32 after = (u32)ctx->h_scalars[21];   // distinct values met after the sentinel
+                for (u32 i = 0, k = 0; i < 257; i++)
+                    final_list[i] = i == after ? (i16)-1 : ab.sym_of_code[fl[k++]];
+                return;
+            }
+        }
         if (al.sigma <= 256 && env_int("TC_MTF_WAVE_CHUNKS", 0) == 0) {
             rows = (int)((al.sigma + 63) / 64);
             last = tc_cdiv(N, GM_TILE);

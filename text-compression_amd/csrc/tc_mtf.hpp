@@ -20,6 +20,7 @@
 struct BwtAcc {  // (L, primary): the shape bytestringToBWT returns
     const u8 *L;
     i64 primary;
+    int dup = 0;  // lane-chunk staging only: the primary slot repeats the symbol before it (see "sigma = 257")
     __device__ __forceinline__ int operator()(u64 j) const {
         return (i64)j == primary ? -1 : (int)L[j];
     }
@@ -709,7 +710,8 @@ __device__ __forceinline__ void gm_stage<BwtAcc>(BwtAcc acc, u64 N, u64 base, co
         __syncthreads();
         if (threadIdx.x == 0) {
             u32 p = (u32)(acc.primary - (i64)base);
-            s_code[(p / GM_CH) * GM_STRIDE + (p % GM_CH)] = s_lut[0];
+            s_code[(p / GM_CH) * GM_STRIDE + (p % GM_CH)] =
+                acc.dup ? s_lut[(u32)acc.L[acc.primary - 1] + 1] : s_lut[0];
         }
     }
 }
@@ -1194,5 +1196,180 @@ __global__ __launch_bounds__(GM_NT) void imtf_gm_kernel(GmiArgs a) {
             if (base + p < a.N) a.out[base + p] = s_tab[s_code[(p / GM_CH) * GM_STRIDE + (p % GM_CH)]];
     }
 }
+
+// ---- sigma = 257: every byte value AND the sentinel -----------------------------------
+// Nine-bit codes do not fit the byte lists of the lane-chunk kernels, but the sentinel of a BWT
+// occurs exactly once, at the primary row p > 0, and the initial list has it in front.  Until p
+// the list therefore reads [the d byte values met so far, by recency] Nothing [the others,
+// sorted]; after p the same with "met since p".  So the ranks are those of a 256-symbol MTF over
+// the bytes alone (row p repeating the byte before it: rank 0, list untouched), plus one for every
+// FIRST occurrence of a byte value before p and for every first occurrence after p; row p itself
+// gets d = the number of distinct values before it, and the final list is the byte list with
+// Nothing inserted behind the values met after p.
+#define M257_NONE 0xffffffffu
+// first[b] = first row < p holding byte b, first[256 + b] = first row > p (M257_NONE: none)
+__global__ __launch_bounds__(256) void mtf257_first_kernel(const u8 *__restrict__ L, u64 N, u64 p,
+                                                           u32 *__restrict__ first) {
+    __shared__ u32 s_first[512];
+    for (int i = threadIdx.x; i < 512; i += 256) s_first[i] = M257_NONE;
+    __syncthreads();
+    for (u64 j = (u64)blockIdx.x * 256 + threadIdx.x; j < N; j += (u64)gridDim.x * 256) {
+        if (j == p) continue;
+        const u32 k = (u32)L[j] + (j > p ? 256u : 0u);
+        if ((u32)j < s_first[k]) atomicMin(&s_first[k], (u32)j);
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < 512; i += 256)
+        if (s_first[i] != M257_NONE) atomicMin(&first[i], s_first[i]);
+}
+// res[0] = distinct values before p (= the rank of the sentinel), res[1] = distinct values after p
+__global__ __launch_bounds__(512) void mtf257_fix_kernel(u16 *__restrict__ idx, const u32 *__restrict__ first,
+                                                         u64 p, u64 *__restrict__ res) {
+    __shared__ u32 s_n[2];
+    if (threadIdx.x < 2) s_n[threadIdx.x] = 0;
+    __syncthreads();
+    const u32 f = first[threadIdx.x];
+    if (f != M257_NONE) {
+        idx[f] += 1;
+        atomicAdd(&s_n[threadIdx.x >> 8], 1u);
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        idx[p] = (u16)s_n[0];
+        res[0] = s_n[0];
+        res[1] = s_n[1];
+    }
+}
+
+// The inverse.  d (the number of distinct values met) grows at every row whose rank exceeds it,
+// at most 256 times before p and 256 times after; those rows are exactly the first occurrences.
+#define M257_TILE 4096
+__global__ __launch_bounds__(256) void imtf257_tmax_kernel(const u16 *__restrict__ idx, u64 N,
+                                                           u16 *__restrict__ tmax) {
+    __shared__ u32 s[4];
+    const u64 base = (u64)blockIdx.x * M257_TILE;
+    u32 m = 0;
+    for (int k = 0; k < M257_TILE / 256; k++) {
+        const u64 j = base + (u64)k * 256 + threadIdx.x;
+        if (j < N) {
+            const u32 r = idx[j];
+            m = r > m ? r : m;
+        }
+    }
+    for (int d = 32; d >= 1; d >>= 1) {
+        const u32 o = (u32)__shfl_xor((int)m, d, 64);
+        m = o > m ? o : m;
+    }
+    if ((threadIdx.x & 63) == 0) s[threadIdx.x >> 6] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        u32 a = s[0] > s[1] ? s[0] : s[1], b = s[2] > s[3] ? s[2] : s[3];
+        tmax[blockIdx.x] = (u16)(a > b ? a : b);
+    }
+}
+// block-wide minimum of v (M257_NONE = no candidate); every thread returns it
+__device__ __forceinline__ u32 m257_block_min(u32 v, u32 *s_red) {
+    for (int d = 32; d >= 1; d >>= 1) {
+        const u32 o = (u32)__shfl_xor((int)v, d, 64);
+        v = o < v ? o : v;
+    }
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) s_red[threadIdx.x >> 6] = v;
+    __syncthreads();
+    u32 a = s_red[0] < s_red[1] ? s_red[0] : s_red[1], b = s_red[2] < s_red[3] ? s_red[2] : s_red[3];
+    return a < b ? a : b;
+}
+// one block: fix[0..res[0]) = the first occurrences before p, fix[256..256+res[1]) = those after p
+__global__ __launch_bounds__(256) void imtf257_chain_kernel(const u16 *__restrict__ idx, u64 N, u64 p,
+                                                            const u16 *__restrict__ tmax,
+                                                            u32 *__restrict__ fix, u64 *__restrict__ res) {
+    __shared__ u16 s_r[M257_TILE];
+    __shared__ u32 s_red[4];
+    const u32 tid = threadIdx.x;
+    for (int reg = 0; reg < 2; reg++) {
+        const u64 lo = reg ? p + 1 : 0, hi = reg ? N : p;
+        u32 d = 0;
+        u64 cur = lo;
+        while (cur < hi && d < 256) {
+            // the next tile that can hold a rank above d (the tile `cur` is inside is always read)
+            u64 t = cur / M257_TILE;
+            if (cur % M257_TILE == 0) {
+                const u64 tend = (hi + M257_TILE - 1) / M257_TILE;
+                u32 found = M257_NONE;
+                while (t < tend) {
+                    u32 c = M257_NONE;
+                    for (int q = 0; q < 8; q++) {
+                        const u64 tt = t + (u64)tid * 8 + q;
+                        if (c == M257_NONE && tt < tend && tmax[tt] > d) c = (u32)(tt - t);
+                    }
+                    found = m257_block_min(c, s_red);
+                    if (found != M257_NONE) break;
+                    t += 2048;
+                }
+                if (found == M257_NONE) break;
+                t += found;
+                cur = t * M257_TILE > cur ? t * M257_TILE : cur;
+            }
+            const u64 tb = t * M257_TILE;
+            const u64 te = tb + M257_TILE < hi ? tb + M257_TILE : hi;
+            __syncthreads();
+            for (u32 q = tid; q < M257_TILE; q += 256) s_r[q] = tb + q < te ? idx[tb + q] : (u16)0;
+            __syncthreads();
+            for (;;) {
+                u32 c = M257_NONE;
+                const u32 q0 = tid * 16;
+                for (u32 q = q0; q < q0 + 16; q++)
+                    if (c == M257_NONE && tb + q >= cur && s_r[q] > d) c = q;
+                const u32 f = m257_block_min(c, s_red);
+                if (f == M257_NONE) break;
+                if (tid == 0) fix[reg * 256 + d] = (u32)(tb + f);
+                d++;
+                cur = tb + f + 1;
+                if (d >= 256) break;
+            }
+            if (d < 256) cur = tb + M257_TILE;
+        }
+        if (tid == 0) res[reg] = d;
+        __syncthreads();
+    }
+}
+// every row other than p must have a rank different from the d of its stretch (a rank equal to d
+// would be another sentinel), and row p the rank d; res[2] != 0 otherwise (the caller then takes
+// the nine-bit path, which reproduces the reference on any index stream)
+__global__ __launch_bounds__(256) void imtf257_check_kernel(const u16 *__restrict__ idx, u64 N, u64 p,
+                                                            const u32 *__restrict__ fix,
+                                                            u64 *__restrict__ res) {
+    __shared__ u32 s_fix[512];
+    const u32 nA = (u32)res[0], nB = (u32)res[1];
+    for (int i = threadIdx.x; i < 512; i += 256)
+        s_fix[i] = (i < 256 ? (u32)i < nA : (u32)(i - 256) < nB) ? fix[i] : M257_NONE;
+    __syncthreads();
+    bool bad = false;
+    for (u64 j = (u64)blockIdx.x * 256 + threadIdx.x; j < N; j += (u64)gridDim.x * 256) {
+        const u32 r = idx[j];
+        if (j == p) {
+            bad |= r != nA;
+            continue;
+        }
+        const u32 *f = s_fix + (j > p ? 256 : 0);
+        u32 lo = 0, hi = 256;          // d = number of first occurrences before row j
+        while (lo < hi) {
+            const u32 mid = (lo + hi) >> 1;
+            if (f[mid] < (u32)j) lo = mid + 1;
+            else hi = mid;
+        }
+        bad |= r == lo && !(lo < 256 && f[lo] == (u32)j);
+        bad |= r > 256;
+    }
+    if (__ballot(bad) && (threadIdx.x & 63) == 0) atomicOr((unsigned long long *)&res[2], 1ull);
+}
+__global__ __launch_bounds__(512) void imtf257_apply_kernel(u16 *__restrict__ idx, u64 p,
+                                                            const u32 *__restrict__ fix,
+                                                            const u64 *__restrict__ res) {
+    const u32 t = threadIdx.x;
+    if ((t < 256 ? t < (u32)res[0] : t - 256 < (u32)res[1])) idx[fix[t]] -= 1;
+    if (t == 0) idx[p] = 0;
+}
+__global__ void imtf257_sentinel_kernel(i16 *out, u64 p) { out[p] = -1; }
 
 #endif  // __HIPCC__
