@@ -22,12 +22,12 @@ def markov():
     src = torch.where(keep, torch.zeros_like(idx), idx)
     src = torch.cummax(src, 0).values
     return sym[src].contiguous()
-def zipf_words(vocab=20000, a=1.1):
+def zipf_words(vocab=20000, a=1.1, lo=97, hi=123):
     # English-like: Zipf-distributed words over a random vocabulary, single spaces
     rs = np.random.default_rng(5)
     wl = rs.integers(2, 10, vocab)
     off = np.concatenate([[0], np.cumsum(wl + 1)])
-    flat = rs.integers(97, 123, int(off[-1])).astype(np.uint8)
+    flat = rs.integers(lo, hi, int(off[-1])).astype(np.uint8)
     flat[off[1:] - 1] = 32
     p = 1.0 / np.arange(1, vocab + 1) ** a
     nw = n // 5 + 1000
@@ -69,6 +69,7 @@ classes = {
     "genome_like": genome_like,
     "acgt4": lambda: torch.tensor([65, 67, 71, 84], dtype=torch.uint8, device="cuda")[rnd(4, 0).long()],
     "zipf_words": zipf_words,
+    "binary_words": lambda: zipf_words(lo=0, hi=256),     # the same structure over all 256 byte values (sigma = 257)
     "acgtn": lambda: None,
     "ascii96": lambda: rnd(96, 32),
     "bytes256": lambda: rnd(256),

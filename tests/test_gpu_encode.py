@@ -84,7 +84,8 @@ def test_mtf_general_sigma(ctx, sigma, monkeypatch):
     nsym = sigma - 1 if sigma == 257 or sigma % 2 else sigma       # with / without a Nothing
     with_nothing = nsym < sigma
     alphabet = rng.permutation(256)[:nsym]
-    for N, skew in ((1, 0), (127, 1), (129, 0), (32768, 1), (32769, 0), (100001, 1), (70000, 0)):
+    for N, skew in ((1, 0), (127, 1), (129, 0), (32768, 1), (32769, 0), (100001, 1), (70000, 0),
+                    (1100000, 0), (1100001, 1)):     # >= 2^20: the path is chosen by a sample of the stream
         if skew:
             p = 1.0 / np.arange(1, nsym + 1) ** 1.5
             body = rng.choice(nsym, N, p=p / p.sum())
@@ -100,10 +101,10 @@ def test_mtf_general_sigma(ctx, sigma, monkeypatch):
         eidx, efl = O.mtf_encode_arr(sym)
         idx, fl = ctx.mtf_encode_sym(sym)
         assert np.array_equal(idx, eidx) and fl.tolist() == efl.tolist(), (sigma, N, skew)
-        if N == 100001:
-            monkeypatch.setenv("TC_MTF_WAVE_CHUNKS", "1")
+        if N == 100001 or N == 1100000:
+            monkeypatch.setenv("TC_MTF_WAVE_CHUNKS" if N == 100001 else "TC_MTF_RANK_SAMPLE", "1" if N == 100001 else "0")
             idx, fl = ctx.mtf_encode_sym(sym)
-            monkeypatch.delenv("TC_MTF_WAVE_CHUNKS")
+            monkeypatch.delenv("TC_MTF_WAVE_CHUNKS" if N == 100001 else "TC_MTF_RANK_SAMPLE")
             assert np.array_equal(idx, eidx) and fl.tolist() == efl.tolist()
         if (sym >= 0).all() or int(np.sum(sym < 0)) == 1:
             # (L, primary) accessor form: 16-byte staged loads + sentinel patch
@@ -118,12 +119,12 @@ def test_mtf_general_sigma(ctx, sigma, monkeypatch):
 def _texts_257():
     rng = np.random.default_rng(257)
     out = []
-    for n in (300, 5000, 40000, 300000):
+    for n in (300, 5000, 40000, 1200000):
         t = rng.integers(0, 256, n).astype(np.uint8)
         t[rng.permutation(n)[:256]] = np.arange(256, dtype=np.uint8)
         out.append(t.tobytes())
     # skewed: few values dominate, the others turn up one by one, far apart
-    n = 600000
+    n = 1300000
     t = rng.choice(np.array([65, 66, 67, 200], np.uint8), n, p=[0.5, 0.3, 0.15, 0.05])
     pos = np.sort(rng.permutation(n)[:256])
     t[pos] = rng.permutation(256).astype(np.uint8)
@@ -157,6 +158,10 @@ def test_sigma_257_sentinel_split(ctx, t, monkeypatch):
         except textcomp.TcError as e:
             return ("error", e.args[0])
     got_bad = outcome(bad)
+    monkeypatch.setenv("TC_MTF_RANK_SAMPLE", "0")        # lane chunks whatever the ranks look like
+    blk1 = ctx.encode(t)
+    assert blk1["final_list"].tolist() == efl.tolist() and np.array_equal(blk1["run_count"], ec)
+    assert np.array_equal(blk1["run_value"], ev)
     monkeypatch.setenv("TC_MTF_SENTINEL_SPLIT", "0")
     blk0 = ctx.encode(t)
     assert blk0["final_list"].tolist() == efl.tolist() and np.array_equal(blk0["run_count"], ec)

@@ -672,15 +672,30 @@ static void mtf_encode_device(tc_ctx *ctx, Arena &A, Acc acc, u64 N, const u32 *
         for (int v = 0; v < 257; v++) lut.v[v] = al.code_of_sym[v];
         int rows;
         u32 last;  // slot of the final list
+        // large alphabets: lane chunks unless the sampled average rank says the symbols are spread
+        // uniformly (tc_mtf.hpp, "which general path?")
+        auto prefers_wave = [&](const Alphabet &ax) {
+            if (ax.sigma <= 128 || N < (u64)MRS_BLOCKS * 256 * MRS_WIN || env_int("TC_MTF_RANK_SAMPLE", 1) == 0)
+                return false;
+            u64 *d_sum = ctx->d_scalars + 23;
+            tc_memset_async(ctx, d_sum, 0, sizeof(u64));
+            mtf_rank_sample_kernel<Acc><<<MRS_BLOCKS, 256, 0, s>>>(acc, N, d_sum);
+            TC_LAUNCH_CHECK(ctx);
+            tc_d2h(ctx, &ctx->h_scalars[23], d_sum, sizeof(u64));
+            TC_HIP(ctx, hipStreamSynchronize(s));
+            const u64 avg = ctx->h_scalars[23] / ((u64)MRS_BLOCKS * 256);   // distinct symbols per window
+            return avg >= (u64)env_int("TC_MTF_WAVE_MIN_DISTINCT", 128);
+        };
         if constexpr (std::is_same<Acc, BwtAcc>::value) {
             // sigma = 257 with the one sentinel of a BWT: 256-symbol lane chunks + fix-ups (tc_mtf.hpp)
+            u32 bytes_only[257];
+            memcpy(bytes_only, counts257, sizeof bytes_only);
+            bytes_only[0] = 0;
+            Alphabet ab;
+            ab.build(bytes_only);   // 256 symbols, code = byte value
             if (al.sigma == 257 && acc.primary > 0 && (u64)acc.primary < N &&
-                env_int("TC_MTF_WAVE_CHUNKS", 0) == 0 && env_int("TC_MTF_SENTINEL_SPLIT", 1) != 0) {
-                u32 bytes_only[257];
-                memcpy(bytes_only, counts257, sizeof bytes_only);
-                bytes_only[0] = 0;
-                Alphabet ab;
-                ab.build(bytes_only);   // 256 symbols, code = byte value
+                env_int("TC_MTF_WAVE_CHUNKS", 0) == 0 && env_int("TC_MTF_SENTINEL_SPLIT", 1) != 0 &&
+                !prefers_wave(ab)) {
                 BwtAcc dup = acc;
                 dup.dup = 1;
                 mtf_lane_launch<BwtAcc, 4>(ctx, dup, N, ab, lists, seen, d_idx);
@@ -702,7 +717,7 @@ static void mtf_encode_device(tc_ctx *ctx, Arena &A, Acc acc, u64 N, const u32 *
                 return;
             }
         }
-        if (al.sigma <= 256 && env_int("TC_MTF_WAVE_CHUNKS", 0) == 0) {
+        if (al.sigma <= 256 && env_int("TC_MTF_WAVE_CHUNKS", 0) == 0 && !prefers_wave(al)) {
             rows = (int)((al.sigma + 63) / 64);
             last = tc_cdiv(N, GM_TILE);
             if (rows == 1) mtf_lane_launch<Acc, 1>(ctx, acc, N, al, lists, seen, d_idx);

@@ -1197,6 +1197,30 @@ __global__ __launch_bounds__(GM_NT) void imtf_gm_kernel(GmiArgs a) {
     }
 }
 
+// ---- which general path?  The lane chunks cost ~ rank / 4 list words per symbol, the wave chunks a
+// constant; on large alphabets with uniformly spread symbols (average rank ~ sigma / 2) the wave
+// chunks win.  The rank of a symbol is the number of distinct symbols since its last occurrence, so
+// the number of distinct symbols in short windows tells the two cases apart: MRS_BLOCKS * 256
+// windows of MRS_WIN symbols spread over the stream, one per lane, a 256-bit set each.
+#define MRS_WIN 256
+#define MRS_BLOCKS 16
+template <class Acc>
+__global__ __launch_bounds__(256) void mtf_rank_sample_kernel(Acc acc, u64 N, u64 *__restrict__ out) {
+    __shared__ u32 s_set[256 * 9];
+    u32 *set = s_set + threadIdx.x * 9;
+    for (int i = 0; i < 8; i++) set[i] = 0;
+    const u64 w = (u64)blockIdx.x * 256 + threadIdx.x;
+    const u64 start = (N - MRS_WIN) / (MRS_BLOCKS * 256 - 1) * w;
+    for (u32 k = 0; k < MRS_WIN; k++) {
+        const u32 c = (u32)(acc(start + k) & 255);
+        set[c >> 5] |= 1u << (c & 31);
+    }
+    u32 sum = 0;
+    for (int i = 0; i < 8; i++) sum += (u32)__popc(set[i]);
+    for (int d = 32; d >= 1; d >>= 1) sum += (u32)__shfl_xor((int)sum, d, 64);
+    if ((threadIdx.x & 63) == 0) atomicAdd((unsigned long long *)out, (unsigned long long)sum);
+}
+
 // ---- sigma = 257: every byte value AND the sentinel -----------------------------------
 // Nine-bit codes do not fit the byte lists of the lane-chunk kernels, but the sentinel of a BWT
 // occurs exactly once, at the primary row p > 0, and the initial list has it in front.  Until p
