@@ -911,13 +911,21 @@ __device__ __forceinline__ u32 rank_of(const RankLookup &r, const u16 *s_lut, u6
                 lo = r.kdir[v];
                 hi = r.kdir[v + 1];
             }
-            while (lo < hi) {
+            while (lo < hi) {   // first element of p's top-bits bucket
                 const u64 mid = (lo + hi) >> 1;
-                const u64 t = r.tkeys[mid] >> r.tshift;
-                const bool less = t < tk || (t == tk && suffix_cmp(r.text, r.n, r.sa[mid], p, r.h0) < 0);
-                if (less) lo = mid + 1; else hi = mid;
+                if ((r.tkeys[mid] >> r.tshift) < tk) lo = mid + 1; else hi = mid;
             }
-            return (u32)lo;
+            // the bucket occupies the same range in tkeys (in pass order) and in the SA (in suffix
+            // order); p's whole key is unique, so its place among the members is the number of
+            // members with a smaller key -- no look at the text or the SA (an untied suffix never
+            // sits in an over-long bucket: those go to the table whole)
+            u32 below = 0;
+            for (u64 j = lo; j < r.N; j++) {
+                const u64 t = r.tkeys[j];
+                if ((t >> r.tshift) != tk) break;
+                below += (t & ~0xffull) < key ? 1u : 0u;
+            }
+            return (u32)lo + below;
         }
         while (lo < hi) {
             u64 mid = (lo + hi) >> 1;
