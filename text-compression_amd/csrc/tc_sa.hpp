@@ -544,10 +544,38 @@ struct FinishArgs {
     u32 *ovbits;       // finish_fix_kernel: one bit per position, set for members of over-long buckets
 };
 
+// tied members are staged per wave and leave with ONE counter update per flush: on inputs with ties in
+// most windows (repeats) a device-scope atomic per window on one address serialises the grid
+// (genome-like 256 MiB: 6.6 ms, of which ~5 ms waiting for the counter)
+#ifndef FIN_STAGE
+#define FIN_STAGE 192   // staged entries per wave (a window adds at most 128)
+#endif
 __global__ __launch_bounds__(FIN_NT) void finish_kernel(FinishArgs a) {
     __shared__ u32 s_low[FIN_NT / 64][128];
+#if FIN_STAGE
+    __shared__ u32 s_stg[FIN_NT / 64][3][FIN_STAGE + 128];
+#endif
     const int w = threadIdx.x >> 6, l = threadIdx.x & 63;
     u32 *low = s_low[w];
+#if FIN_STAGE
+    u32 nstg = 0;   // wave-uniform
+    auto flush = [&]() {
+        u32 base = 0;
+        if (l == 0) base = atomicAdd(&a.counters[0], nstg);
+        base = __shfl(base, 0, 64);
+        __builtin_amdgcn_wave_barrier();
+        for (u32 e = l; e < nstg; e += 64) {
+            const u32 o = base + e;
+            if (o < a.act_cap) {
+                a.out_slot[o] = s_stg[w][0][e];
+                a.out_idx[o] = s_stg[w][1][e];
+                a.out_grp[o] = s_stg[w][2][e];
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+        nstg = 0;
+    };
+#endif
     const u64 N = a.N;
     const u64 wave = (u64)blockIdx.x * (FIN_NT / 64) + w;
     const u64 ws0 = wave * 64 * FIN_WPW;
@@ -660,6 +688,34 @@ __global__ __launch_bounds__(FIN_NT) void finish_kernel(FinishArgs a) {
         const bool actA = ownA && eqA > 0, actB = ownB && eqB > 0;
         const u64 abA = __ballot(actA), abB = __ballot(actB);
         const u32 nact = (u32)__popcll(abA) + (u32)__popcll(abB);
+#if FIN_STAGE
+        if (nact) {
+            if (nstg > FIN_STAGE) flush();
+            if (actA) {
+                const u32 e = nstg + (u32)__popcll(abA & lanemask_lt());
+                s_stg[w][0][e] = (u32)(ws + sA) + rankA;
+                s_stg[w][1][e] = vA;
+                s_stg[w][2][e] = (u32)(ws + sA) + ltA;
+            }
+            if (actB) {
+                const u32 e = nstg + (u32)__popcll(abA) + (u32)__popcll(abB & lanemask_lt());
+                s_stg[w][0][e] = (u32)(ws + sB) + rankB;
+                s_stg[w][1][e] = vB;
+                s_stg[w][2][e] = (u32)(ws + sB) + ltB;
+            }
+            nstg += nact;
+        }
+        if (ownA) {
+            u32 j = (u32)(ws + sA) + rankA;
+            a.sa_out[j] = vA;
+            a.L[j] = (u8)(kA & 0xff);
+        }
+        if (ownB) {
+            u32 j = (u32)(ws + sB) + rankB;
+            a.sa_out[j] = vB;
+            a.L[j] = (u8)(kB & 0xff);
+        }
+#else
         u32 abase = 0;
         if (nact) {
             if (l == 0) abase = atomicAdd(&a.counters[0], nact);
@@ -691,6 +747,7 @@ __global__ __launch_bounds__(FIN_NT) void finish_kernel(FinishArgs a) {
                 }
             }
         }
+#endif
         tprev = lastA;
         hasprev = true;
     };
@@ -701,6 +758,9 @@ __global__ __launch_bounds__(FIN_NT) void finish_kernel(FinishArgs a) {
 #pragma unroll
         for (int win = 0; win < FIN_WPW; win++) window(std::false_type{}, win);
     }
+#if FIN_STAGE
+    if (nstg) flush();
+#endif
 }
 
 // Second pass, launched only when the lean pass met a bucket longer than it handles.  Members of
