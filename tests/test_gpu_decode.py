@@ -109,16 +109,19 @@ def test_rle_decode_long_runs(ctx):
 
 
 @pytest.mark.parametrize("env", [{"TC_IBWT_SCATTER": "0"}, {"TC_IBWT_REWALK": "1"},
-                                 {"TC_IBWT_SCATTER": "0", "TC_IBWT_REWALK": "1"}],
+                                 {"TC_IBWT_SCATTER": "0", "TC_IBWT_REWALK": "1"}, {"TC_IBWT_LF": "0"},
+                                 {"TC_IBWT_LF": "0", "TC_IBWT_REWALK": "1"},
+                                 {"TC_IBWT_LF": "0", "TC_IBWT_SCATTER": "0"}],
                          ids=lambda e: ",".join("%s=%s" % kv for kv in e.items()))
 def test_ibwt_path_selectors(ctx, env, monkeypatch):
     """The alternatives inside the inverse BWT (generic radix sort of the positions instead of the
-    dedicated scatter; every recorded segment treated as overflowed and walked again) decode to
-    the same text."""
+    dedicated scatter; every recorded segment treated as overflowed and walked again; small alphabets
+    by positions instead of by LF over the packed last column) decode to the same text."""
     rng = np.random.default_rng(5)
     texts = [O.gen_acgtn(31, 1 << 20).tobytes(), O.gen_ascii(32, 200000).tobytes(),
              bytes(rng.integers(0, 256, 100000, dtype=np.uint8)),
-             bytes(rng.choice(list(b"ACGT"), 1000).astype(np.uint8)) * 300]
+             bytes(rng.choice(list(b"ACGT"), 1000).astype(np.uint8)) * 300,
+             O.gen_acgtn(33, 127).tobytes(), b"A" * 5000 + b"C", b"AC" * 40000, b"G"]
     blks = [ctx.encode(t) for t in texts]
     for k, v in env.items():
         monkeypatch.setenv(k, v)

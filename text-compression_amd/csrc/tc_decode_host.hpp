@@ -323,6 +323,287 @@ __global__ __launch_bounds__(256) void ibwt_copy_kernel(u32 K, const u32 *__rest
     for (u32 i = lane_id(); i < len; i += 64) text[p0 + i] = src[i];
 }
 
+// ---- small alphabets (<= 5 byte values, one Nothing): the walk by LF instead of by positions ------
+// The position array of the sort above is 4 N bytes and every step of a walk reads 4 of them at a
+// random place.  For DNA-like records the same step can be computed from the last column itself:
+// LF(r) = C[c] + (occurrences of c = L[r] above row r) is the inverse of the step the reference
+// takes (sorted[f].position), so walking it from row e = 0 visits the same cycle backwards and
+// emits the text reversed.  The last column is kept as 64-byte lines of 128 rows: {occurrences of
+// codes 0..3 above the line, three bit planes of the 3-bit codes}; a step reads ONE line of a
+// structure of N / 2 bytes (0.5 GB for a 1 GiB record, half of it inside the 256 MB MALL) and
+// needs no sort of the positions at all.  The Nothing row p is stored as code 0 and taken back out
+// of code 0's counts; LF(p) = 0 closes the cycle.  Code 4's count is what is left of the line start.
+#define LF_ROWS 128                 // rows per line
+#define LF_BLOCK (256 * LF_ROWS)    // rows per block of the build kernels
+#define LF_STRIDE 132               // staged bytes per line in LDS (33 words: conflict-free)
+struct LfTable {
+    u32 C[8];     // first sorted row of code c
+    u8 sym[8];    // byte value of code c
+};
+
+// pass 1: per block, occurrences of codes 0..3; the row of the Nothing -> *prim
+template <class Acc>
+__global__ __launch_bounds__(256) void lf_count_kernel(Acc acc, u32 N, Lut8 lut, u32 *__restrict__ bcnt,
+                                                       u32 *__restrict__ prim) {
+    __shared__ u8 s_lut[260];
+    __shared__ u32 s_c[4];
+    for (int i = threadIdx.x; i < 257; i += 256) s_lut[i] = lut.v[i];
+    if (threadIdx.x < 4) s_c[threadIdx.x] = 0;
+    __syncthreads();
+    const u64 base = (u64)blockIdx.x * LF_BLOCK;
+    u32 c[4] = {0, 0, 0, 0};
+    for (u32 i = threadIdx.x; i < LF_BLOCK; i += 256) {
+        const u64 j = base + i;
+        if (j >= N) break;
+        const int sym = acc(j);
+        if (sym < 0) atomicMin(prim, (u32)j);
+        const u32 code = s_lut[sym + 1];
+        c[0] += code == 0; c[1] += code == 1; c[2] += code == 2; c[3] += code == 3;
+    }
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        u32 v = c[k];
+        for (int d = 32; d >= 1; d >>= 1) v += (u32)__shfl_xor((int)v, d, 64);
+        if ((threadIdx.x & 63) == 0) atomicAdd(&s_c[k], v);
+    }
+    __syncthreads();
+    if (threadIdx.x < 4) bcnt[(u64)blockIdx.x * 4 + threadIdx.x] = s_c[threadIdx.x];
+}
+// exclusive scan of the block counts, four counters side by side (one block)
+__global__ __launch_bounds__(1024) void lf_scan_kernel(u32 *bcnt, u32 nb) {
+    __shared__ u32 s_part[1024][4];
+    const u32 per = (nb + 1023) / 1024;
+    const u32 lo = threadIdx.x * per, hi = lo + per < nb ? lo + per : nb;
+    u32 v[4] = {0, 0, 0, 0};
+    for (u32 t = lo; t < hi; t++)
+        for (int k = 0; k < 4; k++) v[k] += bcnt[(u64)t * 4 + k];
+    for (int k = 0; k < 4; k++) s_part[threadIdx.x][k] = v[k];
+    __syncthreads();
+    if (threadIdx.x < 4) {
+        u32 run = 0;
+        for (int i = 0; i < 1024; i++) {
+            const u32 c = s_part[i][threadIdx.x];
+            s_part[i][threadIdx.x] = run;
+            run += c;
+        }
+    }
+    __syncthreads();
+    u32 run[4];
+    for (int k = 0; k < 4; k++) run[k] = s_part[threadIdx.x][k];
+    for (u32 t = lo; t < hi; t++)
+        for (int k = 0; k < 4; k++) {
+            const u32 c = bcnt[(u64)t * 4 + k];
+            bcnt[(u64)t * 4 + k] = run[k];
+            run[k] += c;
+        }
+}
+// pass 2: the lines
+template <class Acc>
+__global__ __launch_bounds__(256) void lf_build_kernel(Acc acc, u32 N, Lut8 lut, const u32 *__restrict__ bcnt,
+                                                       uint4 *__restrict__ lines) {
+    __shared__ u8 s_lut[260];
+    __shared__ u32 s_code[256 * LF_STRIDE / 4];
+    __shared__ u64 s_wsum[4];
+    for (int i = threadIdx.x; i < 257; i += 256) s_lut[i] = lut.v[i];
+    __syncthreads();
+    const u64 base = (u64)blockIdx.x * LF_BLOCK;
+    u8 *sc = reinterpret_cast<u8 *>(s_code);
+    for (u32 i = threadIdx.x; i < LF_BLOCK; i += 256) {
+        const u64 j = base + i;
+        sc[(i / LF_ROWS) * LF_STRIDE + (i % LF_ROWS)] = j < N ? s_lut[acc(j) + 1] : (u8)0;
+    }
+    __syncthreads();
+    const u32 *mine = s_code + threadIdx.x * (LF_STRIDE / 4);
+    u64 pl[3][2] = {{0, 0}, {0, 0}, {0, 0}};
+#pragma unroll
+    for (int h = 0; h < 2; h++)
+        for (int q = 0; q < 16; q++) {
+            const u32 w = mine[h * 16 + q];
+#pragma unroll
+            for (int b = 0; b < 4; b++) {
+                const u32 code = (w >> (8 * b)) & 7u;
+                const int bit = q * 4 + b;
+                pl[0][h] |= (u64)(code & 1u) << bit;
+                pl[1][h] |= (u64)((code >> 1) & 1u) << bit;
+                pl[2][h] |= (u64)((code >> 2) & 1u) << bit;
+            }
+        }
+    // occurrences of codes 0..3 in this line, 16 bits each (a block holds 32768 rows)
+    u64 cnt = 0;
+#pragma unroll
+    for (int c = 0; c < 4; c++) {
+        u32 k = 0;
+#pragma unroll
+        for (int h = 0; h < 2; h++)
+            k += (u32)__popcll(((c & 1) ? pl[0][h] : ~pl[0][h]) & ((c & 2) ? pl[1][h] : ~pl[1][h]) & ~pl[2][h]);
+        cnt |= (u64)k << (16 * c);
+    }
+    // rows past N were staged as code 0: take them back out (only the last line of the text)
+    {
+        const u64 lstart = base + (u64)threadIdx.x * LF_ROWS;
+        if (lstart + LF_ROWS > N) cnt -= (lstart >= N ? (u64)LF_ROWS : lstart + LF_ROWS - N);
+    }
+    u64 inc = cnt;
+    for (int d = 1; d < 64; d <<= 1) {
+        const u64 t = __shfl_up(inc, d, 64);
+        if ((int)(threadIdx.x & 63) >= d) inc += t;
+    }
+    if ((threadIdx.x & 63) == 63) s_wsum[threadIdx.x >> 6] = inc;
+    __syncthreads();
+    u64 pre = inc - cnt;
+    for (int i = 0; i < (int)(threadIdx.x >> 6); i++) pre += s_wsum[i];
+    const u64 lstart = base + (u64)threadIdx.x * LF_ROWS;
+    if (lstart < N) {
+        const u32 *bc = bcnt + (u64)blockIdx.x * 4;
+        uint4 *o = lines + (lstart / LF_ROWS) * 4;
+        o[0] = make_uint4(bc[0] + (u32)(pre & 0xffff), bc[1] + (u32)((pre >> 16) & 0xffff),
+                          bc[2] + (u32)((pre >> 32) & 0xffff), bc[3] + (u32)(pre >> 48));
+        o[1] = make_uint4((u32)pl[0][0], (u32)(pl[0][0] >> 32), (u32)pl[0][1], (u32)(pl[0][1] >> 32));
+        o[2] = make_uint4((u32)pl[1][0], (u32)(pl[1][0] >> 32), (u32)pl[1][1], (u32)(pl[1][1] >> 32));
+        o[3] = make_uint4((u32)pl[2][0], (u32)(pl[2][0] >> 32), (u32)pl[2][1], (u32)(pl[2][1] >> 32));
+    }
+}
+
+// one LF step; `code` = the code of L[r].  r == p (the Nothing row): LF = 0
+__device__ __forceinline__ u32 lf_step(const uint4 *__restrict__ lines, const u32 *s_C, u32 p, u32 r, u32 &code) {
+    const uint4 *ln = lines + (u64)(r / LF_ROWS) * 4;
+    const uint4 a = ln[0], b0 = ln[1], b1 = ln[2], b2 = ln[3];
+    const u32 o = r % LF_ROWS, hi = o >> 6, sh = o & 63u;
+    const u64 p0[2] = {(u64)b0.x | ((u64)b0.y << 32), (u64)b0.z | ((u64)b0.w << 32)};
+    const u64 p1[2] = {(u64)b1.x | ((u64)b1.y << 32), (u64)b1.z | ((u64)b1.w << 32)};
+    const u64 p2[2] = {(u64)b2.x | ((u64)b2.y << 32), (u64)b2.z | ((u64)b2.w << 32)};
+    const u32 c0 = (u32)((hi ? p0[1] : p0[0]) >> sh) & 1u, c1 = (u32)((hi ? p1[1] : p1[0]) >> sh) & 1u,
+              c2 = (u32)((hi ? p2[1] : p2[0]) >> sh) & 1u;
+    code = c0 | (c1 << 1) | (c2 << 2);
+    const u64 m0 = (c0 ? p0[0] : ~p0[0]) & (c1 ? p1[0] : ~p1[0]) & (c2 ? p2[0] : ~p2[0]);
+    const u64 m1 = (c0 ? p0[1] : ~p0[1]) & (c1 ? p1[1] : ~p1[1]) & (c2 ? p2[1] : ~p2[1]);
+    const u64 below = (1ull << sh) - 1ull;
+    const u32 in_line = hi ? (u32)__popcll(m0) + (u32)__popcll(m1 & below) : (u32)__popcll(m0 & below);
+    const u32 lstart = r - o;
+    const u32 above = code == 0 ? a.x : code == 1 ? a.y : code == 2 ? a.z : code == 3 ? a.w
+                                                                              : lstart - (a.x + a.y + a.z + a.w);
+    if (r == p) return 0u;
+    return s_C[code] + above + in_line - ((code == 0 && r > p) ? 1u : 0u);
+}
+
+// the walks of ibwt_walk1_kernel with the LF step (same records, same chain bookkeeping)
+__global__ __launch_bounds__(256) void ibwt_lfwalk1_kernel(const uint4 *__restrict__ lines, u32 N, u32 K,
+                                                           const u32 *__restrict__ prim, LfTable tb,
+                                                           u32 *__restrict__ nxt, u32 *__restrict__ dist,
+                                                           u8 *__restrict__ seg, u32 *__restrict__ seglen,
+                                                           u8 *__restrict__ segflag, u32 force_rewalk,
+                                                           u32 *__restrict__ noverflow, u32 *__restrict__ ovlist) {
+    __shared__ u32 s_C[8];
+    __shared__ u8 s_sym[8];
+    if (threadIdx.x < 8) {
+        s_C[threadIdx.x] = tb.C[threadIdx.x];
+        s_sym[threadIdx.x] = tb.sym[threadIdx.x];
+    }
+    __syncthreads();
+    const u32 p = *prim;
+    u32 q = blockIdx.x * 256 + threadIdx.x;
+    if (q >= K) return;
+    u32 r = ibwt_split_row(q), steps = 0;
+    if (r >= N) {
+        nxt[q] = q;
+        dist[q] = 0;
+        seglen[q] = 0;
+        segflag[q] = 0;
+        return;
+    }
+    u8 *out = seg + (u64)q * IBWT_SEGCAP;
+    u32 word = 0;
+    uint4 w4 = make_uint4(0, 0, 0, 0);
+    u32 emitted = 0, flag = force_rewalk ? 1u : 0u;
+    for (;;) {
+        steps++;
+        u32 code;
+        const u32 rn = lf_step(lines, s_C, p, r, code);
+        if (rn != 0) {   // (rn == 0: r was the Nothing row -- nothing to emit)
+            if (emitted < IBWT_SEGCAP) {
+                word |= (u32)s_sym[code] << (8 * (emitted & 3u));
+                if ((emitted & 3u) == 3u) {
+                    const u32 k4 = (emitted >> 2) & 3u;
+                    if (k4 == 0) w4.x = word;
+                    else if (k4 == 1) w4.y = word;
+                    else if (k4 == 2) w4.z = word;
+                    else {
+                        w4.w = word;
+                        reinterpret_cast<uint4 *>(out)[emitted >> 4] = w4;
+                    }
+                    word = 0;
+                }
+            } else {
+                flag |= 1u;
+            }
+            emitted++;
+        }
+        r = rn;
+        if (ibwt_is_splitter(r) || steps > N) break;
+    }
+    if (emitted < IBWT_SEGCAP && (emitted & 15u)) {
+        const u32 k4 = (emitted >> 2) & 3u;
+        if (k4 == 0) w4.x = word;
+        else if (k4 == 1) w4.y = word;
+        else if (k4 == 2) w4.z = word;
+        else w4.w = word;
+        reinterpret_cast<uint4 *>(out)[emitted >> 4] = w4;
+    }
+    nxt[q] = r / IBWT_S;
+    dist[q] = steps;
+    seglen[q] = emitted;
+    segflag[q] = (u8)flag;
+    if (flag & 1u) ovlist[atomicAdd(noverflow, 1u)] = q;
+}
+// segments that did not fit their record buffer: walked again, bytes at their final (reversed) offsets
+__global__ __launch_bounds__(256) void ibwt_lfwalk2_kernel(const uint4 *__restrict__ lines, u32 N, u32 K,
+                                                           const u32 *__restrict__ prim, LfTable tb,
+                                                           const u32 *__restrict__ nxt, const u32 *__restrict__ dist,
+                                                           const u64 *__restrict__ scalars, u8 *__restrict__ text,
+                                                           const u32 *__restrict__ ovlist, u32 nov) {
+    __shared__ u32 s_C[8];
+    __shared__ u8 s_sym[8];
+    if (threadIdx.x < 8) {
+        s_C[threadIdx.x] = tb.C[threadIdx.x];
+        s_sym[threadIdx.x] = tb.sym[threadIdx.x];
+    }
+    __syncthreads();
+    const u32 i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= nov) return;
+    const u32 q = ovlist[i];
+    if (q >= K || (q != 0 && nxt[q] != 0)) return;
+    const u32 p = *prim, Lc = (u32)scalars[6];
+    u32 k = (q == 0) ? 0u : Lc - dist[q];   // offset in the reversed text
+    u32 r = ibwt_split_row(q), steps = 0;
+    while (steps++ <= N) {
+        u32 code;
+        r = lf_step(lines, s_C, p, r, code);
+        if (r == 0) break;
+        if (k + 2 <= Lc) text[Lc - 2 - k] = s_sym[code];
+        k++;
+        if (ibwt_is_splitter(r)) break;
+    }
+}
+// ibwt_copy_kernel for the reversed walk
+__global__ __launch_bounds__(256) void ibwt_copy_rev_kernel(u32 K, const u32 *__restrict__ nxt,
+                                                            const u32 *__restrict__ dist,
+                                                            const u64 *__restrict__ scalars,
+                                                            const u8 *__restrict__ seg,
+                                                            const u32 *__restrict__ seglen,
+                                                            const u8 *__restrict__ segflag,
+                                                            u8 *__restrict__ text) {
+    const u32 q = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (q >= K) return;
+    if (q != 0 && nxt[q] != 0) return;
+    if (segflag[q] & 1u) return;
+    const u32 Lc = (u32)scalars[6];
+    const u32 k0 = (q == 0) ? 0u : Lc - dist[q];
+    const u32 len = seglen[q];
+    const u8 *src = seg + (u64)q * IBWT_SEGCAP;
+    for (u32 i = lane_id(); i < len; i += 64)
+        if (k0 + i + 2 <= Lc) text[Lc - 2 - (k0 + i)] = src[i];
+}
+
 #endif  // __HIPCC__
 
 // Inverse BWT of an accessor stream; d_text receives *n_out bytes (<= N).
@@ -343,6 +624,8 @@ static void ibwt_device(tc_ctx *ctx, Arena &A, Acc acc, u64 N, const u32 *counts
     u32 *seglen = A.get<u32>(K + 1);
     u8 *segflag = A.get<u8>(K + 1);
     u32 *ovlist = A.get<u32>(K + 1);
+    uint4 *lf_lines = A.get<uint4>(((size_t)(N / LF_ROWS) + 1) * 4);   // LF walk: N / 2 bytes
+    u32 *lf_bcnt = A.get<u32>(((size_t)tc_cdiv(N, LF_BLOCK) + 1) * 4);
     if (dry) return;
     hipStream_t s = ctx->stream;
     u32 local[257];
@@ -365,6 +648,63 @@ static void ibwt_device(tc_ctx *ctx, Arena &A, Acc acc, u64 N, const u32 *counts
     }
     ct.c[al.sigma] = (u32)N;
     ct.sigma = al.sigma;
+    if (counts257[0] == 1 && al.sigma <= 6 && N > 1 && env_int("TC_IBWT_LF", 1) != 0) {
+        // small alphabet, one Nothing: walk by LF over the packed last column (see above)
+        Lut8 l8;
+        LfTable tb = {};
+        for (int v = 0; v < 257; v++) l8.v[v] = 0;
+        u32 crow = 1;   // row 0 is the Nothing's
+        for (u32 c = 1; c < al.sigma; c++) {
+            const int sym = al.sym_of_code[c];
+            l8.v[sym + 1] = (u8)(c - 1);
+            tb.C[c - 1] = crow;
+            tb.sym[c - 1] = (u8)sym;
+            crow += counts257[sym + 1];
+        }
+        uint4 *lines = lf_lines;
+        u32 *bcnt = lf_bcnt;
+        u32 *prim = reinterpret_cast<u32 *>(ctx->d_scalars + 18);
+        u8 *seg = reinterpret_cast<u8 *>(k0);
+        const u32 nb = tc_cdiv(N, LF_BLOCK);
+        tc_memset_async(ctx, prim, 0xff, sizeof(u64));
+        tc_memset_async(ctx, ctx->d_scalars + 17, 0, sizeof(u64));
+        lf_count_kernel<Acc><<<nb, 256, 0, s>>>(acc, (u32)N, l8, bcnt, prim);
+        TC_LAUNCH_CHECK(ctx);
+        lf_scan_kernel<<<1, 1024, 0, s>>>(bcnt, nb);
+        TC_LAUNCH_CHECK(ctx);
+        lf_build_kernel<Acc><<<nb, 256, 0, s>>>(acc, (u32)N, l8, bcnt, lines);
+        TC_LAUNCH_CHECK(ctx);
+        ibwt_lfwalk1_kernel<<<tc_cdiv(K, 256), 256, 0, s>>>(lines, (u32)N, K, prim, tb, nx[0], ds[0], seg, seglen,
+                                                           segflag, (u32)env_int("TC_IBWT_REWALK", 0),
+                                                           reinterpret_cast<u32 *>(ctx->d_scalars + 17), ovlist);
+        TC_LAUNCH_CHECK(ctx);
+        ibwt_terminal_kernel<<<1, 1, 0, s>>>(nx[0], ds[0], ctx->d_scalars);
+        TC_LAUNCH_CHECK(ctx);
+        int cur = 0;
+        for (int r = 0; r < ceil_log2_u64(K) + 1; r++) {
+            ibwt_jump_kernel<<<tc_cdiv(K, 256), 256, 0, s>>>(nx[cur], ds[cur], nx[cur ^ 1], ds[cur ^ 1], K);
+            TC_LAUNCH_CHECK(ctx);
+            cur ^= 1;
+        }
+        ibwt_len_kernel<<<1, 1, 0, s>>>(nx[cur], ds[cur], ctx->d_scalars, ctx->d_err);
+        TC_LAUNCH_CHECK(ctx);
+        ibwt_copy_rev_kernel<<<tc_cdiv(K, 4), 256, 0, s>>>(K, nx[cur], ds[cur], ctx->d_scalars, seg, seglen, segflag,
+                                                          d_text);
+        TC_LAUNCH_CHECK(ctx);
+        tc_d2h(ctx, &ctx->h_scalars[6], ctx->d_scalars + 6, sizeof(u64));
+        tc_d2h(ctx, &ctx->h_scalars[17], ctx->d_scalars + 17, sizeof(u64));
+        TC_HIP(ctx, hipStreamSynchronize(s));
+        if ((u32)ctx->h_scalars[17]) {
+            const u32 nov = (u32)ctx->h_scalars[17];
+            ibwt_lfwalk2_kernel<<<tc_cdiv(nov, 256), 256, 0, s>>>(lines, (u32)N, K, prim, tb, nx[cur], ds[cur],
+                                                                 ctx->d_scalars, d_text, ovlist, nov);
+            TC_LAUNCH_CHECK(ctx);
+            TC_HIP(ctx, hipStreamSynchronize(s));
+        }
+        const u64 Lc = ctx->h_scalars[6];
+        *n_out = Lc ? Lc - 1 : 0;
+        return;
+    }
     // 1. sorted (symbol, position): spos
     const u32 *spos = nullptr;
     if (al.sigma <= 256 && env_int("TC_IBWT_SCATTER", 1) != 0) {
