@@ -16,6 +16,7 @@
 //      final offsets.  Works for ANY Seq (Maybe Word8): no Nothing => empty output;
 //      a second Nothing met on the chain => TC_ERR_MALFORMED (fromJust, :195).
 #pragma once
+#include <algorithm>
 #include "tc_encode_host.hpp"
 
 #define IBWT_S 256  // splitter spacing (rows)
@@ -342,6 +343,8 @@ struct LfTable {
 };
 
 // pass 1: per block, occurrences of codes 0..3; the row of the Nothing -> *prim
+// prim[0] = row of the (first) Nothing, prim[1] = number of Nothings, prim[2] != 0: a symbol outside the
+// expected alphabet (lut value 0xff) was met
 template <class Acc>
 __global__ __launch_bounds__(256) void lf_count_kernel(Acc acc, u32 N, Lut8 lut, u32 *__restrict__ bcnt,
                                                        u32 *__restrict__ prim) {
@@ -356,8 +359,12 @@ __global__ __launch_bounds__(256) void lf_count_kernel(Acc acc, u32 N, Lut8 lut,
         const u64 j = base + i;
         if (j >= N) break;
         const int sym = acc(j);
-        if (sym < 0) atomicMin(prim, (u32)j);
+        if (sym < 0) {
+            atomicMin(prim, (u32)j);
+            atomicAdd(prim + 1, 1u);
+        }
         const u32 code = s_lut[sym + 1];
+        if (code == 0xffu && !prim[2]) atomicOr(prim + 2, 1u);
         c[0] += code == 0; c[1] += code == 1; c[2] += code == 2; c[3] += code == 3;
     }
 #pragma unroll
@@ -370,7 +377,7 @@ __global__ __launch_bounds__(256) void lf_count_kernel(Acc acc, u32 N, Lut8 lut,
     if (threadIdx.x < 4) bcnt[(u64)blockIdx.x * 4 + threadIdx.x] = s_c[threadIdx.x];
 }
 // exclusive scan of the block counts, four counters side by side (one block)
-__global__ __launch_bounds__(1024) void lf_scan_kernel(u32 *bcnt, u32 nb) {
+__global__ __launch_bounds__(1024) void lf_scan_kernel(u32 *bcnt, u32 nb, u32 *__restrict__ totals) {
     __shared__ u32 s_part[1024][4];
     const u32 per = (nb + 1023) / 1024;
     const u32 lo = threadIdx.x * per, hi = lo + per < nb ? lo + per : nb;
@@ -386,6 +393,7 @@ __global__ __launch_bounds__(1024) void lf_scan_kernel(u32 *bcnt, u32 nb) {
             s_part[i][threadIdx.x] = run;
             run += c;
         }
+        totals[threadIdx.x] = run;   // occurrences of codes 0..3 in the whole column
     }
     __syncthreads();
     u32 run[4];
@@ -608,8 +616,10 @@ __global__ __launch_bounds__(256) void ibwt_copy_rev_kernel(u32 K, const u32 *__
 
 // Inverse BWT of an accessor stream; d_text receives *n_out bytes (<= N).
 template <class Acc>
+// alphabet (optional, fused decode): the sorted symbols the stream can hold (the block's MTF list);
+// lets the small-alphabet path count on the device instead of taking a histogram first
 static void ibwt_device(tc_ctx *ctx, Arena &A, Acc acc, u64 N, const u32 *counts257, u8 *d_text,
-                        u64 *n_out, bool dry) {
+                        u64 *n_out, bool dry, const i16 *alphabet = nullptr, u32 nalphabet = 0) {
     const u32 K = tc_cdiv(N, IBWT_S);
     u32 *d_counts = A.get<u32>(260);
     // (k0 doubles as the segment record buffer after the sort: K * IBWT_SEGCAP bytes)
@@ -628,50 +638,50 @@ static void ibwt_device(tc_ctx *ctx, Arena &A, Acc acc, u64 N, const u32 *counts
     u32 *lf_bcnt = A.get<u32>(((size_t)tc_cdiv(N, LF_BLOCK) + 1) * 4);
     if (dry) return;
     hipStream_t s = ctx->stream;
-    u32 local[257];
-    if (!counts257) {
-        sym_hist_host<Acc>(ctx, acc, N, d_counts, local);
-        counts257 = local;
-    }
     *n_out = 0;
-    if (counts257[0] == 0) return;  // no Nothing: magicInverseBWT returns empty (:173-174)
-    Alphabet al;
-    al.build(counts257);
-    Lut16 lut;
-    CTable ct;
-    u32 acc_c = 0;
-    for (int v = 0; v < 257; v++) lut.v[v] = al.code_of_sym[v];
-    for (u32 c = 0; c < al.sigma; c++) {
-        ct.c[c] = acc_c;
-        ct.sym[c] = al.sym_of_code[c];
-        acc_c += counts257[al.sym_of_code[c] + 1];
-    }
-    ct.c[al.sigma] = (u32)N;
-    ct.sigma = al.sigma;
-    if (counts257[0] == 1 && al.sigma <= 6 && N > 1 && env_int("TC_IBWT_LF", 1) != 0) {
-        // small alphabet, one Nothing: walk by LF over the packed last column (see above)
+    // small alphabet, one Nothing: walk by LF over the packed last column (see above).  syms = the
+    // byte values in order (codes 0..nsym-1); cnt = their occurrences, or null: counted on the
+    // device (then the walk is only taken if the column holds exactly one Nothing and nothing else
+    // than these symbols -- returns false otherwise, nothing written)
+    auto lf_path = [&](const u8 *syms, u32 nsym, const u32 *cnt) -> bool {
         Lut8 l8;
         LfTable tb = {};
-        for (int v = 0; v < 257; v++) l8.v[v] = 0;
-        u32 crow = 1;   // row 0 is the Nothing's
-        for (u32 c = 1; c < al.sigma; c++) {
-            const int sym = al.sym_of_code[c];
-            l8.v[sym + 1] = (u8)(c - 1);
-            tb.C[c - 1] = crow;
-            tb.sym[c - 1] = (u8)sym;
-            crow += counts257[sym + 1];
+        for (int v = 0; v < 257; v++) l8.v[v] = 0xff;
+        l8.v[0] = 0;
+        for (u32 c = 0; c < nsym; c++) {
+            l8.v[(u32)syms[c] + 1] = (u8)c;
+            tb.sym[c] = syms[c];
         }
         uint4 *lines = lf_lines;
         u32 *bcnt = lf_bcnt;
-        u32 *prim = reinterpret_cast<u32 *>(ctx->d_scalars + 18);
+        u32 *prim = reinterpret_cast<u32 *>(ctx->d_scalars + 24);   // 4 words + 4 totals
         u8 *seg = reinterpret_cast<u8 *>(k0);
         const u32 nb = tc_cdiv(N, LF_BLOCK);
-        tc_memset_async(ctx, prim, 0xff, sizeof(u64));
+        tc_memset_async(ctx, prim, 0, 4 * sizeof(u64));
+        tc_memset_async(ctx, prim, 0xff, sizeof(u32));
         tc_memset_async(ctx, ctx->d_scalars + 17, 0, sizeof(u64));
         lf_count_kernel<Acc><<<nb, 256, 0, s>>>(acc, (u32)N, l8, bcnt, prim);
         TC_LAUNCH_CHECK(ctx);
-        lf_scan_kernel<<<1, 1024, 0, s>>>(bcnt, nb);
+        lf_scan_kernel<<<1, 1024, 0, s>>>(bcnt, nb, prim + 4);
         TC_LAUNCH_CHECK(ctx);
+        u32 tot[5] = {0, 0, 0, 0, 0};
+        if (cnt) {
+            for (u32 c = 0; c < nsym; c++) tot[c] = cnt[c];
+        } else {
+            tc_d2h(ctx, &ctx->h_scalars[24], ctx->d_scalars + 24, 4 * sizeof(u64));
+            TC_HIP(ctx, hipStreamSynchronize(s));
+            const u32 *hp = reinterpret_cast<const u32 *>(&ctx->h_scalars[24]);
+            if (hp[1] != 1 || hp[2] != 0) return false;
+            u64 sum4 = 0;
+            for (int c = 0; c < 4; c++) { tot[c] = hp[4 + c]; sum4 += hp[4 + c]; }
+            tot[0] -= 1;                       // the Nothing was counted as code 0
+            tot[4] = (u32)(N - sum4);
+        }
+        u32 crow = 1;   // row 0 is the Nothing's
+        for (u32 c = 0; c < 5; c++) {
+            tb.C[c] = crow;
+            crow += tot[c];
+        }
         lf_build_kernel<Acc><<<nb, 256, 0, s>>>(acc, (u32)N, l8, bcnt, lines);
         TC_LAUNCH_CHECK(ctx);
         ibwt_lfwalk1_kernel<<<tc_cdiv(K, 256), 256, 0, s>>>(lines, (u32)N, K, prim, tb, nx[0], ds[0], seg, seglen,
@@ -703,8 +713,47 @@ static void ibwt_device(tc_ctx *ctx, Arena &A, Acc acc, u64 N, const u32 *counts
         }
         const u64 Lc = ctx->h_scalars[6];
         *n_out = Lc ? Lc - 1 : 0;
-        return;
+        return true;
+    };
+    const bool lf_on = N > 1 && env_int("TC_IBWT_LF", 1) != 0;
+    if (lf_on && !counts257 && alphabet && nalphabet >= 2 && nalphabet <= 6 && alphabet[0] == -1) {
+        // the caller knows the alphabet: no histogram pass
+        u8 syms[5];
+        bool ok = true;
+        for (u32 i = 1; i < nalphabet; i++) {
+            ok = ok && alphabet[i] > alphabet[i - 1] && alphabet[i] <= 255;
+            syms[i - 1] = (u8)alphabet[i];
+        }
+        if (ok && lf_path(syms, nalphabet - 1, nullptr)) return;
     }
+    u32 local[257];
+    if (!counts257) {
+        sym_hist_host<Acc>(ctx, acc, N, d_counts, local);
+        counts257 = local;
+    }
+    if (counts257[0] == 0) return;  // no Nothing: magicInverseBWT returns empty (:173-174)
+    Alphabet al;
+    al.build(counts257);
+    if (lf_on && counts257[0] == 1 && al.sigma <= 6) {
+        u8 syms[5];
+        u32 cnt[5];
+        for (u32 c = 1; c < al.sigma; c++) {
+            syms[c - 1] = (u8)al.sym_of_code[c];
+            cnt[c - 1] = counts257[al.sym_of_code[c] + 1];
+        }
+        if (lf_path(syms, al.sigma - 1, cnt)) return;
+    }
+    Lut16 lut;
+    CTable ct;
+    u32 acc_c = 0;
+    for (int v = 0; v < 257; v++) lut.v[v] = al.code_of_sym[v];
+    for (u32 c = 0; c < al.sigma; c++) {
+        ct.c[c] = acc_c;
+        ct.sym[c] = al.sym_of_code[c];
+        acc_c += counts257[al.sym_of_code[c] + 1];
+    }
+    ct.c[al.sigma] = (u32)N;
+    ct.sigma = al.sigma;
     // 1. sorted (symbol, position): spos
     const u32 *spos = nullptr;
     if (al.sigma <= 256 && env_int("TC_IBWT_SCATTER", 1) != 0) {
@@ -893,6 +942,12 @@ static void decode_device(tc_ctx *ctx, const tc_block *blk, u8 *d_text) {
     u16 *d_idx = nullptr;
     i16 *d_sym = nullptr;
     u64 got = 0, n_out = 0;
+    i16 sorted_list[TC_MAX_SIGMA];
+    {
+        const u32 sg = blk->sigma <= TC_MAX_SIGMA ? blk->sigma : 0;
+        for (u32 i = 0; i < sg; i++) sorted_list[i] = blk->final_list[i];
+        std::sort(sorted_list, sorted_list + sg);
+    }
     auto plan = [&](Arena &A, bool dry) {
         d_idx = A.get<u16>(N + 64);
         d_sym = A.get<i16>(N + 64);
@@ -908,7 +963,8 @@ static void decode_device(tc_ctx *ctx, const tc_block *blk, u8 *d_text) {
         hi = A.off > hi ? A.off : hi;
         A.off = mark;
         SymAcc acc{d_sym};
-        ibwt_device<SymAcc>(ctx, A, acc, N, nullptr, d_text, &n_out, dry);
+        // the symbols the stream can hold: the block's MTF list, sorted
+        ibwt_device<SymAcc>(ctx, A, acc, N, nullptr, d_text, &n_out, dry, sorted_list, blk->sigma);
         hi = A.off > hi ? A.off : hi;
         A.off = hi;
     };
