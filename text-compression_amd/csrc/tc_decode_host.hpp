@@ -19,16 +19,21 @@
 #include <algorithm>
 #include "tc_encode_host.hpp"
 
-#define IBWT_S 256  // splitter spacing (rows)
+#ifndef IBWT_S
+#define IBWT_S 256  // splitter spacing (rows), a power of two
+#endif
+#define IBWT_SBITS (IBWT_S == 256 ? 8 : IBWT_S == 512 ? 9 : IBWT_S == 1024 ? 10 : 7)
 
 #ifdef __HIPCC__
 
 // the splitter of block q = r / 256 sits at offset -(byte sum of q) mod 256; block 0: row 0
 __device__ __forceinline__ u32 ibwt_split_off(u32 q) {
-    return (0u - (q + (q >> 8) + (q >> 16))) & 255u;
+    return (0u - (q + (q >> 8) + (q >> 16))) & (u32)(IBWT_S - 1);
 }
 __device__ __forceinline__ u32 ibwt_split_row(u32 q) { return q * IBWT_S + ibwt_split_off(q); }
-__device__ __forceinline__ bool ibwt_is_splitter(u32 r) { return (r & 255u) == ibwt_split_off(r >> 8); }
+__device__ __forceinline__ bool ibwt_is_splitter(u32 r) {
+    return (r & (u32)(IBWT_S - 1)) == ibwt_split_off(r >> IBWT_SBITS);
+}
 
 template <class Acc>
 __global__ __launch_bounds__(256) void ibwt_keys_kernel(Acc acc, u32 N, Lut16 lut,
@@ -166,7 +171,7 @@ __global__ __launch_bounds__(ISC_NT) void ibwt_scatter_kernel(Acc acc, u32 N, Lu
 // number to seglen[q].  Flags: bit 0 = the segment is longer than IBWT_SEGCAP (listed, re-walked by
 // ibwt_walk2_kernel), bit 1 = a Nothing row other than row 0 was met (an error only if the segment
 // turns out to lie on the chain of row e).
-#define IBWT_SEGCAP 4096   // segment lengths are geometric with mean 256: one in 10^7 is longer
+#define IBWT_SEGCAP (16 * IBWT_S)   // segment lengths are geometric with mean IBWT_S: one in 10^7 is longer
 __global__ __launch_bounds__(256) void ibwt_walk1_kernel(const u32 *__restrict__ spos, u32 N, u32 K,
                                                          u32 *__restrict__ nxt,
                                                          u32 *__restrict__ dist, CTable ct,
