@@ -111,12 +111,13 @@ def test_rle_decode_long_runs(ctx):
 @pytest.mark.parametrize("env", [{"TC_IBWT_SCATTER": "0"}, {"TC_IBWT_REWALK": "1"},
                                  {"TC_IBWT_SCATTER": "0", "TC_IBWT_REWALK": "1"}, {"TC_IBWT_LF": "0"},
                                  {"TC_IBWT_LF": "0", "TC_IBWT_REWALK": "1"},
-                                 {"TC_IBWT_LF": "0", "TC_IBWT_SCATTER": "0"}],
+                                 {"TC_IBWT_LF": "0", "TC_IBWT_SCATTER": "0"}, {"TC_MTF_FORCE_GENERAL": "1"}],
                          ids=lambda e: ",".join("%s=%s" % kv for kv in e.items()))
 def test_ibwt_path_selectors(ctx, env, monkeypatch):
     """The alternatives inside the inverse BWT (generic radix sort of the positions instead of the
     dedicated scatter; every recorded segment treated as overflowed and walked again; small alphabets
-    by positions instead of by LF over the packed last column) decode to the same text."""
+    by positions instead of by LF over the packed last column; the inverse MTF of a small alphabet on the
+    byte-list kernels instead of the nibble ones) decode to the same text."""
     rng = np.random.default_rng(5)
     texts = [O.gen_acgtn(31, 1 << 20).tobytes(), O.gen_ascii(32, 200000).tobytes(),
              bytes(rng.integers(0, 256, 100000, dtype=np.uint8)),

@@ -898,6 +898,19 @@ static void mtf_decode_device(tc_ctx *ctx, Arena &A, const u16 *d_idx, u64 N, co
         }
         // not the index stream of a BWT with its sentinel at `primary`: the nine-bit path below
     }
+    if (sigma <= 16 && env_int("TC_MTF_FORCE_GENERAL", 0) == 0 && env_int("TC_MTF_WAVE_CHUNKS", 0) == 0) {
+        // list = 16 nibbles in a register (tc_mtf.hpp, "inverse MTF, sigma <= 16")
+        hipStream_t s = ctx->stream;
+        const u32 tiles = tc_cdiv(N, MTF_TILE);
+        u64 *t_perm = reinterpret_cast<u64 *>(perms);   // tiles + 1 words of the (chunks + 1) * 640 bytes
+        imtf_nib_summary_kernel<u16><<<tiles, MTF_NT, 0, s>>>(d_idx, N, sigma, t_perm, ctx->d_err);
+        TC_LAUNCH_CHECK(ctx);
+        imtf_nib_scan_kernel<<<1, MTF_NT, 0, s>>>(t_perm, tiles);
+        TC_LAUNCH_CHECK(ctx);
+        imtf_nib_apply_kernel<u16, i16><<<tiles, MTF_NT, 0, s>>>(d_idx, N, sigma, t_perm, tab, d_out, ctx->d_err);
+        TC_LAUNCH_CHECK(ctx);
+        return;
+    }
     if (sigma <= 256 && env_int("TC_MTF_WAVE_CHUNKS", 0) == 0) {
         const u32 rows = (sigma + 63) / 64;
         if (rows <= 1) imtf_lane_launch<1>(ctx, d_idx, N, sigma, perms, tab, d_out);

@@ -1197,6 +1197,202 @@ __global__ __launch_bounds__(GM_NT) void imtf_gm_kernel(GmiArgs a) {
     }
 }
 
+// ---- inverse MTF, sigma <= 16: the nibble path mirrored ---------------------------------------
+// A chunk's effect on the list is a permutation of list POSITIONS (run it on the identity): P with
+// out[i] = in[P[i]], 16 nibbles in one register; "a then b" = a gathered by b.  A lane runs its
+// 64-index chunk once, leaving in LDS, for every index, the position of the INCOMING list it
+// reads (q) -- so after the scan over lanes and tiles the symbols are sixteen-way table lookups
+// into the lane's incoming list, not a second sequential pass.
+__device__ __forceinline__ u64 nibi_gather(u64 a, u64 b) {   // a then b
+    u64 r = 0;
+#pragma unroll
+    for (int i = 0; i < 16; i++) r |= ((a >> (4 * ((b >> (4 * i)) & 15ull))) & 15ull) << (4 * i);
+    return r;
+}
+// stage MTF_TILE indices (u16 or u8) as bytes, chunk-major with MTF_STRIDE; an index >= sigma is
+// DS.index out of range: flagged, read as 0
+template <class IT>
+__device__ __forceinline__ void nibi_stage(const IT *__restrict__ idx, u64 N, u64 base, u32 sigma, u8 *s_code,
+                                           u32 *err) {
+    bool bad = false;
+    const IT *src = idx + base;
+    if ((((uintptr_t)src) & 15) == 0) {
+        constexpr int PER = 16 / sizeof(IT);   // indices per 16-byte load
+        for (u32 g = threadIdx.x; g < MTF_TILE / PER; g += MTF_NT) {
+            const u32 p = PER * g;
+            u32 v[PER];
+            if (base + p + PER <= N) {
+                const uint4 t = *reinterpret_cast<const uint4 *>(src + p);
+                const u32 x[4] = {t.x, t.y, t.z, t.w};
+#pragma unroll
+                for (int q = 0; q < PER; q++)
+                    v[q] = sizeof(IT) == 2 ? (x[q >> 1] >> (16 * (q & 1))) & 0xffffu : (x[q >> 2] >> (8 * (q & 3))) & 0xffu;
+            } else {
+#pragma unroll
+                for (int q = 0; q < PER; q++) v[q] = base + p + q < N ? (u32)src[p + q] : 0u;
+            }
+#pragma unroll
+            for (int q = 0; q < PER; q++)
+                if (v[q] >= sigma) { bad = true; v[q] = 0; }
+            u32 *dst = reinterpret_cast<u32 *>(s_code + (p / MTF_CH) * MTF_STRIDE + (p % MTF_CH));
+#pragma unroll
+            for (int q = 0; q < PER / 4; q++)
+                dst[q] = v[4 * q] | (v[4 * q + 1] << 8) | (v[4 * q + 2] << 16) | (v[4 * q + 3] << 24);
+        }
+    } else {
+        for (u32 p = threadIdx.x; p < MTF_TILE; p += MTF_NT) {
+            u32 v = base + p < N ? (u32)src[p] : 0u;
+            if (v >= sigma) { bad = true; v = 0; }
+            s_code[(p / MTF_CH) * MTF_STRIDE + (p % MTF_CH)] = (u8)v;
+        }
+    }
+    if (bad) atomicOr(err, 0x100u);
+}
+// this lane's chunk on the identity: returns its permutation; RECORD: every index byte is replaced
+// by the incoming-list position it reads
+template <bool RECORD>
+__device__ __forceinline__ u64 nibi_chunk(u8 *s_code, u32 nvalid) {
+    u32 *cw = reinterpret_cast<u32 *>(s_code + threadIdx.x * MTF_STRIDE);
+    u64 q = NIB_IDENT;
+#pragma unroll 4
+    for (u32 w = 0; w < MTF_CH / 4; w++) {
+        const u32 wv = cw[w];
+        u32 ov = 0;
+#pragma unroll
+        for (int b = 0; b < 4; b++) {
+            if (4 * w + b < nvalid) {
+                const u32 r = (wv >> (8 * b)) & 15u;
+                const u32 c = (u32)(q >> (4 * r)) & 15u;
+                q = nib_front(q, r, c);
+                ov |= c << (8 * b);
+            }
+        }
+        if (RECORD) cw[w] = ov;
+    }
+    return q;
+}
+// exclusive block scan of permutations (lane order); *agg = the block's permutation
+__device__ __forceinline__ u64 nibi_block_excl(u64 mine, u64 *s_w, u64 *agg) {
+    const int w = threadIdx.x >> 6, l = threadIdx.x & 63;
+    u64 inc = mine;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const u64 t = __shfl_up(inc, d, 64);
+        if (l >= d) inc = nibi_gather(t, inc);
+    }
+    u64 exc = __shfl_up(inc, 1, 64);
+    if (l == 0) exc = NIB_IDENT;
+    if (l == 63) s_w[w] = inc;
+    __syncthreads();
+    u64 pre = NIB_IDENT, tot = NIB_IDENT;
+    for (int i = 0; i < MTF_NT / 64; i++) {
+        if (i < w) pre = nibi_gather(pre, s_w[i]);
+        tot = nibi_gather(tot, s_w[i]);
+    }
+    *agg = tot;
+    return nibi_gather(pre, exc);
+}
+template <class IT>
+__global__ __launch_bounds__(MTF_NT) void imtf_nib_summary_kernel(const IT *__restrict__ idx, u64 N, u32 sigma,
+                                                                   u64 *__restrict__ t_perm, u32 *err) {
+    __shared__ __attribute__((aligned(16))) u8 s_code[MTF_NT * MTF_STRIDE];
+    __shared__ u64 s_w[MTF_NT / 64];
+    const u64 base = (u64)blockIdx.x * MTF_TILE;
+    nibi_stage<IT>(idx, N, base, sigma, s_code, err);
+    __syncthreads();
+    const u64 cbase = base + (u64)threadIdx.x * MTF_CH;
+    const u32 nvalid = cbase >= N ? 0u : (N - cbase >= MTF_CH ? (u32)MTF_CH : (u32)(N - cbase));
+    const u64 mine = nibi_chunk<false>(s_code, nvalid);
+    u64 agg;
+    (void)nibi_block_excl(mine, s_w, &agg);
+    if (threadIdx.x == 0) t_perm[blockIdx.x] = agg;
+}
+// exclusive scan over the tile permutations, in place (one block)
+__global__ __launch_bounds__(MTF_NT) void imtf_nib_scan_kernel(u64 *t_perm, u32 tiles) {
+    __shared__ u64 s_w[MTF_NT / 64];
+    const u32 per = (tiles + MTF_NT - 1) / MTF_NT;
+    const u32 lo = threadIdx.x * per, hi = lo + per < tiles ? lo + per : tiles;
+    u64 mine = NIB_IDENT;
+    for (u32 t = lo; t < hi; t++) mine = nibi_gather(mine, t_perm[t]);
+    u64 agg;
+    u64 run = nibi_block_excl(mine, s_w, &agg);
+    for (u32 t = lo; t < hi; t++) {
+        const u64 cur = t_perm[t];
+        t_perm[t] = run;
+        run = nibi_gather(run, cur);
+    }
+}
+// OT = i16: symbols through `tab`; OT = u8: the codes themselves
+template <class IT, class OT>
+__global__ __launch_bounds__(MTF_NT) void imtf_nib_apply_kernel(const IT *__restrict__ idx, u64 N, u32 sigma,
+                                                                 const u64 *__restrict__ t_perm, SymTab tab,
+                                                                 OT *__restrict__ out, u32 *err) {
+    __shared__ __attribute__((aligned(16))) u8 s_code[MTF_NT * MTF_STRIDE];
+    __shared__ u64 s_w[MTF_NT / 64];
+    __shared__ i16 s_tab[16];
+    if (threadIdx.x < 16) s_tab[threadIdx.x] = tab.v[threadIdx.x];
+    const u64 base = (u64)blockIdx.x * MTF_TILE;
+    nibi_stage<IT>(idx, N, base, sigma, s_code, err);
+    __syncthreads();
+    const u64 cbase = base + (u64)threadIdx.x * MTF_CH;
+    const u32 nvalid = cbase >= N ? 0u : (N - cbase >= MTF_CH ? (u32)MTF_CH : (u32)(N - cbase));
+    const u64 mine = nibi_chunk<true>(s_code, nvalid);
+    u64 agg;
+    const u64 exc = nibi_block_excl(mine, s_w, &agg);
+    // the list this lane's chunk starts from (codes: the initial list is the identity)
+    const u64 lin = nibi_gather(t_perm[blockIdx.x], exc);
+    u32 *cw = reinterpret_cast<u32 *>(s_code + threadIdx.x * MTF_STRIDE);
+#pragma unroll 4
+    for (u32 w = 0; w < MTF_CH / 4; w++) {
+        const u32 wv = cw[w];
+        u32 ov = 0;
+#pragma unroll
+        for (int b = 0; b < 4; b++) ov |= ((u32)(lin >> (4 * ((wv >> (8 * b)) & 15u))) & 15u) << (8 * b);
+        cw[w] = ov;
+    }
+    __syncthreads();
+    if (sizeof(OT) == 2) {
+        if ((((uintptr_t)(out + base)) & 15) == 0) {
+            uint4 *o = reinterpret_cast<uint4 *>(out + base);
+            for (u32 g = threadIdx.x; g < MTF_TILE / 8; g += MTF_NT) {
+                const u32 p = 8 * g;
+                const u8 *sb = s_code + (p / MTF_CH) * MTF_STRIDE + (p % MTF_CH);
+                if (base + p + 8 <= N) {
+                    u32 t[4];
+#pragma unroll
+                    for (int q = 0; q < 4; q++)
+                        t[q] = (u32)(u16)s_tab[sb[2 * q]] | ((u32)(u16)s_tab[sb[2 * q + 1]] << 16);
+                    o[g] = make_uint4(t[0], t[1], t[2], t[3]);
+                } else {
+                    for (u32 q = 0; q < 8; q++)
+                        if (base + p + q < N) out[base + p + q] = (OT)s_tab[sb[q]];
+                }
+            }
+        } else {
+            for (u32 p = threadIdx.x; p < MTF_TILE; p += MTF_NT)
+                if (base + p < N) out[base + p] = (OT)s_tab[s_code[(p / MTF_CH) * MTF_STRIDE + (p % MTF_CH)]];
+        }
+    } else {
+        if ((((uintptr_t)(out + base)) & 15) == 0) {
+            uint4 *o = reinterpret_cast<uint4 *>(out + base);
+            for (u32 g = threadIdx.x; g < MTF_TILE / 16; g += MTF_NT) {
+                const u32 p = 16 * g;
+                const u32 *sb = reinterpret_cast<const u32 *>(s_code + (p / MTF_CH) * MTF_STRIDE + (p % MTF_CH));
+                if (base + p + 16 <= N) {
+                    o[g] = make_uint4(sb[0], sb[1], sb[2], sb[3]);
+                } else {
+                    const u8 *s8 = reinterpret_cast<const u8 *>(sb);
+                    for (u32 q = 0; q < 16; q++)
+                        if (base + p + q < N) out[base + p + q] = (OT)s8[q];
+                }
+            }
+        } else {
+            for (u32 p = threadIdx.x; p < MTF_TILE; p += MTF_NT)
+                if (base + p < N) out[base + p] = (OT)s_code[(p / MTF_CH) * MTF_STRIDE + (p % MTF_CH)];
+        }
+    }
+}
+
 // ---- which general path?  The lane chunks cost ~ rank / 4 list words per symbol, the wave chunks a
 // constant; on large alphabets with uniformly spread symbols (average rank ~ sigma / 2) the wave
 // chunks win.  The rank of a symbol is the number of distinct symbols since its last occurrence, so
