@@ -469,7 +469,9 @@ __global__ __launch_bounds__(GRP_NT, 4) void group_kernel(GroupArgs a) {
 #ifndef FIN_WPW
 #define FIN_WPW 8      // windows per wave; measured at 1 GiB: 2: 7.75, 4: 6.96, 8: 6.59, 12: 7.99, 16: 7.89 ms
 #endif
+#ifndef FIN_NT
 #define FIN_NT 256
+#endif
 
 // SA and last column of a text made of one repeated byte: SA = n, n-1, .., 0
 __global__ __launch_bounds__(256) void unary_sa_kernel(const u8 *__restrict__ text, u32 n, u32 *__restrict__ sa,
@@ -558,11 +560,15 @@ __global__ __launch_bounds__(FIN_NT) void finish_kernel(FinishArgs a) {
     const int w = threadIdx.x >> 6, l = threadIdx.x & 63;
     u32 *low = s_low[w];
 #if FIN_STAGE
+    __shared__ u32 s_nstg[FIN_NT / 64];
+    __shared__ u32 s_base;
     u32 nstg = 0;   // wave-uniform
-    auto flush = [&]() {
-        u32 base = 0;
-        if (l == 0) base = atomicAdd(&a.counters[0], nstg);
-        base = __shfl(base, 0, 64);
+    // have_base: the slots were obtained for the whole block (end of the kernel)
+    auto flush = [&](bool have_base, u32 base) {
+        if (!have_base) {
+            if (l == 0) base = atomicAdd(&a.counters[0], nstg);
+            base = __shfl(base, 0, 64);
+        }
         __builtin_amdgcn_wave_barrier();
         for (u32 e = l; e < nstg; e += 64) {
             const u32 o = base + e;
@@ -579,7 +585,11 @@ __global__ __launch_bounds__(FIN_NT) void finish_kernel(FinishArgs a) {
     const u64 N = a.N;
     const u64 wave = (u64)blockIdx.x * (FIN_NT / 64) + w;
     const u64 ws0 = wave * 64 * FIN_WPW;
+#if !FIN_STAGE
     if (ws0 >= N) return;
+#endif
+    // (staged: a wave past the end runs through -- every window returns at once -- to reach the
+    // block-wide hand-over of the staged entries)
     const u64 lowmask = a.lbits >= 64 ? ~0ull : ((1ull << a.lbits) - 1ull);  // remaining key bits
 
     // all chunks of this wave are requested up front (one round trip instead of one per window)
@@ -602,7 +612,7 @@ __global__ __launch_bounds__(FIN_NT) void finish_kernel(FinishArgs a) {
             vv[c] = pos < N ? a.sa_in[pos] : 0u;
         }
     }
-    u64 tprev = ws0 > 0 ? (a.keys[ws0 - 1] >> a.tshift) : 0;  // wave-uniform
+    u64 tprev = (ws0 > 0 && ws0 <= N) ? (a.keys[ws0 - 1] >> a.tshift) : 0;  // wave-uniform
     bool hasprev = ws0 > 0;
 
     auto window = [&](auto full_tag, const int win) {
@@ -690,7 +700,7 @@ __global__ __launch_bounds__(FIN_NT) void finish_kernel(FinishArgs a) {
         const u32 nact = (u32)__popcll(abA) + (u32)__popcll(abB);
 #if FIN_STAGE
         if (nact) {
-            if (nstg > FIN_STAGE) flush();
+            if (nstg > FIN_STAGE) flush(false, 0u);
             if (actA) {
                 const u32 e = nstg + (u32)__popcll(abA & lanemask_lt());
                 s_stg[w][0][e] = (u32)(ws + sA) + rankA;
@@ -759,7 +769,20 @@ __global__ __launch_bounds__(FIN_NT) void finish_kernel(FinishArgs a) {
         for (int win = 0; win < FIN_WPW; win++) window(std::false_type{}, win);
     }
 #if FIN_STAGE
-    if (nstg) flush();
+    // one counter update per BLOCK: a device-scope atomic on one address is the slowest thing here
+    // when most waves hold ties (genome-like input)
+    if (l == 0) s_nstg[w] = nstg;
+    __syncthreads();
+    u32 tot = 0, before = 0;
+#pragma unroll
+    for (int i = 0; i < FIN_NT / 64; i++) {
+        if (i < w) before += s_nstg[i];
+        tot += s_nstg[i];
+    }
+    if (tot == 0) return;
+    if (threadIdx.x == 0) s_base = atomicAdd(&a.counters[0], tot);
+    __syncthreads();
+    if (nstg) flush(true, s_base + before);
 #endif
 }
 
