@@ -64,6 +64,7 @@ struct SaBuffers {
     u64 *t_bits;   // N bits
     u32 *t_dir;    // per 64-bit word of t_bits
     u32 *t_bsum;
+    u32 *fin_rc;   // finish_kernel: region counters + region offsets
     u32 *kdir;     // 2^SA_KDIR_BITS + 1
     u64 sparse_cap;
     u32 *hist;
@@ -91,6 +92,7 @@ static size_t sa_carve(Arena &A, u64 N, SaBuffers &b, bool own_v1) {
     b.t_bits = A.get<u64>(N / 64 + 2);
     b.t_dir = A.get<u32>(N / 64 + 2);
     b.t_bsum = A.get<u32>(N / 64 / BDIR_TILE + 2);
+    b.fin_rc = A.get<u32>(FIN_REGIONS * FIN_RSTRIDE + 128);
     b.kdir = A.get<u32>((1u << SA_KDIR_BITS) + 2);
     b.hist = A.get<u32>(RDX_MAX_PASSES * RDX_BINS);
     b.rstatus = A.get<u64>(radix_status_words(N));
@@ -342,13 +344,24 @@ static void sa_run(tc_ctx *ctx, SaBuffers &b, const u8 *d_text, u64 n, u32 *d_sa
             fa.keys = rb.keys; fa.sa_in = rb.vals; fa.N = (u32)N; fa.tshift = 64 - topbits;
             fa.lshift = 64 - keybits; fa.lbits = keybits - topbits;
             fa.sa_out = va; fa.L = d_L;
-            fa.out_slot = b.act[0][0]; fa.out_idx = b.act[0][1]; fa.out_grp = b.act[0][2];
+            // the lean pass appends to 64 regions of the SECOND active set (one counter each); they are
+            // then packed into the first one, which everything below works on
+            fa.out_slot = b.act[1][0]; fa.out_idx = b.act[1][1]; fa.out_grp = b.act[1][2];
             fa.act_cap = (u32)N; fa.counters = counters;
+            fa.rcount = b.fin_rc; fa.rcap = (u32)(N / FIN_REGIONS);
             fa.fix_cap = (u32)(b.sparse_cap - 1024);
-            fa.ovbits = b.act[1][0];   // the second active set is still unused
+            fa.ovbits = b.act[1][0];   // (after the packing) the second active set is unused again
+            u32 *roff = b.fin_rc + FIN_REGIONS * FIN_RSTRIDE;
+            tc_memset_async(ctx, b.fin_rc, 0, (FIN_REGIONS * FIN_RSTRIDE + 128) * sizeof(u32));
             const u32 waves = tc_cdiv(N, 64 * FIN_WPW);
             finish_kernel<<<tc_cdiv(waves, FIN_NT / 64), FIN_NT, 0, s>>>(fa);
             TC_LAUNCH_CHECK(ctx);
+            finish_regions_kernel<<<1, 64, 0, s>>>(fa.rcount, fa.rcap, roff, counters);
+            TC_LAUNCH_CHECK(ctx);
+            finish_compact_kernel<<<1024, 256, 0, s>>>(roff, fa.rcap, b.act[1][0], b.act[1][1], b.act[1][2],
+                                                      b.act[0][0], b.act[0][1], b.act[0][2]);
+            TC_LAUNCH_CHECK(ctx);
+            fa.out_slot = b.act[0][0]; fa.out_idx = b.act[0][1]; fa.out_grp = b.act[0][2];
             tc_d2h(ctx, &ctx->h_scalars[12], ctx->d_scalars + 12, sizeof(u64));
             TC_HIP(ctx, hipStreamSynchronize(s));
             u32 fm = (u32)(ctx->h_scalars[12] & 0xffffffffu), over = (u32)(ctx->h_scalars[12] >> 32);
@@ -367,7 +380,7 @@ static void sa_run(tc_ctx *ctx, SaBuffers &b, const u8 *d_text, u64 n, u32 *d_sa
                 finish_fix_kernel<<<tc_cdiv(fwaves, FIN_NT / 64), FIN_NT, 0, s>>>(fa);
                 TC_LAUNCH_CHECK(ctx);
                 if (fm_lean) {
-                    finish_filter_kernel<<<tc_cdiv(fm_lean, 256), 256, 0, s>>>(fa.out_slot, fm_lean, fa.ovbits, ndropped);
+                    finish_filter_kernel<<<tc_cdiv(fm_lean, 256) < 4096u ? tc_cdiv(fm_lean, 256) : 4096u, 256, 0, s>>>(fa.out_slot, fm_lean, fa.ovbits, ndropped);
                     TC_LAUNCH_CHECK(ctx);
                 }
                 tc_d2h(ctx, &ctx->h_scalars[12], ctx->d_scalars + 12, 2 * sizeof(u64));

@@ -542,6 +542,10 @@ struct FinishArgs {
     u32 *counters;     // [0] active count, [1] bit 0: a bucket longer than the window logic handles was
                        //     met (what was written for its members is void), bit 1: such buckets were emitted as
                        //     tied groups
+    u32 *rcount;       // finish_kernel: FIN_REGIONS counters, FIN_RSTRIDE words apart; block b appends to region
+                       //     b % FIN_REGIONS of out_* (rcap entries each) -- one counter for the whole grid is a
+                       //     12 ns serial step per block on repeat-rich input
+    u32 rcap;
     u32 fix_cap;       // finish_fix_kernel stops writing once the active count exceeds this
     u32 *ovbits;       // finish_fix_kernel: one bit per position, set for members of over-long buckets
 };
@@ -549,6 +553,8 @@ struct FinishArgs {
 // tied members are staged per wave and leave with ONE counter update per flush: on inputs with ties in
 // most windows (repeats) a device-scope atomic per window on one address serialises the grid
 // (genome-like 256 MiB: 6.6 ms, of which ~5 ms waiting for the counter)
+#define FIN_REGIONS 64
+#define FIN_RSTRIDE 64
 #ifndef FIN_STAGE
 #define FIN_STAGE 192   // staged entries per wave (a window adds at most 128)
 #endif
@@ -564,15 +570,18 @@ __global__ __launch_bounds__(FIN_NT) void finish_kernel(FinishArgs a) {
     __shared__ u32 s_base;
     u32 nstg = 0;   // wave-uniform
     // have_base: the slots were obtained for the whole block (end of the kernel)
-    auto flush = [&](bool have_base, u32 base) {
+    const u32 region = blockIdx.x % FIN_REGIONS;
+    u32 *rctr = a.rcount + region * FIN_RSTRIDE;
+    const u32 rbase = region * a.rcap;
+    auto flush = [&](bool have_base, u32 base) {   // base: offset inside the block's region
         if (!have_base) {
-            if (l == 0) base = atomicAdd(&a.counters[0], nstg);
+            if (l == 0) base = atomicAdd(rctr, nstg);
             base = __shfl(base, 0, 64);
         }
         __builtin_amdgcn_wave_barrier();
         for (u32 e = l; e < nstg; e += 64) {
-            const u32 o = base + e;
-            if (o < a.act_cap) {
+            const u32 o = rbase + base + e;
+            if (base + e < a.rcap) {
                 a.out_slot[o] = s_stg[w][0][e];
                 a.out_idx[o] = s_stg[w][1][e];
                 a.out_grp[o] = s_stg[w][2][e];
@@ -586,7 +595,7 @@ __global__ __launch_bounds__(FIN_NT) void finish_kernel(FinishArgs a) {
     const u64 wave = (u64)blockIdx.x * (FIN_NT / 64) + w;
     const u64 ws0 = wave * 64 * FIN_WPW;
 #if !FIN_STAGE
-    if (ws0 >= N) return;
+#error "finish_kernel needs the staged hand-over (FIN_STAGE > 0)"
 #endif
     // (staged: a wave past the end runs through -- every window returns at once -- to reach the
     // block-wide hand-over of the staged entries)
@@ -780,7 +789,7 @@ __global__ __launch_bounds__(FIN_NT) void finish_kernel(FinishArgs a) {
         tot += s_nstg[i];
     }
     if (tot == 0) return;
-    if (threadIdx.x == 0) s_base = atomicAdd(&a.counters[0], tot);
+    if (threadIdx.x == 0) s_base = atomicAdd(rctr, tot);
     __syncthreads();
     if (nstg) flush(true, s_base + before);
 #endif
@@ -888,15 +897,63 @@ __global__ __launch_bounds__(FIN_NT) void finish_fix_kernel(FinishArgs a) {
 // sort behind every real entry); *ndropped counts them
 __global__ __launch_bounds__(256) void finish_filter_kernel(u32 *__restrict__ slot, u32 count,
                                                             const u32 *__restrict__ ovbits, u32 *ndropped) {
-    const u32 k = blockIdx.x * 256 + threadIdx.x;
-    bool drop = false;
-    if (k < count) {
+    // grid-stride, one counter update per block (an update per wave on the one address took longer
+    // than the pass itself on repeat-rich input)
+    __shared__ u32 s_n;
+    if (threadIdx.x == 0) s_n = 0;
+    __syncthreads();
+    u32 mine = 0;
+    for (u64 k = (u64)blockIdx.x * 256 + threadIdx.x; k < count; k += (u64)gridDim.x * 256) {
         const u32 j = slot[k];
-        drop = (ovbits[j >> 5] >> (j & 31)) & 1u;
-        if (drop) slot[k] = 0xFFFFFFFFu;
+        if ((ovbits[j >> 5] >> (j & 31)) & 1u) {
+            slot[k] = 0xFFFFFFFFu;
+            mine++;
+        }
     }
-    const u64 m = __ballot(drop);
-    if (m && lane_id() == 0) atomicAdd(ndropped, (u32)__popcll(m));
+    for (int d = 32; d >= 1; d >>= 1) mine += (u32)__shfl_xor((int)mine, d, 64);
+    if (lane_id() == 0 && mine) atomicAdd(&s_n, mine);
+    __syncthreads();
+    if (threadIdx.x == 0 && s_n) atomicAdd(ndropped, s_n);
+}
+
+// the regions of finish_kernel -> one contiguous list.  roff[r] = entries before region r; counters[0]
+// = their total (what the host reads); a region that overflowed makes the total exceed every capacity.
+__global__ __launch_bounds__(64) void finish_regions_kernel(const u32 *__restrict__ rcount, u32 rcap,
+                                                            u32 *__restrict__ roff, u32 *__restrict__ counters) {
+    const u32 l = threadIdx.x;
+    const u32 c = rcount[l * FIN_RSTRIDE];
+    const bool over = c > rcap;
+    u32 inc = over ? rcap : c;
+    const u32 mine = inc;
+    for (int d = 1; d < 64; d <<= 1) {
+        const u32 t = (u32)__shfl_up((int)inc, d, 64);
+        if ((int)l >= d) inc += t;
+    }
+    roff[l] = inc - mine;
+    const u64 anyover = __ballot(over);
+    if (l == 63) {
+        roff[64] = inc;
+        counters[0] = anyover ? 0xFFFFFFF0u : inc;
+    }
+}
+__global__ __launch_bounds__(256) void finish_compact_kernel(const u32 *__restrict__ roff, u32 rcap,
+                                                             const u32 *__restrict__ in_slot,
+                                                             const u32 *__restrict__ in_idx,
+                                                             const u32 *__restrict__ in_grp,
+                                                             u32 *__restrict__ out_slot, u32 *__restrict__ out_idx,
+                                                             u32 *__restrict__ out_grp) {
+    const u32 total = roff[64];
+    for (u64 k = (u64)blockIdx.x * 256 + threadIdx.x; k < total; k += (u64)gridDim.x * 256) {
+        u32 lo = 0, hi = FIN_REGIONS;   // the region whose range holds entry k
+        while (hi - lo > 1) {
+            const u32 mid = (lo + hi) >> 1;
+            if (roff[mid] <= (u32)k) lo = mid; else hi = mid;
+        }
+        const u64 src = (u64)lo * rcap + ((u32)k - roff[lo]);
+        out_slot[k] = in_slot[src];
+        out_idx[k] = in_idx[src];
+        out_grp[k] = in_grp[src];
+    }
 }
 
 // active set arrives unordered from finish_kernel; refine needs it in SA order:
