@@ -50,7 +50,9 @@ struct Alphabet {
 };
 
 // ------------------------------------------------------------------ suffix array
+#ifndef SA_KDIR_BITS
 #define SA_KDIR_BITS 22
+#endif
 struct SaBuffers {
     u64 *k0, *k1;
     u32 *v0, *v1;
