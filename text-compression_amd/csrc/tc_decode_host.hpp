@@ -16,6 +16,7 @@
 //      final offsets.  Works for ANY Seq (Maybe Word8): no Nothing => empty output;
 //      a second Nothing met on the chain => TC_ERR_MALFORMED (fromJust, :195).
 #pragma once
+#include <type_traits>
 #include <algorithm>
 #include "tc_encode_host.hpp"
 
@@ -360,10 +361,7 @@ __global__ __launch_bounds__(256) void lf_count_kernel(Acc acc, u32 N, Lut8 lut,
     __syncthreads();
     const u64 base = (u64)blockIdx.x * LF_BLOCK;
     u32 c[4] = {0, 0, 0, 0};
-    for (u32 i = threadIdx.x; i < LF_BLOCK; i += 256) {
-        const u64 j = base + i;
-        if (j >= N) break;
-        const int sym = acc(j);
+    auto one = [&](u64 j, int sym) {
         if (sym < 0) {
             atomicMin(prim, (u32)j);
             atomicAdd(prim + 1, 1u);
@@ -371,7 +369,27 @@ __global__ __launch_bounds__(256) void lf_count_kernel(Acc acc, u32 N, Lut8 lut,
         const u32 code = s_lut[sym + 1];
         if (code == 0xffu && !prim[2]) atomicOr(prim + 2, 1u);
         c[0] += code == 0; c[1] += code == 1; c[2] += code == 2; c[3] += code == 3;
+    };
+    bool done = false;
+    if constexpr (std::is_same<Acc, SymAcc>::value) {
+        // eight symbols per 16-byte load (2-byte loads run at a fraction of the HBM rate)
+        if (base + LF_BLOCK <= N && (((uintptr_t)(acc.s + base)) & 15) == 0) {
+            const uint4 *src = reinterpret_cast<const uint4 *>(acc.s + base);
+            for (u32 g = threadIdx.x; g < LF_BLOCK / 8; g += 256) {
+                const uint4 t = src[g];
+                const u32 x[4] = {t.x, t.y, t.z, t.w};
+#pragma unroll
+                for (int q = 0; q < 8; q++) one(base + 8 * g + q, (int)(i16)((x[q >> 1] >> (16 * (q & 1))) & 0xffffu));
+            }
+            done = true;
+        }
     }
+    if (!done)
+        for (u32 i = threadIdx.x; i < LF_BLOCK; i += 256) {
+            const u64 j = base + i;
+            if (j >= N) break;
+            one(j, acc(j));
+        }
 #pragma unroll
     for (int k = 0; k < 4; k++) {
         u32 v = c[k];
@@ -421,10 +439,32 @@ __global__ __launch_bounds__(256) void lf_build_kernel(Acc acc, u32 N, Lut8 lut,
     __syncthreads();
     const u64 base = (u64)blockIdx.x * LF_BLOCK;
     u8 *sc = reinterpret_cast<u8 *>(s_code);
-    for (u32 i = threadIdx.x; i < LF_BLOCK; i += 256) {
-        const u64 j = base + i;
-        sc[(i / LF_ROWS) * LF_STRIDE + (i % LF_ROWS)] = j < N ? s_lut[acc(j) + 1] : (u8)0;
+    bool staged = false;
+    if constexpr (std::is_same<Acc, SymAcc>::value) {
+        if (base + LF_BLOCK <= N && (((uintptr_t)(acc.s + base)) & 15) == 0) {
+            const uint4 *src = reinterpret_cast<const uint4 *>(acc.s + base);
+            for (u32 g = threadIdx.x; g < LF_BLOCK / 8; g += 256) {
+                const uint4 t = src[g];
+                const u32 x[4] = {t.x, t.y, t.z, t.w};
+                u32 w2[2] = {0, 0};
+#pragma unroll
+                for (int q = 0; q < 8; q++) {
+                    const int sym = (int)(i16)((x[q >> 1] >> (16 * (q & 1))) & 0xffffu);
+                    w2[q >> 2] |= (u32)s_lut[sym + 1] << (8 * (q & 3));
+                }
+                const u32 i = 8 * g;   // eight codes of one line: two aligned words
+                u32 *dst = reinterpret_cast<u32 *>(sc + (i / LF_ROWS) * LF_STRIDE + (i % LF_ROWS));
+                dst[0] = w2[0];
+                dst[1] = w2[1];
+            }
+            staged = true;
+        }
     }
+    if (!staged)
+        for (u32 i = threadIdx.x; i < LF_BLOCK; i += 256) {
+            const u64 j = base + i;
+            sc[(i / LF_ROWS) * LF_STRIDE + (i % LF_ROWS)] = j < N ? s_lut[acc(j) + 1] : (u8)0;
+        }
     __syncthreads();
     const u32 *mine = s_code + threadIdx.x * (LF_STRIDE / 4);
     u64 pl[3][2] = {{0, 0}, {0, 0}, {0, 0}};
