@@ -64,3 +64,61 @@ def test_mirror_error_behaviour():
     assert rle.bytestringBWTFromRLEB([b"2", b"a", b"9"]) == [97, 97]   # odd tail ignored
     with pytest.raises(textcomp.TcMalformed):
         mtf.bytestringBWTFromMTFB(([5], [b"a", None]))     # DS.index out of range
+
+
+def test_hunit_through_text_variants(golden):
+    """The same HUnit vectors through the Text instantiations (`...T`): the elements are the
+    golden strings themselves (the reference builds them with decodeUtf8 . BS.singleton)."""
+    from textcomp import mtf, rle
+    for v in golden["rle"]:
+        assert rle.textToBWTToRLET(v["text"]) == v["rle"]
+        assert rle.bytestringToBWTToRLET(v["text"].encode()) == v["rle"]
+        assert rle.textFromBWTFromRLET(v["rle"]) == v["text"]
+        assert rle.bytestringFromBWTFromRLET(v["rle"]) == v["text"].encode()
+    v = golden["mtf"][0]
+    assert mtf.textToBWTToMTFT(v["text"]) == (v["indices"], v["final_list"])
+    assert mtf.bytestringToBWTToMTFT(v["text"].encode()) == (v["indices"], v["final_list"])
+    assert mtf.textFromBWTFromMTFT((v["indices"], v["final_list"])) == v["text"]
+    assert mtf.bytestringFromBWTFromMTFT((v["indices"], v["final_list"])) == v["text"].encode()
+
+
+def test_text_and_bytestring_variants_agree():
+    """Every variant of one function family is the ByteString one re-wrapped (RLE.hs:83-274,
+    MTF.hs:82-278, FMIndex.hs:385-599); non-ASCII bytes raise where decodeUtf8 would."""
+    from textcomp import bwt, fmindex, mtf, rle
+    text = "mississippi river banks, mississippi mud"
+    bs = text.encode()
+    B = bwt.textToBWT(text)                               # TextBWT = BWT Word8 of the UTF-8 bytes
+    Bb = [None if v is None else bytes([v]) for v in B]   # Seq (Maybe ByteString)
+    Bt = [None if v is None else chr(v) for v in B]       # Seq (Maybe Text)
+    RB, RT = rle.bytestringBWTToRLEB(B), rle.bytestringBWTToRLET(B)
+    assert RT == [None if e is None else e.decode() for e in RB]
+    assert rle.textBWTToRLEB(B) == RB and rle.textBWTToRLET(B) == RT
+    assert rle.bytestringToRLEB(Bb) == RB and rle.textToRLEB(Bt) == RB
+    assert rle.bytestringToRLET(Bb) == RT and rle.textToRLET(Bt) == RT
+    assert rle.bytestringBWTFromRLEB(RB) == B == rle.bytestringBWTFromRLET(RT)
+    assert rle.textBWTFromRLEB(RB) == Bt == rle.textBWTFromRLET(RT)
+    assert rle.bytestringFromRLEB(RB) == Bb == rle.bytestringFromRLET(RT)
+    assert rle.textFromRLEB(RB) == Bt == rle.textFromRLET(RT)
+    assert rle.textFromBWTFromRLET(RT) == text and rle.bytestringFromBWTFromRLET(RT) == bs
+    MB, MT = mtf.bytestringBWTToMTFB(B), mtf.bytestringBWTToMTFT(B)
+    assert MT == (MB[0], [None if e is None else e.decode() for e in MB[1]])
+    assert mtf.textBWTToMTFB(B) == MB and mtf.textBWTToMTFT(B) == MT
+    assert mtf.bytestringToMTFB(Bb) == MB and mtf.textToMTFB(Bt) == MB
+    assert mtf.bytestringToMTFT(Bb) == MT and mtf.textToMTFT(Bt) == MT
+    assert mtf.bytestringBWTFromMTFB(MB) == B == mtf.bytestringBWTFromMTFT(MT)
+    assert mtf.textBWTFromMTFB(MB) == Bt == mtf.textBWTFromMTFT(MT)
+    assert mtf.bytestringFromMTFB(MB) == Bb == mtf.bytestringFromMTFT(MT)
+    assert mtf.textFromMTFB(MB) == Bt == mtf.textFromMTFT(MT)
+    assert mtf.textFromBWTFromMTFT(MT) == text and mtf.bytestringFromBWTFromMTFT(MT) == bs
+    pats = ["ssi", "mississippi", "zz", "i"]
+    cb = fmindex.bytestringFMIndexCountS([p.encode() for p in pats], bs)
+    assert fmindex.textFMIndexCountS(pats, text) == [(p, c) for p, (_, c) in zip(pats, cb)] == fmindex.textFMIndexCountP(pats, text)
+    assert [c for _, c in cb] == [4, 2, None, 9]
+    lb = fmindex.bytestringFMIndexLocateS([p.encode() for p in pats], bs)
+    assert fmindex.textFMIndexLocateS(pats, text) == [(p, h) for p, (_, h) in zip(pats, lb)] == fmindex.textFMIndexLocateP(pats, text)
+    assert fmindex.textFMIndexCountS([], text) == [] and fmindex.textFMIndexCountS(pats, "") == []
+    with pytest.raises(UnicodeDecodeError):               # decodeUtf8 . BS.singleton on a byte >= 0x80
+        rle.textToBWTToRLET("café")
+    with pytest.raises(UnicodeDecodeError):
+        fmindex.textFMIndexCountS(["a"], "café")

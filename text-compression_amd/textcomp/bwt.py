@@ -54,3 +54,32 @@ def bytestringFromByteStringBWT(bwt, ctx=None):
 def textFromBWT(bwt, ctx=None):
     """textFromBWT (BWT.hs:120-123)."""
     return bytestringFromWord8BWT(bwt, ctx).decode("utf-8")
+
+
+# ---- shared by the Text (`...T`) variants of Data.RLE / Data.MTF / Data.FMIndex ---------------
+# The reference turns every byte of a BWT into a Text with `DTE.decodeUtf8 . BS.singleton`
+# (RLE.hs:137-140, MTF.hs:137-140, FMIndex.hs:150-158): defined for ASCII bytes only, an exception
+# otherwise.  Here: bytes <-> str element-wise with Python's strict UTF-8 codec (UnicodeDecodeError
+# where decodeUtf8 throws).  Elements are the single bytes every BWT-derived sequence holds.
+def _elems_to_text(seq):
+    """fmap (fmap DTE.decodeUtf8)"""
+    return [None if e is None else e.decode("utf-8") for e in seq]
+
+
+def _elems_to_bytes(seq):
+    """fmap (fmap DTE.encodeUtf8); elements must be one byte long once encoded"""
+    out = []
+    for e in seq:
+        if e is None:
+            out.append(None)
+            continue
+        b = e.encode("utf-8")
+        if len(b) != 1:
+            raise ValueError("only one-byte elements are supported on the device path: %r" % (e,))
+        out.append(b)
+    return out
+
+
+def _word8_to_bytes(bwt):
+    """BWT Word8 (int|None) -> BWT ByteString (bytes|None): fmap (fmap BS.singleton)"""
+    return [None if v is None else bytes([v]) for v in bwt]

@@ -82,5 +82,97 @@ def bytestringFromBWTFromRLEB(rle, ctx=None):
 
 
 def textFromBWTFromRLEB(rle, ctx=None):
-    """textFromBWTFromRLEB (RLE.hs:198-200)."""
+    """textFromBWTFromRLEB (RLE.hs:199-201)."""
     return bytestringFromBWTFromRLEB(rle, ctx).decode("utf-8")
+
+
+# ---- the Text instantiations and the remaining ByteString ones (RLE.hs:35-62) -------------------
+# A TextBWT (BWT.hs:79-81) wraps the BWT Word8 of the UTF-8 bytes, so it is the same list here.
+def textBWTToRLEB(tbwt, ctx=None):
+    """textBWTToRLEB :: TextBWT -> RLE ByteString (RLE.hs:107-113)."""
+    return bytestringBWTToRLEB(tbwt, ctx)
+
+
+def bytestringBWTToRLET(bwt, ctx=None):
+    """bytestringBWTToRLET :: BWT Word8 -> RLE Text (RLE.hs:137-143)."""
+    return _bwt._elems_to_text(bytestringBWTToRLEB(bwt, ctx))
+
+
+def textBWTToRLET(tbwt, ctx=None):
+    """textBWTToRLET :: TextBWT -> RLE Text (RLE.hs:127-133)."""
+    return bytestringBWTToRLET(tbwt, ctx)
+
+
+def bytestringToBWTToRLET(bs, ctx=None):
+    """bytestringToBWTToRLET (RLE.hs:89-91) = bytestringBWTToRLET . bytestringToBWT."""
+    return _bwt._elems_to_text(bytestringToBWTToRLEB(bs, ctx))
+
+
+def textToBWTToRLET(text, ctx=None):
+    """textToBWTToRLET (RLE.hs:101-103) = textBWTToRLET . textToBWT."""
+    return bytestringToBWTToRLET(text.encode("utf-8"), ctx)
+
+
+def textToRLEB(seq, ctx=None):
+    """textToRLEB :: Seq (Maybe Text) -> RLE ByteString (RLE.hs:146-152)."""
+    return bytestringToRLEB(_bwt._elems_to_bytes(seq), ctx)
+
+
+def textToRLET(seq, ctx=None):
+    """textToRLET :: Seq (Maybe Text) -> RLE Text (RLE.hs:162-166)."""
+    return _bwt._elems_to_text(textToRLEB(seq, ctx))
+
+
+def bytestringToRLET(seq, ctx=None):
+    """bytestringToRLET :: Seq (Maybe ByteString) -> RLE Text (RLE.hs:169-175)."""
+    return _bwt._elems_to_text(bytestringToRLEB(seq, ctx))
+
+
+def _rle_to_bytes(rle):
+    """fmap (fmap DTE.encodeUtf8) on an RLE Text (counts are several digits long)"""
+    return [None if e is None else e.encode("utf-8") for e in rle]
+
+
+def bytestringBWTFromRLET(rle, ctx=None):
+    """bytestringBWTFromRLET :: RLE Text -> BWT ByteString (RLE.hs:219-224); as a BWT Word8."""
+    return bytestringBWTFromRLEB(_rle_to_bytes(rle), ctx)
+
+
+def textBWTFromRLET(rle, ctx=None):
+    """textBWTFromRLET :: RLE Text -> BWT Text (RLE.hs:211-215): str|None elements."""
+    return _bwt._elems_to_text(_bwt._word8_to_bytes(bytestringBWTFromRLET(rle, ctx)))
+
+
+def textBWTFromRLEB(rle, ctx=None):
+    """textBWTFromRLEB :: RLE ByteString -> BWT Text (RLE.hs:228-233)."""
+    return _bwt._elems_to_text(_bwt._word8_to_bytes(bytestringBWTFromRLEB(rle, ctx)))
+
+
+def bytestringFromBWTFromRLET(rle, ctx=None):
+    """bytestringFromBWTFromRLET :: RLE Text -> ByteString (RLE.hs:190-195)."""
+    return _bwt.bytestringFromWord8BWT(bytestringBWTFromRLET(rle, ctx), ctx)
+
+
+def textFromBWTFromRLET(rle, ctx=None):
+    """textFromBWTFromRLET :: RLE Text -> Text (RLE.hs:205-207)."""
+    return bytestringFromBWTFromRLET(rle, ctx).decode("utf-8")
+
+
+def bytestringFromRLEB(rle, ctx=None):
+    """bytestringFromRLEB :: RLE ByteString -> Seq (Maybe ByteString) (RLE.hs:254-258)."""
+    return _bwt._word8_to_bytes(bytestringBWTFromRLEB(rle, ctx))
+
+
+def textFromRLEB(rle, ctx=None):
+    """textFromRLEB :: RLE ByteString -> Seq (Maybe Text) (RLE.hs:245-250)."""
+    return _bwt._elems_to_text(bytestringFromRLEB(rle, ctx))
+
+
+def bytestringFromRLET(rle, ctx=None):
+    """bytestringFromRLET :: RLE Text -> Seq (Maybe ByteString) (RLE.hs:270-275)."""
+    return _bwt._word8_to_bytes(bytestringBWTFromRLET(rle, ctx))
+
+
+def textFromRLET(rle, ctx=None):
+    """textFromRLET :: RLE Text -> Seq (Maybe Text) (RLE.hs:262-266)."""
+    return _bwt._elems_to_text(bytestringFromRLET(rle, ctx))
