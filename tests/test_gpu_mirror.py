@@ -122,3 +122,25 @@ def test_text_and_bytestring_variants_agree():
         rle.textToBWTToRLET("café")
     with pytest.raises(UnicodeDecodeError):
         fmindex.textFMIndexCountS(["a"], "café")
+
+
+def test_fmindex_value_against_doc_tables(golden):
+    """The FMIndex value (Cc, OccCK, SA) laid out from the device's BWT / C array / suffix array
+    equals the reference's abracadabra doc tables (FMIndex/Internal.hs:49-113) and inverts."""
+    from textcomp import fmindex
+    d = golden["fmindex_doc"]
+    text = d["text"].encode()
+    cc, occck, sa = fmindex.bytestringToBWTToFMIndexB(text)
+    name = lambda e: "$" if e is None else e.decode()
+    assert {name(s): c for c, s in cc} == d["C"]
+    assert [name(s) for _, s in cc] == sorted(d["C"], key=lambda k: (k != "$", k))      # Nothing first, then sorted
+    assert "".join(name(x) for _, _, x in occck[0][1]) == d["L"]
+    for sym, col in occck:
+        assert [k for k, _, _ in col] == list(range(1, len(text) + 2))
+        assert [o for _, o, _ in col] == d["Occ"][name(sym)]
+    assert [r for r, _, _ in sa] == list(range(1, len(text) + 2))
+    assert sorted(p for _, p, _ in sa) == list(range(1, len(text) + 2))
+    assert all(sfx == text[p - 1:] for _, p, sfx in sa) and [s for _, _, s in sa] == sorted(s for _, _, s in sa)
+    assert fmindex.bytestringFromBWTFromFMIndexB((cc, occck, sa)) == text
+    assert fmindex.textToBWTToFMIndexB(d["text"]) == (cc, occck, sa)
+    assert fmindex.bytestringToBWTToFMIndexB(b"") == ([], [], [])

@@ -75,3 +75,55 @@ def textFMIndexLocateS(pats, text, ctx=None):
 def textFMIndexLocateP(pats, text, ctx=None):
     """textFMIndexLocateP (FMIndex.hs:574-599)."""
     return textFMIndexLocateS(pats, text, ctx)
+
+
+# ---- the FMIndex VALUE (FMIndex/Internal.hs:153-170) ------------------------------------------
+# FMIndex (Cc, OccCK, SA): sigma pairs, sigma x N triples and N suffix records -- O(sigma N + N^2)
+# elements, a shape for small inputs (the reference builds it through the O(n^2) rotation matrix).
+# The device supplies what the path computes (BWT, C array, suffix array); the Seq-of-tuples shape
+# is laid out here.  count / locate never materialise it: they run on the device index (`tc_fm`).
+def bytestringToBWTToFMIndexB(bs, ctx=None):
+    """bytestringToBWTToFMIndexB :: ByteString -> FMIndex ByteString (FMIndex.hs:108-111,162-183):
+    (Cc, OccCK, SA) with Cc = [(C[c], c)], OccCK = [(c, [(k, Occ(c, k), L[k])  k = 1..N])] for the
+    present symbols c in order (Nothing first, Occ inclusive of k; seqToCc / seqToOccCK,
+    FMIndex/Internal.hs:195-316) and SA = [(suffixindex, suffixstartpos, suffix)], 1-based
+    (createSuffixArray, BWT/Internal.hs:110-134)."""
+    from . import bwt as _bwt
+    if len(bs) == 0:
+        return [], [], []
+    c = ctx or default_context()
+    B = _bwt.bytestringToBWT(bs, c)
+    fm = c.fm_build(bs)
+    try:
+        info = fm.info()
+    finally:
+        fm.close()
+    el = lambda s: None if s < 0 else bytes([int(s)])
+    cc = [(int(v), el(s)) for s, v in zip(info["c_sym"], info["c_val"])]
+    Lb = [None if v is None else bytes([v]) for v in B]
+    occck = []
+    for _, sym in cc:
+        run, col = 0, []
+        for k, x in enumerate(Lb, start=1):
+            if x == sym:
+                run += 1
+            col.append((k, run, x))
+        occck.append((sym, col))
+    sa = c.suffix_array(bs)
+    sarec = [(j + 1, int(p) + 1, bytes(bs[int(p):])) for j, p in enumerate(sa)]
+    return cc, occck, sarec
+
+
+def textToBWTToFMIndexB(text, ctx=None):
+    """textToBWTToFMIndexB (FMIndex.hs:122-125)."""
+    return bytestringToBWTToFMIndexB(text.encode("utf-8"), ctx)
+
+
+def bytestringFromBWTFromFMIndexB(fmi, ctx=None):
+    """bytestringFromBWTFromFMIndexB (FMIndex.hs:244-246): the text back from the index -- the BWT is
+    the third component of the first OccCK row (seqFromFMIndex, FMIndex/Internal.hs:324-338)."""
+    from . import bwt as _bwt
+    cc, occck, sa = fmi
+    if len(cc) == 0 or len(occck) == 0 or len(sa) == 0:
+        return b""
+    return _bwt.bytestringFromByteStringBWT([x for _, _, x in occck[0][1]], ctx)
