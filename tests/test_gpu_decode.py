@@ -111,7 +111,8 @@ def test_rle_decode_long_runs(ctx):
 @pytest.mark.parametrize("env", [{"TC_IBWT_SCATTER": "0"}, {"TC_IBWT_REWALK": "1"},
                                  {"TC_IBWT_SCATTER": "0", "TC_IBWT_REWALK": "1"}, {"TC_IBWT_LF": "0"},
                                  {"TC_IBWT_LF": "0", "TC_IBWT_REWALK": "1"},
-                                 {"TC_IBWT_LF": "0", "TC_IBWT_SCATTER": "0"}, {"TC_MTF_FORCE_GENERAL": "1"}],
+                                 {"TC_IBWT_LF": "0", "TC_IBWT_SCATTER": "0"}, {"TC_MTF_FORCE_GENERAL": "1"},
+                                 {"TC_DECODE_BYTES": "0"}, {"TC_DECODE_BYTES": "0", "TC_IBWT_LF": "0"}],
                          ids=lambda e: ",".join("%s=%s" % kv for kv in e.items()))
 def test_ibwt_path_selectors(ctx, env, monkeypatch):
     """The alternatives inside the inverse BWT (generic radix sort of the positions instead of the

@@ -348,6 +348,12 @@ struct LfTable {
     u8 sym[8];    // byte value of code c
 };
 
+// the symbols as MTF codes, one byte each (fused decode of a small alphabet): code 0 = Nothing,
+// code c = the (c-1)-th byte value; as an accessor it yields c - 1, i.e. -1 or the LF code itself
+struct CodeAcc {
+    const u8 *c;
+    __device__ __forceinline__ int operator()(u64 j) const { return (int)c[j] - 1; }
+};
 // pass 1: per block, occurrences of codes 0..3; the row of the Nothing -> *prim
 // prim[0] = row of the (first) Nothing, prim[1] = number of Nothings, prim[2] != 0: a symbol outside the
 // expected alphabet (lut value 0xff) was met
@@ -380,6 +386,18 @@ __global__ __launch_bounds__(256) void lf_count_kernel(Acc acc, u32 N, Lut8 lut,
                 const u32 x[4] = {t.x, t.y, t.z, t.w};
 #pragma unroll
                 for (int q = 0; q < 8; q++) one(base + 8 * g + q, (int)(i16)((x[q >> 1] >> (16 * (q & 1))) & 0xffffu));
+            }
+            done = true;
+        }
+    }
+    if constexpr (std::is_same<Acc, CodeAcc>::value) {
+        if (base + LF_BLOCK <= N && (((uintptr_t)(acc.c + base)) & 15) == 0) {
+            const uint4 *src = reinterpret_cast<const uint4 *>(acc.c + base);
+            for (u32 g = threadIdx.x; g < LF_BLOCK / 16; g += 256) {
+                const uint4 t = src[g];
+                const u32 x[4] = {t.x, t.y, t.z, t.w};
+#pragma unroll
+                for (int q = 0; q < 16; q++) one(base + 16 * g + q, (int)((x[q >> 2] >> (8 * (q & 3))) & 0xffu) - 1);
             }
             done = true;
         }
@@ -456,6 +474,27 @@ __global__ __launch_bounds__(256) void lf_build_kernel(Acc acc, u32 N, Lut8 lut,
                 u32 *dst = reinterpret_cast<u32 *>(sc + (i / LF_ROWS) * LF_STRIDE + (i % LF_ROWS));
                 dst[0] = w2[0];
                 dst[1] = w2[1];
+            }
+            staged = true;
+        }
+    }
+    if constexpr (std::is_same<Acc, CodeAcc>::value) {
+        if (base + LF_BLOCK <= N && (((uintptr_t)(acc.c + base)) & 15) == 0) {
+            const uint4 *src = reinterpret_cast<const uint4 *>(acc.c + base);
+            for (u32 g = threadIdx.x; g < LF_BLOCK / 16; g += 256) {
+                const uint4 t = src[g];
+                const u32 x[4] = {t.x, t.y, t.z, t.w};
+                u32 w4[4];
+#pragma unroll
+                for (int q = 0; q < 4; q++) {
+                    w4[q] = 0;
+#pragma unroll
+                    for (int b = 0; b < 4; b++)
+                        w4[q] |= (u32)s_lut[(x[q] >> (8 * b)) & 0xffu] << (8 * b);   // lut index = (code - 1) + 1
+                }
+                const u32 i = 16 * g;   // sixteen codes of one line: four aligned words
+                u32 *dst = reinterpret_cast<u32 *>(sc + (i / LF_ROWS) * LF_STRIDE + (i % LF_ROWS));
+                dst[0] = w4[0]; dst[1] = w4[1]; dst[2] = w4[2]; dst[3] = w4[3];
             }
             staged = true;
         }
@@ -719,7 +758,8 @@ static void ibwt_device(tc_ctx *ctx, Arena &A, Acc acc, u64 N, const u32 *counts
         for (int v = 0; v < 257; v++) l8.v[v] = 0xff;
         l8.v[0] = 0;
         for (u32 c = 0; c < nsym; c++) {
-            l8.v[(u32)syms[c] + 1] = (u8)c;
+            // (a CodeAcc stream already holds the codes: its "symbol" c is code c)
+            l8.v[(std::is_same<Acc, CodeAcc>::value ? c : (u32)syms[c]) + 1] = (u8)c;
             tb.sym[c] = syms[c];
         }
         uint4 *lines = lf_lines;
@@ -796,6 +836,10 @@ static void ibwt_device(tc_ctx *ctx, Arena &A, Acc acc, u64 N, const u32 *counts
         }
         if (ok && lf_path(syms, nalphabet - 1, nullptr)) return;
     }
+    if constexpr (std::is_same<Acc, CodeAcc>::value) {
+        *n_out = ~0ull;   // a code stream only takes the LF walk; the caller falls back to symbols
+        return;
+    } else {
     u32 local[257];
     if (!counts257) {
         sym_hist_host<Acc>(ctx, acc, N, d_counts, local);
@@ -878,6 +922,7 @@ static void ibwt_device(tc_ctx *ctx, Arena &A, Acc acc, u64 N, const u32 *counts
     }
     u64 Lc = ctx->h_scalars[6];
     *n_out = Lc ? Lc - 1 : 0;
+    }   // (!CodeAcc)
 }
 
 // ---- inverse MTF ---------------------------------------------------------------
@@ -916,6 +961,24 @@ static void imtf_lane_launch(tc_ctx *ctx, const u16 *d_idx, u64 N, u32 sigma, u1
 }
 
 // seqFromMTF: initial list = sort(unique(list)) (MTF/Internal.hs:214).
+// list = 16 nibbles in a register (tc_mtf.hpp, "inverse MTF, sigma <= 16"); t_perm: tiles + 1 words
+template <class IT, class OT>
+static void imtf_nib_device(tc_ctx *ctx, u64 *t_perm, const IT *d_idx, u64 N, u32 sigma, const SymTab &tab,
+                            OT *d_out) {
+    hipStream_t s = ctx->stream;
+    const u32 tiles = tc_cdiv(N, MTF_TILE);
+    imtf_nib_summary_kernel<IT><<<tiles, MTF_NT, 0, s>>>(d_idx, N, sigma, t_perm, ctx->d_err);
+    TC_LAUNCH_CHECK(ctx);
+    imtf_nib_scan_kernel<<<1, MTF_NT, 0, s>>>(t_perm, tiles);
+    TC_LAUNCH_CHECK(ctx);
+    imtf_nib_apply_kernel<IT, OT><<<tiles, MTF_NT, 0, s>>>(d_idx, N, sigma, t_perm, tab, d_out, ctx->d_err);
+    TC_LAUNCH_CHECK(ctx);
+}
+__global__ __launch_bounds__(256) void codes_to_syms_kernel(const u8 *__restrict__ codes, u64 N, SymTab tab,
+                                                            i16 *__restrict__ out) {
+    for (u64 j = (u64)blockIdx.x * 256 + threadIdx.x; j < N; j += (u64)gridDim.x * 256) out[j] = tab.v[codes[j]];
+}
+
 // primary / d_idx_rw (fused decode only): the row of the one sentinel and the same index buffer,
 // writable -- lets sigma = 257 take the 256-symbol lane chunks (tc_mtf.hpp, "sigma = 257")
 static void mtf_decode_device(tc_ctx *ctx, Arena &A, const u16 *d_idx, u64 N, const i16 *list,
@@ -964,16 +1027,7 @@ static void mtf_decode_device(tc_ctx *ctx, Arena &A, const u16 *d_idx, u64 N, co
         // not the index stream of a BWT with its sentinel at `primary`: the nine-bit path below
     }
     if (sigma <= 16 && env_int("TC_MTF_FORCE_GENERAL", 0) == 0 && env_int("TC_MTF_WAVE_CHUNKS", 0) == 0) {
-        // list = 16 nibbles in a register (tc_mtf.hpp, "inverse MTF, sigma <= 16")
-        hipStream_t s = ctx->stream;
-        const u32 tiles = tc_cdiv(N, MTF_TILE);
-        u64 *t_perm = reinterpret_cast<u64 *>(perms);   // tiles + 1 words of the (chunks + 1) * 640 bytes
-        imtf_nib_summary_kernel<u16><<<tiles, MTF_NT, 0, s>>>(d_idx, N, sigma, t_perm, ctx->d_err);
-        TC_LAUNCH_CHECK(ctx);
-        imtf_nib_scan_kernel<<<1, MTF_NT, 0, s>>>(t_perm, tiles);
-        TC_LAUNCH_CHECK(ctx);
-        imtf_nib_apply_kernel<u16, i16><<<tiles, MTF_NT, 0, s>>>(d_idx, N, sigma, t_perm, tab, d_out, ctx->d_err);
-        TC_LAUNCH_CHECK(ctx);
+        imtf_nib_device<u16, i16>(ctx, reinterpret_cast<u64 *>(perms), d_idx, N, sigma, tab, d_out);
         return;
     }
     if (sigma <= 256 && env_int("TC_MTF_WAVE_CHUNKS", 0) == 0) {
@@ -988,9 +1042,9 @@ static void mtf_decode_device(tc_ctx *ctx, Arena &A, const u16 *d_idx, u64 N, co
 }
 
 // ---- inverse RLE ---------------------------------------------------------------
-template <class SymT>
+template <class SymT, class OutT = SymT>
 static void rle_decode_device(tc_ctx *ctx, Arena &A, const u32 *d_counts, const SymT *d_syms,
-                              u64 nruns, bool has_nothing, SymT *d_out, u64 cap, u64 *N_out,
+                              u64 nruns, bool has_nothing, OutT *d_out, u64 cap, u64 *N_out,
                               bool dry) {
     const u32 ntiles = tc_cdiv(nruns, RLD_TILE);
     u64 *status = A.get<u64>((size_t)ntiles + 4);
@@ -1008,11 +1062,11 @@ static void rle_decode_device(tc_ctx *ctx, Arena &A, const u32 *d_counts, const 
     a.ticket = reinterpret_cast<u32 *>(status + ntiles + 2);
     a.total = ctx->d_scalars + 7; a.err = ctx->d_err;
     a.huge = huge; a.nhuge = nhuge; a.huge_cap = huge_cap; a.ntiles = ntiles;
-    u32 grid = tc_persistent_grid_for(ctx, rle_decode_fused_kernel<SymT>, RLD_NT, 8);
+    u32 grid = tc_persistent_grid_for(ctx, rle_decode_fused_kernel<SymT, OutT>, RLD_NT, 8);
     if (grid > ntiles) grid = ntiles;
-    rle_decode_fused_kernel<SymT><<<grid, RLD_NT, 0, s>>>(a);
+    rle_decode_fused_kernel<SymT, OutT><<<grid, RLD_NT, 0, s>>>(a);
     TC_LAUNCH_CHECK(ctx);
-    rle_fill_huge_kernel<SymT><<<tc_persistent_grid(ctx, 4), 256, 0, s>>>(huge, nhuge, huge_cap, cap, d_out);
+    rle_fill_huge_kernel<OutT><<<tc_persistent_grid(ctx, 4), 256, 0, s>>>(huge, nhuge, huge_cap, cap, d_out);
     TC_LAUNCH_CHECK(ctx);
     tc_d2h(ctx, &ctx->h_scalars[7], ctx->d_scalars + 7, sizeof(u64));
     TC_HIP(ctx, hipStreamSynchronize(s));
@@ -1031,10 +1085,58 @@ static void decode_device(tc_ctx *ctx, const tc_block *blk, u8 *d_text) {
         for (u32 i = 0; i < sg; i++) sorted_list[i] = blk->final_list[i];
         std::sort(sorted_list, sorted_list + sg);
     }
+    // small alphabets (a proper list: distinct symbols in range): the byte-wide pipeline
+    bool small = blk->sigma >= 1 && blk->sigma <= 16 && env_int("TC_MTF_FORCE_GENERAL", 0) == 0 &&
+                 env_int("TC_MTF_WAVE_CHUNKS", 0) == 0 && env_int("TC_DECODE_BYTES", 1) != 0;
+    for (u32 i = 0; small && i < blk->sigma; i++)
+        small = sorted_list[i] >= -1 && sorted_list[i] <= 255 && (i == 0 || sorted_list[i] > sorted_list[i - 1]);
+    const bool small_lf = small && blk->sigma >= 2 && blk->sigma <= 6 && sorted_list[0] == -1 && N > 1 &&
+                          env_int("TC_IBWT_LF", 1) != 0;
     auto plan = [&](Arena &A, bool dry) {
         d_idx = A.get<u16>(N + 64);
         d_sym = A.get<i16>(N + 64);
         size_t mark = A.off, hi = mark;
+        if (small) {
+            // sigma <= 16: indices and codes one byte each all the way (half the traffic of the u16 / i16 forms)
+            u8 *d_idx8 = reinterpret_cast<u8 *>(d_idx);
+            u8 *d_code8 = reinterpret_cast<u8 *>(d_idx) + ((N + 64 + 15) & ~(u64)15);   // second half of d_idx
+            rle_decode_device<u16, u8>(ctx, A, blk->run_count, blk->run_value, blk->nruns, false, d_idx8, N, &got, dry);
+            if (!dry && got != N)
+                TC_FAIL(ctx, TC_ERR_MALFORMED, "runs expand to %llu symbols, block says %llu",
+                        (unsigned long long)got, (unsigned long long)N);
+            hi = A.off > hi ? A.off : hi;
+            A.off = mark;
+            u64 *t_perm = A.get<u64>((size_t)tc_cdiv(N, MTF_TILE) + 2);
+            SymTab tab;
+            for (u32 v = 0; v < 260; v++) tab.v[v] = v < blk->sigma ? sorted_list[v] : (i16)0;
+            bool walked = false;
+            if (small_lf) {
+                if (!dry) imtf_nib_device<u8, u8>(ctx, t_perm, d_idx8, N, blk->sigma, tab, d_code8);
+                hi = A.off > hi ? A.off : hi;
+                A.off = mark;
+                CodeAcc cacc{d_code8};
+                ibwt_device<CodeAcc>(ctx, A, cacc, N, nullptr, d_text, &n_out, dry, sorted_list, blk->sigma);
+                walked = dry || n_out != ~0ull;
+                if (!walked) {   // not one Nothing / a code outside the list: the symbol path decides
+                    u32 g = tc_cdiv(N, 256 * 8);
+                    codes_to_syms_kernel<<<g > 8192 ? 8192 : g, 256, 0, ctx->stream>>>(d_code8, N, tab, d_sym);
+                    TC_LAUNCH_CHECK(ctx);
+                }
+            } else if (!dry) {
+                imtf_nib_device<u8, i16>(ctx, t_perm, d_idx8, N, blk->sigma, tab, d_sym);
+            }
+            hi = A.off > hi ? A.off : hi;
+            A.off = mark;
+            if (!walked || dry) {
+                SymAcc sacc{d_sym};
+                u64 n2 = 0;
+                ibwt_device<SymAcc>(ctx, A, sacc, N, nullptr, d_text, &n2, dry);
+                if (!walked) n_out = n2;
+            }
+            hi = A.off > hi ? A.off : hi;
+            A.off = hi;
+            return;
+        }
         rle_decode_device<u16>(ctx, A, blk->run_count, blk->run_value, blk->nruns, false, d_idx, N,
                                &got, dry);
         if (!dry && got != N)

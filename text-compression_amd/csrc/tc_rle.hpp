@@ -434,15 +434,16 @@ __device__ __forceinline__ u64 wave_incl_sum64(u64 v) {
     }
     return v;
 }
-template <class SymT>
+// OutT: the element type written (SymT, or u8 for the index stream of a small alphabet)
+template <class SymT, class OutT = SymT>
 __global__ __launch_bounds__(RLD_NT) void rle_decode_fused_kernel(RleDecArgs a) {
     __shared__ u64 s_w[RLD_NT / 64];
     __shared__ u64 s_excl;
     __shared__ u32 s_tile;
-    __shared__ SymT s_stage[RLD_STAGE];
+    __shared__ OutT s_stage[RLD_STAGE];
     const int tid = threadIdx.x, w = tid >> 6, l = tid & 63;
     const SymT *syms = reinterpret_cast<const SymT *>(a.syms);
-    SymT *out = reinterpret_cast<SymT *>(a.out);
+    OutT *out = reinterpret_cast<OutT *>(a.out);
     for (;;) {
         __syncthreads();
         if (tid == 0) s_tile = atomicAdd(a.ticket, 1u);
@@ -476,6 +477,12 @@ __global__ __launch_bounds__(RLD_NT) void rle_decode_fused_kernel(RleDecArgs a) 
             }
         }
         u64 len[RLD_RPT], mine = 0;
+        if (sizeof(OutT) < sizeof(SymT)) {   // narrowed output: a value that does not fit is out of range anyway
+            bool wide = false;
+#pragma unroll
+            for (int k = 0; k < RLD_RPT; k++) wide |= r0 + k < a.nruns && (u32)(u16)sv[k] > 255u;
+            if (wide) atomicOr(a.err, 0x100u);
+        }
 #pragma unroll
         for (int k = 0; k < RLD_RPT; k++) {
             const bool ok = r0 + k < a.nruns;
@@ -505,7 +512,7 @@ __global__ __launch_bounds__(RLD_NT) void rle_decode_fused_kernel(RleDecArgs a) 
 #pragma unroll
             for (int k = 0; k < RLD_RPT; k++) {
                 const u32 ln = (u32)len[k];
-                for (u32 q = 0; q < ln; q++) s_stage[lo + q] = sv[k];
+                for (u32 q = 0; q < ln; q++) s_stage[lo + q] = (OutT)sv[k];
                 lo += ln;
             }
             __syncthreads();
@@ -521,7 +528,7 @@ __global__ __launch_bounds__(RLD_NT) void rle_decode_fused_kernel(RleDecArgs a) 
             const SymT sk = sv[k];
             if (ln && ln < 32)
                 for (u64 q = 0; q < ln; q++)
-                    if (o + q < a.cap) out[o + q] = sk;
+                    if (o + q < a.cap) out[o + q] = (OutT)sk;
             u64 longmask = __ballot(ln >= 32);
             while (longmask) {
                 const int src = __builtin_ctzll(longmask);
@@ -536,7 +543,7 @@ __global__ __launch_bounds__(RLD_NT) void rle_decode_fused_kernel(RleDecArgs a) 
                     continue;
                 }
                 for (u64 q = l; q < ll; q += 64)
-                    if (lo + q < a.cap) out[lo + q] = ss;
+                    if (lo + q < a.cap) out[lo + q] = (OutT)ss;
             }
             o += ln;
         }
