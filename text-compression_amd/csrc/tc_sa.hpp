@@ -268,7 +268,9 @@ __global__ __launch_bounds__(256) void keyhist_fix_kernel(const u8 *__restrict__
 // masks with scalar carries; only the cross-wave / cross-tile prefixes use LDS and a
 // decoupled look-back (max of "last head", sum of actives).
 #define GRP_NT 512
+#ifndef GRP_ITEMS
 #define GRP_ITEMS 8
+#endif
 #define GRP_TILE (GRP_NT * GRP_ITEMS)
 
 struct GroupArgs {
