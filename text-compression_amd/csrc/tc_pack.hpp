@@ -19,6 +19,7 @@
 #define PK_TILE (PK_SUBRUNS * PK_SUB)   // 16384 runs per tile
 #define PK_WORDS (PK_TILE * 2 / 16)     // u64 words of nibbles, worst case (2 per run)
 #define PK_NIB_SIGMA 6
+static_assert(PK_TILE * 2 < 65536, "a tile's nibble count shares a 32-bit word with its escape count (16 bits each)");
 
 static inline int pack_format(u32 sigma) { return sigma <= PK_NIB_SIGMA ? 0 : sigma <= 16 ? 1 : 2; }
 
