@@ -1,0 +1,69 @@
+"""Long randomized differential run against the CPU oracle (not part of the test suite): random
+alphabets (1..257 symbols), copied fragments, runs, periodic stretches; suffix array, fused block,
+decode, container and stream round trips.  usage: fuzz_long.py [cases] [seed] [max_n]"""
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "text-compression_amd"))
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+import oracle as O  # noqa: E402
+import textcomp  # noqa: E402
+
+cases = int(sys.argv[1]) if len(sys.argv) > 1 else 2000
+seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1
+max_n = int(sys.argv[3]) if len(sys.argv) > 3 else 60000
+rng = np.random.default_rng(seed)
+ctx = textcomp.Context(0)
+bad = 0
+for it in range(cases):
+    n = int(rng.integers(1, max_n)) if rng.random() < 0.7 else int(rng.integers(1, 300))
+    kind = rng.random()
+    sigma = 256 if kind < 0.1 else int(rng.integers(1, 7)) if kind < 0.55 else int(rng.integers(1, 41)) if kind < 0.85 else int(rng.integers(41, 257))
+    alpha = rng.permutation(256)[:sigma]
+    if rng.random() < 0.5:
+        t = alpha[rng.integers(0, sigma, n)]
+    else:
+        p = 1.0 / np.arange(1, sigma + 1) ** rng.uniform(0.5, 2.5)
+        t = alpha[rng.choice(sigma, n, p=p / p.sum())]
+    for _ in range(int(rng.integers(0, 8))):
+        ln = int(rng.integers(1, max(2, n // 2)))
+        a0, b0 = int(rng.integers(0, n - ln + 1)), int(rng.integers(0, n - ln + 1))
+        t[b0:b0 + ln] = t[a0:a0 + ln].copy()
+    if rng.random() < 0.3:
+        ln = int(rng.integers(1, n + 1)); a0 = int(rng.integers(0, n - ln + 1))
+        t[a0:a0 + ln] = t[a0]
+    if rng.random() < 0.15 and n > 16:
+        per = int(rng.integers(1, max(2, n // 4)))
+        t = np.resize(t[:per], n)
+    if sigma == 256 and n >= 256 and rng.random() < 0.7:
+        t[rng.permutation(n)[:256]] = np.arange(256)
+    tb = t.astype(np.uint8).tobytes()
+    try:
+        sa = ctx.suffix_array(tb)
+        assert sa.tolist() == O.suffix_array(tb).tolist(), "suffix array"
+        blk = ctx.encode(tb)
+        L = O.bwt_encode_arr(tb)
+        eidx, efl = O.mtf_encode_arr(L)
+        ec, ev = O.rle_encode_u32_arr(eidx)
+        assert blk["primary"] == int(np.nonzero(L < 0)[0][0]) and blk["final_list"].tolist() == efl.tolist(), "header"
+        assert blk["run_count"].tolist() == ec.tolist() and blk["run_value"].tolist() == ev.tolist(), "runs"
+        assert ctx.decode(blk) == tb, "decode"
+        if it % 4 == 0:
+            blob = ctx.encode_container(tb)
+            assert ctx.decode_container(blob) == tb, "container"
+            bs = int(rng.integers(1, n + 2))
+            st = ctx.encode_stream(tb, bs)
+            assert ctx.decode_stream(st) == tb, "stream"
+    except Exception as e:  # noqa: BLE001
+        bad += 1
+        print("CASE %d seed %d n %d sigma %d: %s %r" % (it, seed, n, sigma, type(e).__name__, e), flush=True)
+        np.save("gpurun_out/fuzz_fail_%d_%d.npy" % (seed, it), t.astype(np.uint8))
+        if bad >= 5:
+            break
+    if it % 200 == 0:
+        print("case", it, "ok so far, failures", bad, flush=True)
+print("done: %d cases, %d failures" % (cases, bad))
+sys.exit(1 if bad else 0)
