@@ -112,13 +112,16 @@ def test_rle_decode_long_runs(ctx):
                                  {"TC_IBWT_SCATTER": "0", "TC_IBWT_REWALK": "1"}, {"TC_IBWT_LF": "0"},
                                  {"TC_IBWT_LF": "0", "TC_IBWT_REWALK": "1"},
                                  {"TC_IBWT_LF": "0", "TC_IBWT_SCATTER": "0"}, {"TC_MTF_FORCE_GENERAL": "1"},
-                                 {"TC_DECODE_BYTES": "0"}, {"TC_DECODE_BYTES": "0", "TC_IBWT_LF": "0"}],
+                                 {"TC_DECODE_BYTES": "0"}, {"TC_DECODE_BYTES": "0", "TC_IBWT_LF": "0"},
+                                 {"TC_IBWT_SEGCAP": "1024"}, {"TC_IBWT_SEGCAP": "1024", "TC_IBWT_LF": "0"},
+                                 {"TC_IBWT_SEGCAP": "64"}, {"TC_IBWT_SEGCAP": "64", "TC_IBWT_LF": "0"}],
                          ids=lambda e: ",".join("%s=%s" % kv for kv in e.items()))
 def test_ibwt_path_selectors(ctx, env, monkeypatch):
     """The alternatives inside the inverse BWT (generic radix sort of the positions instead of the
     dedicated scatter; every recorded segment treated as overflowed and walked again; small alphabets
     by positions instead of by LF over the packed last column; the inverse MTF of a small alphabet on the
-    byte-list kernels instead of the nibble ones) decode to the same text."""
+    byte-list kernels instead of the nibble ones; records that count as full early, so that walks continue in extra
+    splitter slots -- 1024 -- or use them up and are repeated the old way -- 64) decode to the same text."""
     rng = np.random.default_rng(5)
     texts = [O.gen_acgtn(31, 1 << 20).tobytes(), O.gen_ascii(32, 200000).tobytes(),
              bytes(rng.integers(0, 256, 100000, dtype=np.uint8)),

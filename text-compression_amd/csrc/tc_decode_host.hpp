@@ -173,12 +173,27 @@ __global__ __launch_bounds__(ISC_NT) void ibwt_scatter_kernel(Acc acc, u32 N, Lu
 // ibwt_walk2_kernel), bit 1 = a Nothing row other than row 0 was met (an error only if the segment
 // turns out to lie on the chain of row e).
 #define IBWT_SEGCAP (16 * IBWT_S)   // segment lengths are geometric with mean IBWT_S: one in 10^7 is longer
+// A record that fills up before a splitter row is met is closed where the walk stands and the walk goes
+// on as a NEW splitter (slot K + e, e from the counter `nextra`, at most extra_cap of them): no segment is
+// ever walked twice -- a second, serial walk of one long segment costs ~1 us per row, 4 ms for a full
+// record, whatever the rest of the grid does.
+__global__ __launch_bounds__(256) void ibwt_extra_init_kernel(u32 K, u32 Ktot, u32 *__restrict__ nxt,
+                                                              u32 *__restrict__ dist, u32 *__restrict__ seglen,
+                                                              u8 *__restrict__ segflag) {
+    const u32 q = K + blockIdx.x * 256 + threadIdx.x;
+    if (q >= Ktot) return;
+    nxt[q] = q;      // inert until a walk takes the slot
+    dist[q] = 0;
+    seglen[q] = 0;
+    segflag[q] = 0;
+}
 __global__ __launch_bounds__(256) void ibwt_walk1_kernel(const u32 *__restrict__ spos, u32 N, u32 K,
                                                          u32 *__restrict__ nxt,
                                                          u32 *__restrict__ dist, CTable ct,
                                                          u8 *__restrict__ seg, u32 *__restrict__ seglen,
                                                          u8 *__restrict__ segflag, u32 force_rewalk,
-                                                         u32 *__restrict__ noverflow, u32 *__restrict__ ovlist) {
+                                                         u32 *__restrict__ noverflow, u32 *__restrict__ ovlist,
+                                                         u32 *__restrict__ nextra, u32 extra_cap, u32 segcap) {
     __shared__ u32 s_c[260];
     __shared__ i16 s_sym[260];
     for (int i = threadIdx.x; i < 260; i += 256) {
@@ -228,6 +243,21 @@ __global__ __launch_bounds__(256) void ibwt_walk1_kernel(const u32 *__restrict__
             emitted++;
         }
         if (ibwt_is_splitter(r) || steps > N) break;
+        if (emitted == segcap && extra_cap) {   // record full: close it here, go on as a new splitter
+            const u32 e = atomicAdd(nextra, 1u);
+            if (e < extra_cap) {
+                nxt[q] = K + e;
+                dist[q] = steps;
+                seglen[q] = emitted;
+                segflag[q] = (u8)flag;
+                q = K + e;
+                out = seg + (u64)q * IBWT_SEGCAP;
+                steps = 0;
+                emitted = 0;
+                word = 0;
+                flag = 0;
+            }   // (else: slots used up -- the host repeats the walk the old way)
+        }
         r = rn;
     }
     if (emitted < IBWT_SEGCAP && (emitted & 15u)) {   // the last, partial group of sixteen
@@ -584,7 +614,8 @@ __global__ __launch_bounds__(256) void ibwt_lfwalk1_kernel(const uint4 *__restri
                                                            u32 *__restrict__ nxt, u32 *__restrict__ dist,
                                                            u8 *__restrict__ seg, u32 *__restrict__ seglen,
                                                            u8 *__restrict__ segflag, u32 force_rewalk,
-                                                           u32 *__restrict__ noverflow, u32 *__restrict__ ovlist) {
+                                                           u32 *__restrict__ noverflow, u32 *__restrict__ ovlist,
+                                                           u32 *__restrict__ nextra, u32 extra_cap, u32 segcap) {
     __shared__ u32 s_C[8];
     __shared__ u8 s_sym[8];
     if (threadIdx.x < 8) {
@@ -632,6 +663,21 @@ __global__ __launch_bounds__(256) void ibwt_lfwalk1_kernel(const uint4 *__restri
         }
         r = rn;
         if (ibwt_is_splitter(r) || steps > N) break;
+        if (emitted == segcap && extra_cap) {   // record full: go on as a new splitter (ibwt_walk1_kernel)
+            const u32 e = atomicAdd(nextra, 1u);
+            if (e < extra_cap) {
+                nxt[q] = K + e;
+                dist[q] = steps;
+                seglen[q] = emitted;
+                segflag[q] = (u8)flag;
+                q = K + e;
+                out = seg + (u64)q * IBWT_SEGCAP;
+                steps = 0;
+                emitted = 0;
+                word = 0;
+                flag = 0;
+            }
+        }
     }
     if (emitted < IBWT_SEGCAP && (emitted & 15u)) {
         const u32 k4 = (emitted >> 2) & 3u;
@@ -732,22 +778,76 @@ static void ibwt_device(tc_ctx *ctx, Arena &A, Acc acc, u64 N, const u32 *counts
     const u32 K = tc_cdiv(N, IBWT_S);
     u32 *d_counts = A.get<u32>(260);
     // (k0 doubles as the segment record buffer after the sort: K * IBWT_SEGCAP bytes)
-    u64 *k0 = A.get<u64>(N > (u64)K * (IBWT_SEGCAP / 8) ? N : (u64)K * (IBWT_SEGCAP / 8));
+    // splitters: one per IBWT_S rows + slots for walks that outgrow a record (ibwt_walk1_kernel)
+    const u32 Kx = K / 32 + 256, Kt = K + Kx;
+    u64 *k0 = A.get<u64>(N > (u64)Kt * (IBWT_SEGCAP / 8) ? N : (u64)Kt * (IBWT_SEGCAP / 8));
     u64 *k1 = A.get<u64>(N);
     u32 *v0 = A.get<u32>(N);
     u32 *v1 = A.get<u32>(N);
     u32 *hist = A.get<u32>(RDX_MAX_PASSES * RDX_BINS);
     u64 *rstatus = A.get<u64>(radix_status_words(N));
-    u32 *nx[2] = {A.get<u32>(K + 1), A.get<u32>(K + 1)};
-    u32 *ds[2] = {A.get<u32>(K + 1), A.get<u32>(K + 1)};
-    u32 *seglen = A.get<u32>(K + 1);
-    u8 *segflag = A.get<u8>(K + 1);
-    u32 *ovlist = A.get<u32>(K + 1);
+    u32 *nx[2] = {A.get<u32>(Kt + 1), A.get<u32>(Kt + 1)};
+    u32 *ds[2] = {A.get<u32>(Kt + 1), A.get<u32>(Kt + 1)};
+    u32 *seglen = A.get<u32>(Kt + 1);
+    u8 *segflag = A.get<u8>(Kt + 1);
+    u32 *ovlist = A.get<u32>(Kt + 1);
     uint4 *lf_lines = A.get<uint4>(((size_t)(N / LF_ROWS) + 1) * 4);   // LF walk: N / 2 bytes
     u32 *lf_bcnt = A.get<u32>(((size_t)tc_cdiv(N, LF_BLOCK) + 1) * 4);
     if (dry) return;
     hipStream_t s = ctx->stream;
     *n_out = 0;
+    // walks (recording) -> chain ranking -> copy-out, shared by both step functions.  First with slots for
+    // walks that outgrow their record; if those run out (or TC_IBWT_REWALK asks for the old way) once more
+    // without, the long segments then being walked a second time.
+    u8 *seg = reinterpret_cast<u8 *>(k0);
+    auto walk_rank_copy = [&](auto launch_walk1, auto launch_walk2, bool reversed) {
+        const u32 rewalk = (u32)env_int("TC_IBWT_REWALK", 0);
+        // (tests: records "full" after fewer symbols, so that small inputs reach the extra slots and their exhaustion)
+        u32 segcap = (u32)env_int("TC_IBWT_SEGCAP", IBWT_SEGCAP) & ~15u;
+        if (segcap < 16 || segcap > IBWT_SEGCAP) segcap = IBWT_SEGCAP;
+        u32 *nov_ctr = reinterpret_cast<u32 *>(ctx->d_scalars + 17);   // [0] overflowed records, [1] extra slots taken
+        for (int attempt = rewalk ? 1 : 0; attempt < 2; attempt++) {
+            const u32 xcap = attempt == 0 ? Kx : 0u;
+            const u32 Ka = K + xcap;    // slots that take part in the ranking
+            tc_memset_async(ctx, ctx->d_scalars + 17, 0, sizeof(u64));
+            if (xcap) {
+                ibwt_extra_init_kernel<<<tc_cdiv(xcap, 256), 256, 0, s>>>(K, Ka, nx[0], ds[0], seglen, segflag);
+                TC_LAUNCH_CHECK(ctx);
+            }
+            launch_walk1(rewalk, nov_ctr, nov_ctr + 1, xcap, segcap);
+            TC_LAUNCH_CHECK(ctx);
+            ibwt_terminal_kernel<<<1, 1, 0, s>>>(nx[0], ds[0], ctx->d_scalars);
+            TC_LAUNCH_CHECK(ctx);
+            int cur = 0;
+            for (int r = 0; r < ceil_log2_u64(Ka) + 1; r++) {
+                ibwt_jump_kernel<<<tc_cdiv(Ka, 256), 256, 0, s>>>(nx[cur], ds[cur], nx[cur ^ 1], ds[cur ^ 1], Ka);
+                TC_LAUNCH_CHECK(ctx);
+                cur ^= 1;
+            }
+            ibwt_len_kernel<<<1, 1, 0, s>>>(nx[cur], ds[cur], ctx->d_scalars, ctx->d_err);
+            TC_LAUNCH_CHECK(ctx);
+            tc_d2h(ctx, &ctx->h_scalars[6], ctx->d_scalars + 6, sizeof(u64));
+            tc_d2h(ctx, &ctx->h_scalars[17], ctx->d_scalars + 17, sizeof(u64));
+            TC_HIP(ctx, hipStreamSynchronize(s));
+            const u32 nov = (u32)(ctx->h_scalars[17] & 0xffffffffu), taken = (u32)(ctx->h_scalars[17] >> 32);
+            if (xcap && taken > xcap) continue;   // slots ran out: the old way
+            if (reversed)
+                ibwt_copy_rev_kernel<<<tc_cdiv(Ka, 4), 256, 0, s>>>(Ka, nx[cur], ds[cur], ctx->d_scalars, seg, seglen,
+                                                                   segflag, d_text);
+            else
+                ibwt_copy_kernel<<<tc_cdiv(Ka, 4), 256, 0, s>>>(Ka, nx[cur], ds[cur], ctx->d_scalars, seg, seglen,
+                                                               segflag, d_text, ctx->d_err);
+            TC_LAUNCH_CHECK(ctx);
+            if (nov) {
+                launch_walk2(nx[cur], ds[cur], nov);
+                TC_LAUNCH_CHECK(ctx);
+            }
+            TC_HIP(ctx, hipStreamSynchronize(s));
+            break;
+        }
+        const u64 Lc = ctx->h_scalars[6];
+        *n_out = Lc ? Lc - 1 : 0;
+    };
     // small alphabet, one Nothing: walk by LF over the packed last column (see above).  syms = the
     // byte values in order (codes 0..nsym-1); cnt = their occurrences, or null: counted on the
     // device (then the walk is only taken if the column holds exactly one Nothing and nothing else
@@ -765,11 +865,9 @@ static void ibwt_device(tc_ctx *ctx, Arena &A, Acc acc, u64 N, const u32 *counts
         uint4 *lines = lf_lines;
         u32 *bcnt = lf_bcnt;
         u32 *prim = reinterpret_cast<u32 *>(ctx->d_scalars + 24);   // 4 words + 4 totals
-        u8 *seg = reinterpret_cast<u8 *>(k0);
         const u32 nb = tc_cdiv(N, LF_BLOCK);
         tc_memset_async(ctx, prim, 0, 4 * sizeof(u64));
         tc_memset_async(ctx, prim, 0xff, sizeof(u32));
-        tc_memset_async(ctx, ctx->d_scalars + 17, 0, sizeof(u64));
         lf_count_kernel<Acc><<<nb, 256, 0, s>>>(acc, (u32)N, l8, bcnt, prim);
         TC_LAUNCH_CHECK(ctx);
         lf_scan_kernel<<<1, 1024, 0, s>>>(bcnt, nb, prim + 4);
@@ -794,35 +892,16 @@ static void ibwt_device(tc_ctx *ctx, Arena &A, Acc acc, u64 N, const u32 *counts
         }
         lf_build_kernel<Acc><<<nb, 256, 0, s>>>(acc, (u32)N, l8, bcnt, lines);
         TC_LAUNCH_CHECK(ctx);
-        ibwt_lfwalk1_kernel<<<tc_cdiv(K, 256), 256, 0, s>>>(lines, (u32)N, K, prim, tb, nx[0], ds[0], seg, seglen,
-                                                           segflag, (u32)env_int("TC_IBWT_REWALK", 0),
-                                                           reinterpret_cast<u32 *>(ctx->d_scalars + 17), ovlist);
-        TC_LAUNCH_CHECK(ctx);
-        ibwt_terminal_kernel<<<1, 1, 0, s>>>(nx[0], ds[0], ctx->d_scalars);
-        TC_LAUNCH_CHECK(ctx);
-        int cur = 0;
-        for (int r = 0; r < ceil_log2_u64(K) + 1; r++) {
-            ibwt_jump_kernel<<<tc_cdiv(K, 256), 256, 0, s>>>(nx[cur], ds[cur], nx[cur ^ 1], ds[cur ^ 1], K);
-            TC_LAUNCH_CHECK(ctx);
-            cur ^= 1;
-        }
-        ibwt_len_kernel<<<1, 1, 0, s>>>(nx[cur], ds[cur], ctx->d_scalars, ctx->d_err);
-        TC_LAUNCH_CHECK(ctx);
-        ibwt_copy_rev_kernel<<<tc_cdiv(K, 4), 256, 0, s>>>(K, nx[cur], ds[cur], ctx->d_scalars, seg, seglen, segflag,
-                                                          d_text);
-        TC_LAUNCH_CHECK(ctx);
-        tc_d2h(ctx, &ctx->h_scalars[6], ctx->d_scalars + 6, sizeof(u64));
-        tc_d2h(ctx, &ctx->h_scalars[17], ctx->d_scalars + 17, sizeof(u64));
-        TC_HIP(ctx, hipStreamSynchronize(s));
-        if ((u32)ctx->h_scalars[17]) {
-            const u32 nov = (u32)ctx->h_scalars[17];
-            ibwt_lfwalk2_kernel<<<tc_cdiv(nov, 256), 256, 0, s>>>(lines, (u32)N, K, prim, tb, nx[cur], ds[cur],
-                                                                 ctx->d_scalars, d_text, ovlist, nov);
-            TC_LAUNCH_CHECK(ctx);
-            TC_HIP(ctx, hipStreamSynchronize(s));
-        }
-        const u64 Lc = ctx->h_scalars[6];
-        *n_out = Lc ? Lc - 1 : 0;
+        walk_rank_copy(
+            [&](u32 rewalk, u32 *nov_ctr, u32 *nextra, u32 xcap, u32 segcap) {
+                ibwt_lfwalk1_kernel<<<tc_cdiv(K, 256), 256, 0, s>>>(lines, (u32)N, K, prim, tb, nx[0], ds[0], seg, seglen,
+                                                                   segflag, rewalk, nov_ctr, ovlist, nextra, xcap, segcap);
+            },
+            [&](const u32 *nxf, const u32 *dsf, u32 nov) {
+                ibwt_lfwalk2_kernel<<<tc_cdiv(nov, 256), 256, 0, s>>>(lines, (u32)N, K, prim, tb, nxf, dsf, ctx->d_scalars,
+                                                                     d_text, ovlist, nov);
+            },
+            true);
         return true;
     };
     const bool lf_on = N > 1 && env_int("TC_IBWT_LF", 1) != 0;
@@ -889,39 +968,18 @@ static void ibwt_device(tc_ctx *ctx, Arena &A, Acc acc, u64 N, const u32 *counts
         radix_sort_pairs(ctx, rb, (u32)N, plan, /*gen_idx=*/true, /*hist_ready=*/false);
         spos = rb.vals;
     }
-    // k0 holds the segment records (K * IBWT_SEGCAP ~ 16 N bytes; in the scatter path it is not used for keys at all)
-    u8 *seg = reinterpret_cast<u8 *>(k0);
+    // k0 holds the segment records ((K + Kx) * IBWT_SEGCAP ~ 16.5 N bytes; in the scatter path it is not used for keys at all)
     // 2. splitter walks (recording the symbols passed), chain ranking, copy-out
-    tc_memset_async(ctx, ctx->d_scalars + 17, 0, sizeof(u64));
-    ibwt_walk1_kernel<<<tc_cdiv(K, 256), 256, 0, s>>>(spos, (u32)N, K, nx[0], ds[0], ct, seg, seglen, segflag,
-                                                     (u32)env_int("TC_IBWT_REWALK", 0),
-                                                     reinterpret_cast<u32 *>(ctx->d_scalars + 17), ovlist);
-    TC_LAUNCH_CHECK(ctx);
-    ibwt_terminal_kernel<<<1, 1, 0, s>>>(nx[0], ds[0], ctx->d_scalars);
-    TC_LAUNCH_CHECK(ctx);
-    int cur = 0;
-    for (int r = 0; r < ceil_log2_u64(K) + 1; r++) {
-        ibwt_jump_kernel<<<tc_cdiv(K, 256), 256, 0, s>>>(nx[cur], ds[cur], nx[cur ^ 1], ds[cur ^ 1], K);
-        TC_LAUNCH_CHECK(ctx);
-        cur ^= 1;
-    }
-    ibwt_len_kernel<<<1, 1, 0, s>>>(nx[cur], ds[cur], ctx->d_scalars, ctx->d_err);
-    TC_LAUNCH_CHECK(ctx);
-    ibwt_copy_kernel<<<tc_cdiv(K, 4), 256, 0, s>>>(K, nx[cur], ds[cur], ctx->d_scalars, seg, seglen, segflag,
-                                                  d_text, ctx->d_err);
-    TC_LAUNCH_CHECK(ctx);
-    tc_d2h(ctx, &ctx->h_scalars[6], ctx->d_scalars + 6, sizeof(u64));
-    tc_d2h(ctx, &ctx->h_scalars[17], ctx->d_scalars + 17, sizeof(u64));
-    TC_HIP(ctx, hipStreamSynchronize(s));
-    if ((u32)ctx->h_scalars[17]) {   // some segments did not fit their record buffer: walk them again
-        const u32 nov = (u32)ctx->h_scalars[17];
-        ibwt_walk2_kernel<<<tc_cdiv(nov, 256), 256, 0, s>>>(spos, (u32)N, K, nx[cur], ds[cur],
-                                                           ctx->d_scalars, ct, d_text, ovlist, nov, ctx->d_err);
-        TC_LAUNCH_CHECK(ctx);
-        TC_HIP(ctx, hipStreamSynchronize(s));
-    }
-    u64 Lc = ctx->h_scalars[6];
-    *n_out = Lc ? Lc - 1 : 0;
+    walk_rank_copy(
+        [&](u32 rewalk, u32 *nov_ctr, u32 *nextra, u32 xcap, u32 segcap) {
+            ibwt_walk1_kernel<<<tc_cdiv(K, 256), 256, 0, s>>>(spos, (u32)N, K, nx[0], ds[0], ct, seg, seglen, segflag,
+                                                             rewalk, nov_ctr, ovlist, nextra, xcap, segcap);
+        },
+        [&](const u32 *nxf, const u32 *dsf, u32 nov) {
+            ibwt_walk2_kernel<<<tc_cdiv(nov, 256), 256, 0, s>>>(spos, (u32)N, K, nxf, dsf, ctx->d_scalars, ct, d_text,
+                                                               ovlist, nov, ctx->d_err);
+        },
+        false);
     }   // (!CodeAcc)
 }
 
