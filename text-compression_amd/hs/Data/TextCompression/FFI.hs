@@ -37,3 +37,22 @@ foreign import ccall safe "tc_fm_build"
 foreign import ccall safe "tc_fm_count"
   c_tc_fm_count :: Ptr TcCtx -> Ptr TcFm -> Ptr Word8 -> Ptr Word64 -> Word64 -> Ptr Int64 -> IO Int32
 foreign import ccall safe "tc_fm_free" c_tc_fm_free :: Ptr TcFm -> IO ()
+foreign import ccall safe "tc_fm_locate"
+  c_tc_fm_locate :: Ptr TcCtx -> Ptr TcFm -> Ptr Word8 -> Ptr Word64 -> Word64 -> Ptr Word64 -> Ptr Word64 -> Ptr Word64 -> IO Int32
+-- stored / shipped form (no counterpart in the reference): one record, or any length cut into records
+foreign import ccall unsafe "tc_container_bound"
+  c_tc_container_bound :: Word64 -> Word32 -> Word64
+foreign import ccall safe "tc_encode_container"
+  c_tc_encode_container :: Ptr TcCtx -> Ptr Word8 -> Word64 -> Ptr Word8 -> Ptr Word64 -> IO Int32
+foreign import ccall safe "tc_container_info"
+  c_tc_container_info :: Ptr TcCtx -> Ptr Word8 -> Word64 -> Ptr Word64 -> Ptr Word64 -> IO Int32
+foreign import ccall safe "tc_decode_container"
+  c_tc_decode_container :: Ptr TcCtx -> Ptr Word8 -> Word64 -> Ptr Word8 -> Ptr Word64 -> IO Int32
+foreign import ccall unsafe "tc_stream_bound"
+  c_tc_stream_bound :: Word64 -> Word64 -> Word64
+foreign import ccall safe "tc_encode_stream"
+  c_tc_encode_stream :: Ptr TcCtx -> Ptr Word8 -> Word64 -> Word64 -> Ptr Word8 -> Ptr Word64 -> IO Int32
+foreign import ccall safe "tc_stream_info"
+  c_tc_stream_info :: Ptr TcCtx -> Ptr Word8 -> Word64 -> Ptr Word64 -> Ptr Word64 -> IO Int32
+foreign import ccall safe "tc_decode_stream"
+  c_tc_decode_stream :: Ptr TcCtx -> Ptr Word8 -> Word64 -> Ptr Word8 -> Ptr Word64 -> IO Int32
