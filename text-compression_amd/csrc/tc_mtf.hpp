@@ -256,7 +256,9 @@ __device__ __forceinline__ NibSumm nib_block_excl(NibSumm mine, NibSumm *s_w, Ni
 // at most one of the sigma codes is still unseen (its place is then forced: last).  On
 // high-entropy text that is one or two steps.  Returns false (every lane) if the window
 // of MTF_BACK_MAX positions did not settle it -- the caller then flags the slow path.
+#ifndef MTF_BACK_MAX
 #define MTF_BACK_MAX 8192
+#endif
 template <class Acc>
 __device__ __forceinline__ bool nib_list_before(Acc acc, u64 pos, u32 sigma, const u8 *s_lut, u64 *out) {
     u32 seen = 0;          // bit c set: code c already placed
