@@ -341,6 +341,10 @@ orc_fm *orc_fm_build(const uint8_t *t, int64_t n) {
             for (int32_t r = 0; r < f->sigma; r++) f->ckpt[r * nb + k / ORC_CK] = run[r];
         run[f->row_of[f->L[k] + 1]]++;
     }
+    /* Occ(c, N) is asked for (step 0 of a pattern ending in the largest symbol has e = N): when N is
+     * a multiple of the checkpoint distance the block of k = N starts AT N and needs its checkpoint too */
+    if (f->N % ORC_CK == 0)
+        for (int32_t r = 0; r < f->sigma; r++) f->ckpt[r * nb + f->N / ORC_CK] = run[r];
     return f;
 }
 

@@ -117,3 +117,17 @@ def test_generators_deterministic():
     assert O.gen_acgtn(0xC2, 2000)[:1000].tolist() == a.tolist()      # counter based
     b = O.gen_ascii(0xC1, 1000)
     assert b.min() >= 0x20 and b.max() <= 0x7e
+
+
+def test_fm_count_at_checkpoint_multiples():
+    """Occ(c, N) with N a multiple of the oracle's checkpoint distance (a pattern ending in the largest
+    symbol starts from e = N): found by scripts/fuzz_fm.py -- counts equal naive matching when every
+    pattern byte occurs in the text."""
+    rng = np.random.default_rng(64)
+    for n in (63, 127, 128, 191, 639, 640, 27967):
+        t = bytes(rng.choice(list(b"ioz\xcf"), n).astype(np.uint8))
+        fm = O.FMIndex(t)
+        for p in (b"\xcf", b"o\xcf", b"oo\xcf", b"z", b"iz", t[3:9], t[-4:], t[-1:]):
+            naive = sum(1 for i in range(n - len(p) + 1) if t.startswith(p, i))
+            assert fm.count(p) == (naive or None), (n, p)
+            assert sorted(fm.locate(p)) == [i + 1 for i in range(n - len(p) + 1) if t.startswith(p, i)], (n, p)
