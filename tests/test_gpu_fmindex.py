@@ -96,3 +96,34 @@ def test_config4_shape_small(ctx):
     assert [int(v) or None for v in got] == [ofm.count(p) for p in pats]
     assert int((got == 0).sum()) >= npat // 100 - 1
     fm.close()
+
+
+def test_fm_randomized_against_oracle_and_naive(ctx):
+    """Random texts (lengths around multiples of 64 included: the Occ checkpoints of both sides), random
+    patterns -- substrings, random strings, strings with a foreign byte, the empty pattern: count and
+    locate equal the oracle's; count equals naive matching whenever every pattern byte occurs."""
+    rng = np.random.default_rng(4242)
+    for it in range(40):
+        n = int(rng.choice([63, 64, 127, 128, 639, 4095])) + int(rng.integers(0, 2)) if it % 2 else int(rng.integers(1, 20000))
+        sigma = int(rng.integers(1, 8)) if it % 3 else int(rng.integers(8, 257))
+        alpha = rng.permutation(256)[:sigma]
+        t = alpha[rng.integers(0, sigma, n)].astype(np.uint8)
+        if n > 8:
+            ln = int(rng.integers(1, n // 2)); a0, b0 = int(rng.integers(0, n - ln)), int(rng.integers(0, n - ln))
+            t[b0:b0 + ln] = t[a0:a0 + ln].copy()
+        tb = t.tobytes()
+        pats = [tb[-1:], tb[:1], bytes([int(alpha.max())]), b""]
+        for _ in range(25):
+            m = int(rng.integers(1, 30)); a0 = int(rng.integers(0, n))
+            pats.append(tb[a0:a0 + m])
+            pats.append(alpha[rng.integers(0, sigma, m)].astype(np.uint8).tobytes())
+            p = bytearray(tb[a0:a0 + m]); p[int(rng.integers(0, len(p)))] = int(rng.integers(0, 256)); pats.append(bytes(p))
+        ofm = O.FMIndex(tb)
+        fm = ctx.fm_build(tb)
+        counts, hits = fm.count(pats), fm.locate(pats)
+        fm.close()
+        for p, c, h in zip(pats, counts, hits):
+            assert (None if c == 0 else int(c)) == ofm.count(p), (it, n, p)
+            assert sorted(int(v) for v in h) == sorted(ofm.locate(p)), (it, n, p)
+            if p and all(bytes([b]) in tb for b in p):
+                assert int(c) == sum(1 for i in range(n - len(p) + 1) if tb.startswith(p, i)), (it, n, p)
