@@ -3,11 +3,15 @@
 runs out), beside the device-resident tc_encode_dev."""
 import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-sys.path.insert(0, os.path.join(ROOT, "text-compression_amd")); sys.path.insert(0, os.path.join(ROOT, "tests"))
-import numpy as np, textcomp, oracle as O
+sys.path.insert(0, os.path.join(ROOT, "text-compression_amd"))
+import ctypes as C
+import numpy as np, torch, textcomp
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 1 << 30
 ctx = textcomp.Context(0)
-t = O.gen_acgtn(0xC3, n)
+d = torch.empty(n, dtype=torch.uint8, device="cuda")   # the record of the benchmark, generated on the device
+assert ctx.lib.tc_generate_dev(ctx.handle, 0, 0xC3, n, C.c_void_p(d.data_ptr())) == 0
+t = d.cpu().numpy()
+del d
 for it in range(3):
     t0 = time.perf_counter(); blk = ctx.encode(t); dt = time.perf_counter() - t0
     st = ctx.stats()

@@ -1,6 +1,6 @@
 """Quick GPU bring-up probe (not a test): runs a few encodes and prints mismatches."""
 import os, sys, time
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, os.path.join(ROOT, "text-compression_amd")); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import numpy as np
 import textcomp, oracle as O

@@ -2,7 +2,7 @@
 cannot run there: decode(encode) = text and the run lengths sum to N."""
 import os, sys
 import numpy as np
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, os.path.join(ROOT, "text-compression_amd")); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import oracle as O, textcomp
 ctx = textcomp.Context(0)
