@@ -121,7 +121,7 @@ def test_generators_deterministic():
 
 def test_fm_count_at_checkpoint_multiples():
     """Occ(c, N) with N a multiple of the oracle's checkpoint distance (a pattern ending in the largest
-    symbol starts from e = N): found by scripts/fuzz_fm.py -- counts equal naive matching when every
+    symbol starts from e = N): found by tests/long/fuzz_fm.py -- counts equal naive matching when every
     pattern byte occurs in the text."""
     rng = np.random.default_rng(64)
     for n in (63, 127, 128, 191, 639, 640, 27967):
