@@ -1,7 +1,11 @@
 #!/usr/bin/env python3
 """bench.py -- BWT+MTF+RLE encode throughput on synthetic ACGTN records.
 
-  python bench.py --gpus N --steps K --warmup W        (N > 1: launched by torchrun)
+  python bench.py --gpus N --steps K --warmup W
+
+With N > 1 and no WORLD_SIZE in the environment the command launches itself: the parent (which never
+touches the GPU) starts N fresh ranks through torch.distributed.run on 127.0.0.1, forwards rank 0's
+JSON line and returns the children's exit code.  Under torchrun (WORLD_SIZE set) it is a rank.
 
 A "step" = one fused BWT -> MTF -> RLE encode (tc_encode_dev) of this rank's record,
 input and output resident in HBM; with N > 1 each rank owns one independent record
@@ -60,6 +64,36 @@ def radix_launch_bytes(st, n):
     return total / L
 
 
+def haskell_probe():
+    """north_star asks for the reference's Haskell path timed beside the GPU number (built per
+    text-compression.cabal:98).  That needs GHC on this host; look for it on PATH only (no exec, no
+    subprocess: this also runs in processes that have initialised the GPU)."""
+    import shutil
+    found = {t: shutil.which(t) for t in ("ghc", "cabal", "stack", "runghc")}
+    if found["ghc"]:
+        return "ghc found at %s but the reference sources are not on this host (nproc=%d): not measured" % (found["ghc"], os.cpu_count())
+    return "not measurable: ghc/cabal/stack absent on this host (nproc=%d); the reference sources do not travel either" % os.cpu_count()
+
+
+def self_launch(a):
+    """bare `python bench.py --gpus N` (the driver's form): start N ranks as CHILD processes.  Nothing
+    in this process has touched the GPU (no torch import yet), and it never execs."""
+    import socket
+    import subprocess
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", "4")
+    env["TC_BENCH_SELF_LAUNCHED"] = "1"
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(a.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    p = subprocess.run(cmd, env=env)
+    sys.exit(p.returncode)
+
+
 def cpu_baseline(n_sample, seed):
     """The CPU restatement (oracle/, kind "port", 1 thread) on a bounded sample of the workload."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
@@ -71,12 +105,15 @@ def cpu_baseline(n_sample, seed):
     O.rle_encode_u32_arr(idx)
     dt = time.perf_counter() - t0
     return {"value": round(n_sample / dt / 1e6, 3), "unit": "MB/s", "cores": 1, "kind": "port",
+            "reference_haskell": haskell_probe(),
             "sample": "first %d MiB of the rank-0 record, BWT+MTF+RLE encode by oracle/tc_oracle.c, %.1f s"
                       % (n_sample >> 20, dt)}
 
 
 def main():
     a = parse()
+    if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        self_launch(a)
     import torch
     import torch.distributed as dist
     import textcomp
@@ -86,8 +123,7 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if world != a.gpus:
-        if world == 1 and a.gpus > 1:
-            sys.exit("bench.py --gpus %d must be launched with torch.distributed.run (one rank per GPU)" % a.gpus)
+        sys.exit("bench.py --gpus %d started with WORLD_SIZE=%d" % (a.gpus, world))
     # TC_BENCH_REHEARSAL=1: every rank computes on cuda:0 and the exchange runs over gloo with
     # host staging -- a one-GPU rehearsal of the N > 1 control flow (never a measurement)
     rehearsal = os.environ.get("TC_BENCH_REHEARSAL") == "1"
@@ -101,6 +137,8 @@ def main():
         else:
             dist.init_process_group("nccl", device_id=dev)
     xdev = torch.device("cpu") if rehearsal else dev   # where the exchanged payload lives
+    if os.environ.get("TC_BENCH_FAIL_RANK") == str(rank):   # test hook: a rank that dies (exit-code propagation)
+        sys.exit(3)
 
     n = a.n
     cap = n + 2
@@ -126,7 +164,6 @@ def main():
         gatherer.prime()                  # communicator / peer connection set-up, not part of any step
         packed = [torch.empty(pcap, dtype=torch.uint8, device=dev) for _ in range(2)]
     blk = Block()
-    step_no = [0]
 
     def step():
         blk.nruns = cap
@@ -136,8 +173,7 @@ def main():
         if rc != 0:
             raise RuntimeError("tc_encode_dev rc=%d: %s" % (rc, lib.tc_last_error(ctx.handle).decode()))
         if gatherer is not None:
-            buf = packed[step_no[0] % 2]
-            step_no[0] += 1
+            buf = packed[gatherer.acquire()]   # the send of the record that last used this buffer has completed
             nb = C.c_uint64(pcap)       # the block as one self-describing container (header + packed runs)
             rc = lib.tc_block_to_container_dev(ctx.handle, C.byref(blk), C.c_void_p(buf.data_ptr()), C.byref(nb))
             if rc != 0:
@@ -165,15 +201,33 @@ def main():
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
 
-    if rank == 0 and rehearsal and gatherer is not None:
+    gathered = None
+    if rank == 0 and gatherer is not None:
+        # outside the timed region: EVERY container gathered for the last record is read back on rank 0 --
+        # header, checksum, unpack, full decode -- and compared with the record its rank encoded
+        # (regenerated here from the rank's seed): what arrived over RCCL is the right block of bytes.
         last = gatherer.completed[-1]
         assert len(last) == world and all(int(h[0]) == len(p) for h, p in last), "gather shape"
-        for h, p in last:          # every gathered container decodes to a record of the right size
-            got_n, got_runs = C.c_uint64(), C.c_uint64()
-            hb = bytes(p[:640].numpy().tobytes())
-            assert lib.tc_container_info(ctx.handle, hb, len(hb), C.byref(got_n), C.byref(got_runs)) == 0
-            assert got_n.value == n and got_runs.value == int(h[1])
-        print("rehearsal: gathered", [(int(h[0]), int(h[1])) for h, _ in last], file=sys.stderr)
+        d_chk = torch.empty(n, dtype=torch.uint8, device=dev)
+        d_back = torch.empty(n, dtype=torch.uint8, device=dev)
+        vb = Block()
+        for r, (h, p) in enumerate(last):
+            pd = p.to(dev) if p.device != dev else p
+            if pd.data_ptr() % 16:
+                pd = pd.clone()
+            vb.nruns = cap
+            vb.run_count = d_cnt.data_ptr()
+            vb.run_value = d_val.data_ptr()
+            rc = lib.tc_container_to_block_dev(ctx.handle, C.c_void_p(pd.data_ptr()), int(h[0]), C.byref(vb))
+            assert rc == 0, "gathered container of rank %d: rc=%d %s" % (r, rc, lib.tc_last_error(ctx.handle).decode())
+            assert int(vb.n) == n and int(vb.nruns) == int(h[1]) and int(vb.primary) == int(h[3]), "header of rank %d" % r
+            assert lib.tc_decode_dev(ctx.handle, C.byref(vb), C.c_void_p(d_back.data_ptr())) == 0
+            assert lib.tc_generate_dev(ctx.handle, 0, 0xC500 + r, n, C.c_void_p(d_chk.data_ptr())) == 0
+            torch.cuda.synchronize()
+            assert torch.equal(d_back, d_chk), "record of rank %d does not decode to its text" % r
+        gathered = {"ranks_in_communicator": dist.get_world_size(), "backend": dist.get_backend(),
+                    "containers_verified": world, "container_bytes": [int(h[0]) for h, _ in last]}
+        del d_chk, d_back
     if rank == 0:
         st = ctx.stats()
         total_bytes = n * world * a.steps
@@ -206,6 +260,7 @@ def main():
                                    "in/out resident in HBM%s" % (world, n, ", + RCCL gather of the encoded-block containers on rank 0 (pipelined)" if world > 1 else ""),
                        "record_bytes": n, "records": world, "parallelism": "record-per-gpu x%d" % world},
             "roofline": roof,
+            "gather": gathered,
             "stages_ms": {"suffix_sort+bwt": round(st.ms_sa, 3), "mtf": round(st.ms_mtf, 3), "rle": round(st.ms_rle, 3),
                           "rounds": int(st.rounds), "m": [int(st.m[i]) for i in range(st.rounds)],
                           "passes": [int(st.passes[i]) for i in range(st.rounds)], "runs": int(st.runs)},

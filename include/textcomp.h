@@ -75,6 +75,10 @@ typedef struct tc_stats {
     uint32_t sample_dups;            /* of 8192 sampled suffixes, how many repeated another sample's
                                         globally sorted prefix (> 10 %: full path without trying the
                                         finish pass) */
+    uint32_t msd_path;               /* 1: round 0 ran as the MSD partition levels + bucket finish (tc_msd.hpp:
+                                        long texts over a small alphabet); radix_launches / ms_radix then time
+                                        msd_partition_kernel (first launch reads the text: 1 + 12 B per suffix,
+                                        the others 12 + 12 B) */
 } tc_stats;
 
 /* The encoded block of the fused BWT -> MTF -> RLE pipeline.  The reference has

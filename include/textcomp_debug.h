@@ -9,6 +9,10 @@
 #ifdef __cplusplus
 extern "C" {
 #endif
+/* The container's position-dependent 64-bit checksum (checksum64_kernel) of any device range
+ * (4-byte aligned, length a multiple of 4): lets a test compare full-size device outputs with
+ * a digest computed once by the CPU oracle (tests/golden/c3_digest.json). */
+int tc_dbg_checksum64_dev(tc_ctx *ctx, const void *d_p, uint64_t bytes, uint64_t *out);
 /* Streams `bytes` from one workspace buffer to another `iters` times and returns the
  * mean copy rate in GB/s (read + write bytes / time).  width: bytes per lane per access
  * (1, 2, 4, 8, 16).  mode 0: copy, 1: read-only (sum), 2: write-only (fill). */

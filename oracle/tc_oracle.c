@@ -394,6 +394,14 @@ int64_t orc_fm_count(const orc_fm *f, const uint8_t *pat, int64_t m) {
     return e - s + 1; /* :370-371 */
 }
 
+/* bytestringFMIndexCountS / ...CountP (FMIndex.hs:362-379,411-432): countFMIndex mapped over the
+ * pattern list, result order = pattern order; 0 stands for Nothing.  Reads the index only, so
+ * callers may run slices of one batch on several threads (what parListChunk does, :417-423). */
+void orc_fm_count_batch(const orc_fm *f, const uint8_t *pats, const int64_t *offs, int64_t npat,
+                        int64_t *out) {
+    for (int64_t j = 0; j < npat; j++) out[j] = orc_fm_count(f, pats + offs[j], offs[j + 1] - offs[j]);
+}
+
 int64_t orc_fm_locate(const orc_fm *f, const uint8_t *pat, int64_t m, int64_t *out, int64_t cap) {
     int64_t s, e;
     if (!fm_range(f, pat, m, &s, &e)) return 0;

@@ -97,6 +97,9 @@ typedef struct orc_fm orc_fm;
 orc_fm *orc_fm_build(const uint8_t *t, int64_t n);
 void orc_fm_free(orc_fm *f);
 int64_t orc_fm_count(const orc_fm *f, const uint8_t *pat, int64_t m);
+/* the same over a batch (offs[npat + 1] into pats); thread-safe on a built index */
+void orc_fm_count_batch(const orc_fm *f, const uint8_t *pats, const int64_t *offs, int64_t npat,
+                        int64_t *out);
 /* locateFMIndex (:448-542) + FMIndex.hs:496: 1-based text positions in SA order.
  * Returns number of hits written (<= cap). */
 int64_t orc_fm_locate(const orc_fm *f, const uint8_t *pat, int64_t m, int64_t *out, int64_t cap);

@@ -48,6 +48,7 @@ def lib():
         L.orc_fm_build.argtypes = [p, i64]; L.orc_fm_build.restype = p
         L.orc_fm_free.argtypes = [p]
         L.orc_fm_count.argtypes = [p, p, i64]; L.orc_fm_count.restype = i64
+        L.orc_fm_count_batch.argtypes = [p, p, p, i64, p]; L.orc_fm_count_batch.restype = None
         L.orc_fm_locate.argtypes = [p, p, i64, p, i64]; L.orc_fm_locate.restype = i64
         L.orc_gen_acgtn.argtypes = [C.c_uint64, i64, p]
         L.orc_gen_ascii.argtypes = [C.c_uint64, i64, p]
@@ -250,6 +251,31 @@ class FMIndex:
         p = _u8(pat)
         r = lib().orc_fm_count(self._h, _p(p) if len(p) else None, len(p))
         return None if r == 0 else int(r)
+
+    def count_batch(self, flat, offs, threads=1):
+        """countFMIndex over a batch (flat u8 bytes, int64 offs[npat + 1]) -> int64[npat], 0 = Nothing;
+        threads > 1: contiguous slices on that many threads (the reference's parListChunk,
+        FMIndex.hs:417-423; ctypes releases the GIL during the call)."""
+        flat = np.ascontiguousarray(flat, dtype=np.uint8)
+        offs = np.ascontiguousarray(offs, dtype=np.int64)
+        npat = len(offs) - 1
+        out = np.zeros(npat, dtype=np.int64)
+        if threads <= 1:
+            lib().orc_fm_count_batch(self._h, _p(flat), _p(offs), npat, _p(out))
+            return out
+        import threading
+        per = (npat + threads - 1) // threads
+        ths = []
+        for t in range(threads):
+            lo, hi = min(t * per, npat), min((t + 1) * per, npat)
+            if hi > lo:
+                ths.append(threading.Thread(target=lib().orc_fm_count_batch, args=(
+                    self._h, _p(flat), C.c_void_p(offs.ctypes.data + 8 * lo), hi - lo, C.c_void_p(out.ctypes.data + 8 * lo))))
+        for th in ths:
+            th.start()
+        for th in ths:
+            th.join()
+        return out
 
     def locate(self, pat):
         p = _u8(pat)

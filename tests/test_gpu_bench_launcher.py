@@ -1,0 +1,55 @@
+"""The driver starts the multi-GPU bench as the BARE command `python bench.py --gpus N ...`
+(no torchrun around it).  bench.py must then start its N ranks itself -- as child processes of a
+parent that never touched the GPU -- forward rank 0's single JSON line and return the ranks' exit
+code.  On the one-GPU box the ranks share cuda:0 and the exchange runs over gloo
+(TC_BENCH_REHEARSAL=1: control flow only, never a measurement); the 8-GPU RCCL run is the driver's.
+SURVEY.md 8(e); the only parallelism this replaces is FMIndex.hs:417-423."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _run(args, extra_env, timeout=600):
+    env = dict(os.environ)
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    env.update(extra_env)
+    return subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + args, env=env, cwd=ROOT,
+                          stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=timeout)
+
+
+@pytest.mark.gpu
+def test_bare_command_launches_two_ranks():
+    p = _run(["--gpus", "2", "--steps", "3", "--warmup", "1", "--n", str(1 << 24)], {"TC_BENCH_REHEARSAL": "1"})
+    assert p.returncode == 0, p.stderr[-4000:]
+    lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, p.stdout
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["steps"] == 3 and out["scaling"] == "weak"
+    g = out["gather"]
+    assert g["ranks_in_communicator"] == 2 and g["containers_verified"] == 2 and len(g["container_bytes"]) == 2
+    assert out["value"] > 0 and out["config"]["records"] == 2
+
+
+@pytest.mark.gpu
+def test_rank_failure_propagates():
+    """a rank that dies must turn into a non-zero exit code of the bare command"""
+    p = _run(["--gpus", "2", "--steps", "1", "--warmup", "0", "--n", str(1 << 20)],
+             {"TC_BENCH_REHEARSAL": "1", "TC_BENCH_FAIL_RANK": "1"})
+    assert p.returncode != 0
+    assert not [l for l in p.stdout.splitlines() if l.startswith("{")]
+
+
+def test_parent_does_not_touch_gpu_or_torch():
+    """the launching parent imports neither torch nor the library before it spawns the ranks"""
+    src = open(os.path.join(ROOT, "bench.py")).read()
+    head = src[:src.index("def main()")]
+    assert "import torch" not in head.replace("torch.distributed.run", "")
+    body = src[src.index("def main()"):]
+    assert body.index("self_launch(a)") < body.index("import torch")
+    assert "os.exec" not in src

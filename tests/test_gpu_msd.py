@@ -1,0 +1,85 @@
+"""Round 0 of the suffix sort as MSD partition levels + bucket finish (csrc/tc_msd.hpp): the path the
+1 GiB ACGTN benchmark record takes, forced here at sizes the oracle sorts in seconds
+(TC_SA_MSD_MIN_LOG2 lowers the length from which it is chosen).  Whatever the path, the result is
+the reference's order of the n+1 suffixes (createSuffixArray, BWT/Internal.hs:110-134) -- bit-exact
+against the oracle; `tc_stats.msd_path` tells which way round 0 went."""
+import numpy as np
+import pytest
+
+import oracle as O
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    import textcomp
+    c = textcomp.Context(0)
+    yield c
+    c.close()
+
+
+def _check(ctx, t, expect_msd):
+    t = np.ascontiguousarray(t, dtype=np.uint8)
+    sa = ctx.suffix_array(t)
+    st = ctx.stats()
+    assert st.msd_path == (1 if expect_msd else 0), (st.msd_path, st.finish_pass, st.rounds)
+    want = O.suffix_array(t)
+    assert np.array_equal(sa.astype(np.int64), want.astype(np.int64))
+    blk = ctx.encode(t)
+    L = O.bwt_encode_arr(t)
+    idx, fl = O.mtf_encode_arr(L)
+    counts, vals = O.rle_encode_u32_arr(idx)
+    assert blk["primary"] == int(np.nonzero(L < 0)[0][0])
+    assert blk["final_list"].tolist() == fl.tolist()
+    assert np.array_equal(blk["run_count"], counts) and np.array_equal(blk["run_value"], vals)
+    assert ctx.decode(blk) == t.tobytes()
+
+
+@pytest.mark.parametrize("n", [16385, 20000, 100003, (1 << 20) - 1, (1 << 22) + 5])
+def test_msd_iid_acgtn(ctx, n, monkeypatch):
+    monkeypatch.setenv("TC_SA_MSD_MIN_LOG2", "10")
+    _check(ctx, O.gen_acgtn(0xC2 + n, n), True)
+
+
+@pytest.mark.parametrize("sigma", [2, 3, 4, 7, 15])
+def test_msd_other_small_alphabets(ctx, sigma, monkeypatch):
+    """fields of 8 / 5 / 3 / 2 / 2 symbols (base sigma + 1 in 8 bits)"""
+    monkeypatch.setenv("TC_SA_MSD_MIN_LOG2", "10")
+    rng = np.random.default_rng(sigma)
+    alpha = rng.permutation(256)[:sigma]
+    _check(ctx, alpha[rng.integers(0, sigma, 300000)], True)
+
+
+def test_msd_with_ties_beyond_the_key(ctx, monkeypatch):
+    """copied stretches longer than the 21 key symbols: members equal on all key bits leave the
+    bucket finish as tied groups and are ordered by the doubling rounds"""
+    monkeypatch.setenv("TC_SA_MSD_MIN_LOG2", "10")
+    rng = np.random.default_rng(5)
+    t = O.gen_acgtn(77, 400000).copy()
+    for _ in range(200):
+        ln = int(rng.integers(22, 400))
+        a, b = int(rng.integers(0, len(t) - ln)), int(rng.integers(0, len(t) - ln))
+        t[b:b + ln] = t[a:a + ln].copy()
+    _check(ctx, t, True)
+    assert ctx.stats().rounds >= 2
+
+
+def test_msd_gives_way_to_lsd_on_long_buckets(ctx, monkeypatch):
+    """a poly-A tract of 5000 symbols: one level-3 bucket beyond MSDF_CAP -> the LSD way, same result"""
+    monkeypatch.setenv("TC_SA_MSD_MIN_LOG2", "10")
+    t = O.gen_acgtn(78, 300000).copy()
+    t[1000:6000] = ord("A")
+    _check(ctx, t, False)
+
+
+def test_msd_16m_equals_digest_record(ctx, monkeypatch):
+    """BASELINE configs[1] (16 MiB ACGTN) through the MSD way"""
+    monkeypatch.setenv("TC_SA_MSD_MIN_LOG2", "10")
+    _check(ctx, O.gen_acgtn(0xC2, 1 << 24), True)
+
+
+def test_default_threshold_keeps_small_records_on_lsd(ctx):
+    t = O.gen_acgtn(3, 1 << 20)
+    ctx.suffix_array(t)
+    assert ctx.stats().msd_path == 0

@@ -10,6 +10,7 @@
 #include "tc_radix_host.hpp"
 #include "tc_rle.hpp"
 #include "tc_sa.hpp"
+#include "tc_msd.hpp"
 
 // ---------------------------------------------------------------- small helpers
 static inline void tc_memset_async(tc_ctx *ctx, void *p, int v, size_t bytes) {
@@ -73,7 +74,15 @@ struct SaBuffers {
     u64 *rstatus;
     u64 *gstatus;  // 2*tiles + 2
     u32 *counts;   // 256 byte counts
+    // MSD round 0 (tc_msd.hpp), carved only for texts long enough to take it
+    u32 *msd_pstart[MSD_LEVELS + 1], *msd_pcnt[MSD_LEVELS + 1];   // [l]: parents of level l + 1; [3]: level-3 buckets
+    u32 *msd_tpre[MSD_LEVELS], *msd_seg[MSD_LEVELS];
+    u32 msd_grid;
 };
+
+// the MSD round 0 pays from this many suffixes on (level-3 buckets of >= ~64 members on DNA)
+static inline u64 msd_min_n() { return (u64)env_int("TC_SA_MSD_MIN_LOG2", 27) >= 40 ? ~0ull : 1ull << env_int("TC_SA_MSD_MIN_LOG2", 27); }
+static inline bool msd_wanted(u64 N) { return env_int("TC_SA_MSD", 1) != 0 && N >= msd_min_n() && N > 4 * MSD_TILE; }
 
 static size_t sa_carve(Arena &A, u64 N, SaBuffers &b, bool own_v1) {
     b.k0 = A.get<u64>(N);
@@ -100,6 +109,19 @@ static size_t sa_carve(Arena &A, u64 N, SaBuffers &b, bool own_v1) {
     b.rstatus = A.get<u64>(radix_status_words(N));
     b.gstatus = A.get<u64>(2 * (size_t)tc_cdiv(N, GRP_TILE) + 4);
     b.counts = A.get<u32>(260);
+    for (int l = 0; l <= MSD_LEVELS; l++) b.msd_pstart[l] = b.msd_pcnt[l] = nullptr;
+    if (msd_wanted(N)) {
+        b.msd_grid = 256;   // fixed for the carve; the launch uses min(this, CUs)
+        size_t np = 1;
+        for (int l = 0; l <= MSD_LEVELS; l++, np *= 256) {
+            b.msd_pstart[l] = A.get<u32>(np);
+            b.msd_pcnt[l] = A.get<u32>(np);
+            if (l < MSD_LEVELS) {
+                b.msd_tpre[l] = A.get<u32>(np + 1);
+                b.msd_seg[l] = A.get<u32>((np + b.msd_grid) * 256);
+            }
+        }
+    }
     return A.off;
 }
 
@@ -337,14 +359,22 @@ static void sa_run(tc_ctx *ctx, SaBuffers &b, const u8 *d_text, u64 n, u32 *d_sa
                     h_start = cfg.h0;
                 }
             }
-            RadixPlan plan;
-            plan.add_range(64 - topbits, 64);
-            RadixBuffers rb;
-            build_keys_and_sort(plan, rb, /*sa_in_alt_at_end=*/true);
+            // Round 0, two ways.  MSD (tc_msd.hpp; long texts over a small alphabet): three partition
+            // levels by field 0, 1, 2 with whole-line stores, then every level-3 bucket ordered in LDS.
+            // LSD (tc_radix.hpp): the top fields by stable passes, then finish_kernel.  Both hand over
+            // SA / last column for the untied suffixes and the tied set in act[1] (64 regions).  A text
+            // whose level-3 buckets are too long for the MSD finish falls through to the LSD way.
             u32 *counters = reinterpret_cast<u32 *>(ctx->d_scalars + 12);
+            const bool try_msd = cfg.w == 8 && cfg.P == 7 && b.msd_pstart[0] != nullptr && msd_wanted(N) &&
+                                 env_int("TC_SA_FIELDS", 0) == 0;
+            for (int way = try_msd ? 0 : 1; way < 2 && !have_groups; way++) {
+            const bool msd = way == 0;
+            const int tb = msd ? 8 * MSD_LEVELS : topbits;   // key bits that are globally ordered
+            RadixPlan plan;
+            RadixBuffers rb;
             FinishArgs fa;
-            fa.keys = rb.keys; fa.sa_in = rb.vals; fa.N = (u32)N; fa.tshift = 64 - topbits;
-            fa.lshift = 64 - keybits; fa.lbits = keybits - topbits;
+            fa.N = (u32)N; fa.tshift = 64 - tb;
+            fa.lshift = 64 - keybits; fa.lbits = keybits - tb;
             fa.sa_out = va; fa.L = d_L;
             // the lean pass appends to 64 regions of the SECOND active set (one counter each); they are
             // then packed into the first one, which everything below works on
@@ -354,10 +384,74 @@ static void sa_run(tc_ctx *ctx, SaBuffers &b, const u8 *d_text, u64 n, u32 *d_sa
             fa.fix_cap = (u32)(b.sparse_cap - 1024);
             fa.ovbits = b.act[1][0];   // (after the packing) the second active set is unused again
             u32 *roff = b.fin_rc + FIN_REGIONS * FIN_RSTRIDE;
+            tc_memset_async(ctx, ctx->d_scalars + 12, 0, 2 * sizeof(u64));
             tc_memset_async(ctx, b.fin_rc, 0, (FIN_REGIONS * FIN_RSTRIDE + 128) * sizeof(u32));
+            int npass_stat = 0;
+            if (msd) {
+                RadixKeyGen kg;
+                kg.n_text = (u32)n; kg.B = cfg.B; kg.w = cfg.w; kg.s = cfg.s; kg.P = cfg.P;
+                memcpy(kg.lut, cfg.lut, sizeof kg.lut);
+                MsdTextDigit td;
+                td.text = d_text; td.n = (u32)n; td.B = cfg.B; td.s = cfg.s;
+                memcpy(td.lut, cfg.lut, sizeof td.lut);
+                u32 G = b.msd_grid < (u32)ctx->num_cus ? b.msd_grid : (u32)ctx->num_cus;
+                u32 *maxchild = reinterpret_cast<u32 *>(ctx->d_scalars + 15);
+                msd_root_kernel<<<1, 1, 0, s>>>(b.msd_pstart[0], b.msd_pcnt[0], (u32)N, maxchild);
+                TC_LAUNCH_CHECK(ctx);
+                // level 1 writes (k0, v0); level 2 (k1, va); level 3 (k0, v0); the finish reads (k0, v0)
+                // and writes va / L
+                u64 *kbuf[2] = {b.k0, b.k1};
+                u32 *vbuf[2] = {b.v0, va};
+                ctx->pev_used = 0;
+                st.keygen_fused = 1;
+                u32 np = 1;
+                for (int l = 0; l < MSD_LEVELS; l++, np *= 256) {
+                    MsdLevel ML;
+                    ML.pstart = b.msd_pstart[l]; ML.pcnt = b.msd_pcnt[l]; ML.tpre = b.msd_tpre[l];
+                    ML.nparents = np; ML.shift = 56 - 8 * l; ML.seg = b.msd_seg[l];
+                    ML.cstart = b.msd_pstart[l + 1]; ML.ccnt = b.msd_pcnt[l + 1];
+                    const u64 *kin = l ? kbuf[(l - 1) & 1] : nullptr;
+                    const u32 *vin = l ? vbuf[(l - 1) & 1] : nullptr;
+                    msd_prep_kernel<<<1, 1024, 0, s>>>(ML.pcnt, np, b.msd_tpre[l]);
+                    TC_LAUNCH_CHECK(ctx);
+                    if (l == 0) msd_count_kernel<true><<<G, MSD_NT, 0, s>>>(ML, nullptr, td);
+                    else msd_count_kernel<false><<<G, MSD_NT, 0, s>>>(ML, kin, td);
+                    TC_LAUNCH_CHECK(ctx);
+                    msd_scan_kernel<<<np, 256, 0, s>>>(ML, G, l == MSD_LEVELS - 1 ? maxchild : nullptr);
+                    TC_LAUNCH_CHECK(ctx);
+                    const bool ev = ctx->profile && ctx->pev_used < 16;
+                    if (ev) TC_HIP(ctx, hipEventRecord(ctx->pev[2 * ctx->pev_used], s));
+                    if (l == 0) msd_partition_kernel<true><<<G, MSD_NT, 0, s>>>(ML, nullptr, nullptr, kbuf[0], vbuf[0], d_text, kg);
+                    else msd_partition_kernel<false><<<G, MSD_NT, 0, s>>>(ML, kin, vin, kbuf[l & 1], vbuf[l & 1], d_text, kg);
+                    TC_LAUNCH_CHECK(ctx);
+                    if (ev) {
+                        TC_HIP(ctx, hipEventRecord(ctx->pev[2 * ctx->pev_used + 1], s));
+                        ctx->pev_used++;
+                    }
+                }
+                rb.keys = kbuf[(MSD_LEVELS - 1) & 1];
+                rb.vals = vbuf[(MSD_LEVELS - 1) & 1];
+                MsdFinishArgs mf;
+                mf.keys = rb.keys; mf.vals = rb.vals;
+                mf.pcnt = b.msd_pcnt[MSD_LEVELS - 1];
+                mf.cstart = b.msd_pstart[MSD_LEVELS]; mf.ccnt = b.msd_pcnt[MSD_LEVELS];
+                mf.sa_out = va; mf.L = d_L;
+                mf.out_slot = fa.out_slot; mf.out_idx = fa.out_idx; mf.out_grp = fa.out_grp;
+                mf.rcount = fa.rcount; mf.rcap = fa.rcap; mf.counters = counters;
+                msd_finish_kernel<<<np / 256, MSDF_NT, 0, s>>>(mf);
+                TC_LAUNCH_CHECK(ctx);
+                npass_stat = MSD_LEVELS;
+                st.msd_path = 1;
+            } else {
+            st.msd_path = 0;
+            plan.add_range(64 - topbits, 64);
+            build_keys_and_sort(plan, rb, /*sa_in_alt_at_end=*/true);
+            npass_stat = plan.npass;
+            fa.keys = rb.keys; fa.sa_in = rb.vals;
             const u32 waves = tc_cdiv(N, 64 * FIN_WPW);
             finish_kernel<<<tc_cdiv(waves, FIN_NT / 64), FIN_NT, 0, s>>>(fa);
             TC_LAUNCH_CHECK(ctx);
+            }
             finish_regions_kernel<<<1, 64, 0, s>>>(fa.rcount, fa.rcap, roff, counters);
             TC_LAUNCH_CHECK(ctx);
             finish_compact_kernel<<<1024, 256, 0, s>>>(roff, fa.rcap, b.act[1][0], b.act[1][1], b.act[1][2],
@@ -367,8 +461,9 @@ static void sa_run(tc_ctx *ctx, SaBuffers &b, const u8 *d_text, u64 n, u32 *d_sa
             tc_d2h(ctx, &ctx->h_scalars[12], ctx->d_scalars + 12, sizeof(u64));
             TC_HIP(ctx, hipStreamSynchronize(s));
             u32 fm = (u32)(ctx->h_scalars[12] & 0xffffffffu), over = (u32)(ctx->h_scalars[12] >> 32);
+            if (msd && (over & 4u)) continue;   // a level-3 bucket beyond MSDF_CAP: the LSD way
             u32 slot_bits = (u32)rbits;
-            if ((over & 1u) && fm <= fa.fix_cap && env_int("TC_SA_TIER2", 1) != 0) {
+            if (!msd && (over & 1u) && fm <= fa.fix_cap && env_int("TC_SA_TIER2", 1) != 0) {
                 // some buckets are longer than a wave window: the second pass turns them into tied
                 // groups (the sorted keys are still in place) and voids what the first pass
                 // emitted for their members
@@ -392,17 +487,20 @@ static void sa_run(tc_ctx *ctx, SaBuffers &b, const u8 *d_text, u64 n, u32 *d_sa
                 fm_dropped = (u32)(ctx->h_scalars[13] & 0xffffffffu);
                 slot_bits = (u32)rbits + 1;   // the void slot value must sort behind slot N - 1
             }
+            // (MSD: rank lookups of untied suffixes count inside an UNSORTED level-3 bucket, ~550 keys
+            // each: fine for the few ties of an iid text, hopeless for millions -- the LSD way then)
+            if (msd && fm > (1u << 18)) continue;
             if (!(over & 1u) && fm <= b.sparse_cap - 1024) {
                 m = fm - fm_dropped;
                 // whole buckets were emitted as tied groups: they share only the globally sorted
                 // symbols, so the doubling starts from those
-                if (over & 2u) h_start = (u64)(topbits / (int)cfg.w) * cfg.s;
+                if (over & 2u) h_start = (u64)(tb / (int)cfg.w) * cfg.s;
                 have_groups = true;
                 tkeys = rb.keys;
-                tkeys_shift = 64 - topbits;
+                tkeys_shift = 64 - tb;
                 st.finish_pass = 1;
                 st.rounds = 1;
-                st.m[0] = N; st.key_bytes[0] = 8; st.passes[0] = (u32)plan.npass; st.h[0] = 0;
+                st.m[0] = N; st.key_bytes[0] = 8; st.passes[0] = (u32)npass_stat; st.h[0] = 0;
                 if (m > 0) {  // bring the tied set into SA order (refine relies on it); void entries go last
                     u32 mm = fm;
                     pack_active_kernel<<<tc_cdiv(mm, 256), 256, 0, s>>>(b.act[0][0], b.act[0][2], mm, b.sk[0]);
@@ -419,6 +517,7 @@ static void sa_run(tc_ctx *ctx, SaBuffers &b, const u8 *d_text, u64 n, u32 *d_sa
                     TC_HIP(ctx, hipMemcpyAsync(b.act[0][1], rs.vals, mm * sizeof(u32), hipMemcpyDeviceToDevice, s));
                 }
             }
+            }   // way
         }
     }
     if (!have_groups) {

@@ -1426,6 +1426,13 @@ int tc_fm_info(const tc_fm *fm, uint64_t *N, uint32_t *sigma, int16_t *c_sym, ui
 }
 
 
+int tc_dbg_checksum64_dev(tc_ctx *ctx, const void *d_p, uint64_t bytes, uint64_t *out) {
+    TC_API_BEGIN(ctx)
+    if (!out || (bytes && !d_p) || (bytes & 3) || ((uintptr_t)d_p & 3)) TC_FAIL(ctx, TC_ERR_ARG, "bad argument");
+    *out = checksum64_device(ctx, static_cast<const u8 *>(d_p), bytes);
+    TC_API_END(ctx)
+}
+
 int tc_dbg_stream_bench(tc_ctx *ctx, uint64_t bytes, int width, int mode, int iters, double *gbps) {
     TC_API_BEGIN(ctx)
     if (!gbps || bytes < 4096 || iters < 1 || mode < 0 || mode > 2) TC_FAIL(ctx, TC_ERR_ARG, "bad argument");

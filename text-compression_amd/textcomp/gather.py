@@ -58,17 +58,31 @@ class BlockGather:
             if len(self.completed) > 2 * self.depth:
                 self.completed.pop(0)
 
+    def acquire(self):
+        """Slot of the NEXT submit, with everything that was posted from it completed: the caller owns
+        `depth` payload buffers, writes record k into buffer acquire() and then submits it.  The send
+        of record k - depth (same buffer) has finished when this returns, so the buffer may be
+        overwritten; on rank 0 the result retained for that record aliases the buffer and is dropped
+        from `completed` by then (only the last `depth` results stay valid)."""
+        slot = self._step % self.depth
+        self._finish_slot(slot)
+        while len(self.completed) > self.depth - 1:
+            self.completed.pop(0)
+        return slot
+
     def submit(self, header, payload):
         """header: 6 ints (nbytes, nruns, nesc, primary, sigma, n); payload: uint8 tensor holding
-        at least header[0] bytes, which the caller must not overwrite before the next-but-one
-        submit (double buffering) or drain().  Returns immediately after posting."""
+        at least header[0] bytes -- the buffer of slot acquire(), which the caller must not touch
+        again before acquire() hands the slot back (or drain()).  Returns immediately after posting.
+        An oversize payload raises on EVERY rank (all of them see all headers), after the header
+        exchange, so no rank is left waiting in a collective."""
         slot = self._step % self.depth
         self._step += 1
         self._finish_slot(slot)
         nbytes = int(header[0])
-        if nbytes > self.cap:
-            raise ValueError("packed block of %d bytes exceeds the gather capacity %d" % (nbytes, self.cap))
         if self.world == 1:
+            if nbytes > self.cap:
+                raise ValueError("packed block of %d bytes exceeds the gather capacity %d" % (nbytes, self.cap))
             self.completed.append([(tuple(int(v) for v in header), payload[:nbytes])])
             if len(self.completed) > 2 * self.depth:
                 self.completed.pop(0)
@@ -77,14 +91,15 @@ class BlockGather:
         hdrs = torch.empty(self.world * HDR_WORDS, dtype=torch.int64, device=self.device)
         dist.all_gather_into_tensor(hdrs, hdr, group=self.hdr_group)
         ops, result = [], None
+        H = hdrs.view(self.world, HDR_WORDS).tolist()     # one host sync per record (46 ms steps: negligible)
+        over = [(r, int(H[r][0])) for r in range(self.world) if int(H[r][0]) > self.cap]
+        if over:
+            raise ValueError("packed block(s) exceed the gather capacity %d: (rank, bytes) = %s" % (self.cap, over))
         if self.rank == 0:
             self._alloc()
-            H = hdrs.view(self.world, HDR_WORDS).tolist()
             result = [(tuple(int(v) for v in H[0]), payload[:nbytes])]
             for r in range(1, self.world):
                 k = int(H[r][0])
-                if k > self.cap:
-                    raise ValueError("rank %d sends %d bytes, capacity %d" % (r, k, self.cap))
                 buf = self._recv[slot][r][:k]
                 result.append((tuple(int(v) for v in H[r]), buf))
                 if k:
