@@ -14,7 +14,7 @@ for f in glob.glob("gpurun_out/pmcsq_*/*/*counter_collection.csv"):
         k=r["Kernel_Name"][:44]
         agg[k][r["Counter_Name"]]+=float(r["Counter_Value"])
 for k,d in agg.items():
-    if any(x in k for x in ("radix_pass_kernel<false","finish_kernel","rle_encode","mtf_nib_apply")):
+    if any(x in k for x in ("radix_pass_kernel<false","finish_kernel","rle_encode","mtf_nib_apply","msd_")):
         print(k); 
         for c,v in sorted(d.items()): print("    %-24s %.4g"%(c,v))
 PY

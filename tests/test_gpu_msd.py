@@ -36,7 +36,7 @@ def _check(ctx, t, expect_msd):
     assert ctx.decode(blk) == t.tobytes()
 
 
-@pytest.mark.parametrize("n", [16385, 20000, 100003, (1 << 20) - 1, (1 << 22) + 5])
+@pytest.mark.parametrize("n", [32769, 50000, 100003, (1 << 20) - 1, (1 << 22) + 5])
 def test_msd_iid_acgtn(ctx, n, monkeypatch):
     monkeypatch.setenv("TC_SA_MSD_MIN_LOG2", "10")
     _check(ctx, O.gen_acgtn(0xC2 + n, n), True)
@@ -57,8 +57,8 @@ def test_msd_with_ties_beyond_the_key(ctx, monkeypatch):
     monkeypatch.setenv("TC_SA_MSD_MIN_LOG2", "10")
     rng = np.random.default_rng(5)
     t = O.gen_acgtn(77, 400000).copy()
-    for _ in range(200):
-        ln = int(rng.integers(22, 400))
+    for _ in range(40):
+        ln = int(rng.integers(22, 300))
         a, b = int(rng.integers(0, len(t) - ln)), int(rng.integers(0, len(t) - ln))
         t[b:b + ln] = t[a:a + ln].copy()
     _check(ctx, t, True)
@@ -66,11 +66,15 @@ def test_msd_with_ties_beyond_the_key(ctx, monkeypatch):
 
 
 def test_msd_gives_way_to_lsd_on_long_buckets(ctx, monkeypatch):
-    """a poly-A tract of 5000 symbols: one level-3 bucket beyond MSDF_CAP -> the LSD way, same result"""
+    """a poly-A tract of 20000 symbols: one level-3 bucket beyond MSDF_CAP -> the LSD way, same result;
+    a tract of 1500 stays on the MSD way (its bucket fits a chunk, its members leave as one tied group)"""
     monkeypatch.setenv("TC_SA_MSD_MIN_LOG2", "10")
     t = O.gen_acgtn(78, 300000).copy()
-    t[1000:6000] = ord("A")
+    t[1000:21000] = ord("A")
     _check(ctx, t, False)
+    t = O.gen_acgtn(79, 300000).copy()
+    t[1000:2500] = ord("A")
+    _check(ctx, t, True)
 
 
 def test_msd_16m_equals_digest_record(ctx, monkeypatch):

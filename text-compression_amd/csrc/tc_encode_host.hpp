@@ -331,6 +331,10 @@ static void sa_run(tc_ctx *ctx, SaBuffers &b, const u8 *d_text, u64 n, u32 *d_sa
         if (G < 1) G = 1;
         int forcedG = env_int("TC_SA_GLOBAL_PASSES", 0);
         if (forcedG > 0) G = forcedG;
+        // a candidate for the MSD way sorts by 7 fields: its LSD fallback then needs >= 3 global passes
+        const bool msd_cand = cfg.w == 8 && b.msd_pstart[0] != nullptr && msd_wanted(N) &&
+                              env_int("TC_SA_FIELDS", 0) == 0 && forcedG == 0;
+        if (msd_cand && G < MSD_LEVELS) G = MSD_LEVELS;
         int topbits = 8 * G < keybits ? 8 * G : keybits;
         // cheap look before the leap: if a sample of suffixes already collides heavily on the
         // globally sorted prefix, the tied set would exceed the sparse capacity anyway
@@ -365,8 +369,7 @@ static void sa_run(tc_ctx *ctx, SaBuffers &b, const u8 *d_text, u64 n, u32 *d_sa
             // SA / last column for the untied suffixes and the tied set in act[1] (64 regions).  A text
             // whose level-3 buckets are too long for the MSD finish falls through to the LSD way.
             u32 *counters = reinterpret_cast<u32 *>(ctx->d_scalars + 12);
-            const bool try_msd = cfg.w == 8 && cfg.P == 7 && b.msd_pstart[0] != nullptr && msd_wanted(N) &&
-                                 env_int("TC_SA_FIELDS", 0) == 0;
+            const bool try_msd = msd_cand && cfg.P == 7;
             for (int way = try_msd ? 0 : 1; way < 2 && !have_groups; way++) {
             const bool msd = way == 0;
             const int tb = msd ? 8 * MSD_LEVELS : topbits;   // key bits that are globally ordered

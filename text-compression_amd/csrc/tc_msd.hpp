@@ -25,13 +25,26 @@
 #include "tc_sa.hpp"
 
 #define MSD_NT 1024
-#define MSD_ITEMS 4
+#ifndef MSD_ITEMS
+#define MSD_ITEMS 8
+#endif
 #define MSD_TILE (MSD_NT * MSD_ITEMS)
-#define MSD_GROUP 32          // pairs per store group: 2 lines of keys, 1 line of values
+#ifndef MSD_GROUP
+#define MSD_GROUP 16          // pairs per store group: one 128-byte line of keys, half a line of values
+#endif
+#define MSD_GLOG (MSD_GROUP == 32 ? 5 : 4)
 #define MSD_LEVELS 3
+#ifndef MSDF_NT
 #define MSDF_NT 256
-#define MSDF_CAP 1024         // largest level-3 bucket the finish kernel orders
-#define MSDF_ITEMS (MSDF_CAP / 64)
+#endif
+#ifndef MSDF_ITEMS
+#define MSDF_ITEMS 8
+#endif
+#define MSDF_TILE (MSDF_NT * MSDF_ITEMS)   // pairs per chunk of the finish kernel
+#ifndef MSDF_CH
+#define MSDF_CH 4                          // level-3 buckets per chunk at most
+#endif
+#define MSDF_CAP MSDF_TILE                 // largest level-3 bucket the finish kernel orders
 
 // One partition level.  Parents are numbered by their digit path (level 1: one parent; level 2:
 // 256; level 3: 65536); an absent path is a parent with count 0.  Tiles never straddle parents.
@@ -86,7 +99,7 @@ __global__ __launch_bounds__(1024) void msd_prep_kernel(const u32 *__restrict__ 
 // The walk of a workgroup over its tiles is the same code in the counting and the partition kernel,
 // so both see the same segments.  Thread 0 advances it; the tile's description travels through LDS.
 __device__ __forceinline__ u32 msd_find_parent(const u32 *tpre, u32 nparents, u32 t) {
-    u32 lo = 0, hi = nparents;   // largest q with tpre[q] <= t  (then skip empties forward)
+    u32 lo = 0, hi = nparents;   // largest q with tpre[q] <= t
     while (hi - lo > 1) {
         const u32 mid = (lo + hi) >> 1;
         if (tpre[mid] <= t) lo = mid; else hi = mid;
@@ -96,21 +109,34 @@ __device__ __forceinline__ u32 msd_find_parent(const u32 *tpre, u32 nparents, u3
 
 struct MsdTileInfo {
     u32 base;     // first position of the tile in the input arrays
-    u32 valid;    // pairs in the tile
+    u32 valid;    // pairs in the tile (0: no such tile)
     u32 q;        // parent
     u32 last;     // 1: last tile of its segment (parent changes or range ends)
 };
-// info of tile t (parent hint q, advanced as needed); returns the parent found
-__device__ __forceinline__ u32 msd_tile_info(const MsdLevel &L, u32 t, u32 t_end, u32 q, MsdTileInfo *out) {
-    while (L.tpre[q + 1] <= t) q++;
-    const u32 rel = t - L.tpre[q];
-    const u32 cnt = L.pcnt[q];
-    const u32 off = rel * MSD_TILE;
-    out->base = L.pstart[q] + off;
-    out->valid = cnt - off < MSD_TILE ? cnt - off : MSD_TILE;
-    out->q = q;
-    out->last = (t + 1 >= t_end || L.tpre[q + 1] <= t + 1) ? 1u : 0u;
-    return q;
+// Thread 0's cursor: the parent of the tile last asked for stays in registers, so a tile's description
+// is arithmetic; the tables are read only when the walk enters another parent.
+struct MsdCur {
+    u32 q, tq0, tq1, ps, pc;
+};
+__device__ __forceinline__ void msd_cur_init(const MsdLevel &L, MsdCur &c, u32 t) {
+    c.q = msd_find_parent(L.tpre, L.nparents, t);
+    c.tq0 = L.tpre[c.q]; c.tq1 = L.tpre[c.q + 1]; c.ps = L.pstart[c.q]; c.pc = L.pcnt[c.q];
+}
+__device__ __forceinline__ void msd_cur_info(const MsdLevel &L, MsdCur &c, u32 t, u32 t_end, MsdTileInfo *out) {
+    if (t >= t_end) {
+        out->base = 0; out->valid = 0; out->q = 0; out->last = 0;
+        return;
+    }
+    if (t >= c.tq1) {
+        u32 q = c.q + 1;
+        while (L.tpre[q + 1] <= t) q++;
+        c.q = q; c.tq0 = L.tpre[q]; c.tq1 = L.tpre[q + 1]; c.ps = L.pstart[q]; c.pc = L.pcnt[q];
+    }
+    const u32 off = (t - c.tq0) * MSD_TILE;
+    out->base = c.ps + off;
+    out->valid = c.pc - off < MSD_TILE ? c.pc - off : MSD_TILE;
+    out->q = c.q;
+    out->last = (t + 1 >= t_end || t + 1 >= c.tq1) ? 1u : 0u;
 }
 
 // field 0 of suffix i straight from the text (level 1 only): the first s symbols in base B
@@ -124,70 +150,85 @@ struct MsdTextDigit {
 // ---- per-segment digit counts ------------------------------------------------------------------
 // keys: digit = (key >> shift) & 255.  TEXT (level 1): digit = field 0 of suffix i = its first s
 // symbols in base B, straight from the text (two overlapping word loads per 4 suffixes where the
-// tile lies inside the text; s <= 5 there, else bytes).
+// segment lies inside the text; s <= 5 there, else bytes).  A segment = the run of a workgroup's tiles
+// inside one parent = one contiguous range of positions: no per-tile synchronisation.
 template <bool TEXT>
 __global__ __launch_bounds__(MSD_NT) void msd_count_kernel(MsdLevel L, const u64 *__restrict__ keys,
                                                            MsdTextDigit td) {
     __shared__ u32 s_cnt[256];
     __shared__ u16 s_lut[TEXT ? 256 : 1];
-    __shared__ MsdTileInfo s_info;
+    __shared__ u32 s_seg[4];   // q, lo, hi, next tile
     const u32 tid = threadIdx.x, b = blockIdx.x, G = gridDim.x;
     if (tid < 256) s_cnt[tid] = 0;
     if (TEXT && tid < 256) s_lut[tid] = td.lut[tid];
     const u32 T = L.tpre[L.nparents];
     const u32 t0 = msd_tile_lo(T, b, G), t1 = msd_tile_lo(T, b + 1, G);
     if (t0 >= t1) return;
+    u32 t = t0;
     u32 q = 0;
     if (tid == 0) q = msd_find_parent(L.tpre, L.nparents, t0);
-    for (u32 t = t0; t < t1; t++) {
+    while (t < t1) {
+        if (tid == 0) {
+            while (L.tpre[q + 1] <= t) q++;
+            const u32 tq0 = L.tpre[q], tq1 = L.tpre[q + 1];
+            const u32 te = tq1 < t1 ? tq1 : t1;
+            const u32 ps = L.pstart[q], pc = L.pcnt[q];
+            const u32 lo = ps + (t - tq0) * MSD_TILE;
+            const u64 hi = (u64)ps + (u64)(te - tq0) * MSD_TILE;
+            s_seg[0] = q; s_seg[1] = lo; s_seg[2] = hi < (u64)ps + pc ? (u32)hi : ps + pc; s_seg[3] = te;
+        }
         __syncthreads();
-        if (tid == 0) q = msd_tile_info(L, t, t1, q, &s_info);
-        __syncthreads();
-        const MsdTileInfo ti = s_info;
+        const u32 sq = s_seg[0], lo = s_seg[1], hi = s_seg[2];
+        t = s_seg[3];
         if (TEXT) {
-            const bool words = td.s <= 5 && ti.valid == MSD_TILE && (u64)ti.base + MSD_TILE + 8 <= td.n &&
-                               ((((uintptr_t)td.text) + ti.base) & 3) == 0;
+            const bool words = td.s <= 5 && (u64)lo + 8 < td.n && ((((uintptr_t)td.text) + lo) & 15) == 0;
+            u32 p = lo;
             if (words) {
-                const u32 *tw = reinterpret_cast<const u32 *>(td.text + ti.base);
-                const u64 x = (u64)tw[tid] | ((u64)tw[tid + 1] << 32);   // bytes 4 tid .. 4 tid + 7
-                u32 cd[8];
+                // rounds of 16 positions per thread: one 16-byte load + the 4 bytes behind it
+                // (only rounds that end 8 bytes before the end of the text; the rest goes byte by byte)
+                const u32 span = (u64)hi + 8 <= td.n ? hi - lo : td.n - 8 - lo;
+                const u32 nfull = span / (16 * MSD_NT);
+                const u32 *tw = reinterpret_cast<const u32 *>(td.text + lo);
+                for (u32 r = 0; r < nfull; r++) {
+                    const u32 wi = (r * MSD_NT + tid) * 4;
+                    const u32 x[5] = {tw[wi], tw[wi + 1], tw[wi + 2], tw[wi + 3], tw[wi + 4]};
+                    u32 cd[20];
 #pragma unroll
-                for (int j = 0; j < 8; j++) cd[j] = s_lut[(u32)(x >> (8 * j)) & 255u];
+                    for (int j = 0; j < 20; j++) cd[j] = s_lut[(x[j >> 2] >> (8 * (j & 3))) & 255u];
 #pragma unroll
-                for (int k = 0; k < 4; k++) {
-                    u32 g = 0;
-#pragma unroll
-                    for (int j = 0; j < 5; j++)
-                        if (j < (int)td.s) g = g * td.B + cd[k + j];
-                    atomicAdd(&s_cnt[g], 1u);
-                }
-            } else {
-#pragma unroll
-                for (int k = 0; k < MSD_ITEMS; k++) {
-                    const u32 p = k * MSD_NT + tid;
-                    if (p < ti.valid) {
-                        u64 i = (u64)ti.base + p;
+                    for (int k = 0; k < 16; k++) {
                         u32 g = 0;
-                        for (u32 j = 0; j < td.s; j++, i++) g = g * td.B + (i < td.n ? (u32)s_lut[td.text[i]] : 0u);
+#pragma unroll
+                        for (int j = 0; j < 5; j++)
+                            if (j < (int)td.s) g = g * td.B + cd[k + j];
                         atomicAdd(&s_cnt[g], 1u);
                     }
                 }
+                p = lo + nfull * 16 * MSD_NT;
+            }
+            for (u64 i0 = (u64)p + tid; i0 < hi; i0 += MSD_NT) {
+                u64 i = i0;
+                u32 g = 0;
+                for (u32 j = 0; j < td.s; j++, i++) g = g * td.B + (i < td.n ? (u32)s_lut[td.text[i]] : 0u);
+                atomicAdd(&s_cnt[g], 1u);
             }
         } else {
-            const u64 *kt = keys + ti.base;
-#pragma unroll
-            for (int k = 0; k < MSD_ITEMS; k++) {
-                const u32 p = k * MSD_NT + tid;
-                if (p < ti.valid) atomicAdd(&s_cnt[(u32)(kt[p] >> L.shift) & 255u], 1u);
+            u32 p = lo + tid;
+            for (; p + 3 * MSD_NT < hi; p += 4 * MSD_NT) {
+                const u64 k0 = keys[p], k1 = keys[p + MSD_NT], k2 = keys[p + 2 * MSD_NT], k3 = keys[p + 3 * MSD_NT];
+                atomicAdd(&s_cnt[(u32)(k0 >> L.shift) & 255u], 1u);
+                atomicAdd(&s_cnt[(u32)(k1 >> L.shift) & 255u], 1u);
+                atomicAdd(&s_cnt[(u32)(k2 >> L.shift) & 255u], 1u);
+                atomicAdd(&s_cnt[(u32)(k3 >> L.shift) & 255u], 1u);
             }
+            for (; p < hi; p += MSD_NT) atomicAdd(&s_cnt[(u32)(keys[p] >> L.shift) & 255u], 1u);
         }
-        if (ti.last) {
-            __syncthreads();
-            if (tid < 256) {
-                L.seg[((size_t)ti.q + b) * 256 + tid] = s_cnt[tid];
-                s_cnt[tid] = 0;
-            }
+        __syncthreads();
+        if (tid < 256) {
+            L.seg[((size_t)sq + b) * 256 + tid] = s_cnt[tid];
+            s_cnt[tid] = 0;
         }
+        // (the next round's barrier orders this reset before the next atomics)
     }
 }
 
@@ -205,14 +246,18 @@ __global__ __launch_bounds__(256) void msd_scan_kernel(MsdLevel L, u32 G, u32 *m
     }
     const u32 T = L.tpre[L.nparents];
     const u32 bf = msd_block_of_tile(T, L.tpre[q], G), bl = msd_block_of_tile(T, L.tpre[q + 1] - 1, G);
+    // (workgroups between bf and bl whose tile range is empty -- fewer tiles than workgroups -- own no
+    // segment and wrote nothing)
     u32 tot = 0;
-    for (u32 b = bf; b <= bl; b++) tot += L.seg[((size_t)q + b) * 256 + d];
+    for (u32 b = bf; b <= bl; b++)
+        if (msd_tile_lo(T, b, G) < msd_tile_lo(T, b + 1, G)) tot += L.seg[((size_t)q + b) * 256 + d];
     u32 all;
     const u32 excl = block_excl_sum<256>(tot, s_scan, &all);
     u32 run = L.pstart[q] + excl;
     L.cstart[c] = run;
     L.ccnt[c] = tot;
     for (u32 b = bf; b <= bl; b++) {
+        if (msd_tile_lo(T, b, G) >= msd_tile_lo(T, b + 1, G)) continue;
         const size_t o = ((size_t)q + b) * 256 + d;
         const u32 v = L.seg[o];
         L.seg[o] = run;
@@ -232,11 +277,19 @@ __global__ __launch_bounds__(256) void msd_scan_kernel(MsdLevel L, u32 G, u32 *m
 // ---- one partition pass -------------------------------------------------------------------------
 // KEYGEN: level 1, keys are built from the text (layout of keybuild_kernel in tc_sa.hpp: P fields
 // of s symbols in base B, w = 8 bits each, from bit 63 down; low byte = the preceding text byte).
+//
+// Per tile (8192 pairs, 8 per thread): rank inside the digit by one LDS atomic per pair (any order will
+// do), the tile sorted by digit into the staging area, then for every digit the whole 16-pair groups of
+// (carry ++ the tile's segment) are stored -- 128 B of keys and 64 B of values, aligned -- and what is
+// left becomes the carry.  The loads of tile t + 1 are issued before tile t is ranked and land
+// while it is staged; they are consumed before tile t's stores are issued, so no wave ever waits for a
+// store.
+typedef u32 msd_u32x4 __attribute__((ext_vector_type(4)));
 template <bool KEYGEN>
-__global__ __launch_bounds__(MSD_NT) void msd_partition_kernel(MsdLevel L, const u64 *__restrict__ kin,
-                                                               const u32 *__restrict__ vin,
-                                                               u64 *__restrict__ kout, u32 *__restrict__ vout,
-                                                               const u8 *__restrict__ text, RadixKeyGen kg) {
+__global__ __launch_bounds__(MSD_NT) void msd_partition_kernel(MsdLevel L, const u64 *kin, const u32 *vin,
+                                                               u64 *kout, u32 *vout, const u8 *text,
+                                                               RadixKeyGen kg) {
+    // (no __restrict__ on purpose: loads that may alias the stores keep their place in program order)
     // staging of the tile sorted by digit; the key-generation image overlays it
     __shared__ __attribute__((aligned(16))) u64 s_keys[MSD_TILE];
     __shared__ __attribute__((aligned(16))) u32 s_vals[MSD_TILE];
@@ -244,25 +297,25 @@ __global__ __launch_bounds__(MSD_NT) void msd_partition_kernel(MsdLevel L, const
     // segment's first group are phantoms standing for the positions before the segment's range)
     __shared__ __attribute__((aligned(16))) u64 c_keys[256 * MSD_GROUP];
     __shared__ __attribute__((aligned(16))) u32 c_vals[256 * MSD_GROUP];
-    __shared__ u32 s_cnt[256], s_dstart[256], s_r[256], s_ng[256], s_goff[256], s_cur[256], s_ph[256];
-    __shared__ u16 s_gmap[512];
-    __shared__ u16 s_jmap[256];
+    __shared__ u32 s_cnt[256], s_dstart[256], s_r[256], s_cur[256], s_ph[256];
     __shared__ u32 s_scan[8];
-    __shared__ u32 s_tot[2];
     __shared__ u16 s_klut[KEYGEN ? 256 : 1];
-    __shared__ MsdTileInfo s_info[2];
+    static_assert(MSD_GROUP == 16 || MSD_GROUP == 32, "group = 16 or 32 pairs");
+    static_assert((size_t)MSD_TILE * 12 + 256 * MSD_GROUP * 12 + 8192 <= 163840, "LDS budget");
+    __shared__ MsdTileInfo s_info[4];
 
     const u32 tid = threadIdx.x, b = blockIdx.x, G = gridDim.x;
-    const u32 hw = tid >> 5, l5 = tid & 31;
     if (KEYGEN && tid < 256) s_klut[tid] = kg.lut[tid];
     if (tid < 256) { s_cnt[tid] = 0; s_r[tid] = 0; s_ph[tid] = 0; s_cur[tid] = 0; }
     const u32 T = L.tpre[L.nparents];
     const u32 t0 = msd_tile_lo(T, b, G), t1 = msd_tile_lo(T, b + 1, G);
     if (t0 >= t1) return;
-    u32 q = 0;
+    MsdCur cs = {};
     if (tid == 0) {
-        q = msd_find_parent(L.tpre, L.nparents, t0);
-        q = msd_tile_info(L, t0, t1, q, &s_info[0]);
+        msd_cur_init(L, cs, t0);
+        msd_cur_info(L, cs, t0, t1, &s_info[0]);
+        msd_cur_info(L, cs, t0 + 1, t1, &s_info[1]);
+        msd_cur_info(L, cs, t0 + 2, t1, &s_info[2]);
     }
     __syncthreads();
 
@@ -276,36 +329,80 @@ __global__ __launch_bounds__(MSD_NT) void msd_partition_kernel(MsdLevel L, const
 
     u64 key[MSD_ITEMS], nkey[MSD_ITEMS];
     u32 val[MSD_ITEMS], nval[MSD_ITEMS];
-    uint4 raw = make_uint4(0, 0, 0, 0), nraw = make_uint4(0, 0, 0, 0);
-    auto load_tile = [&](const MsdTileInfo &ti, u64 *kk, u32 *vv, uint4 &rw) {
-        if (KEYGEN) {
-            // 16 text bytes per thread from position base - KG_PRE + 16 * tid (bytes outside the text: 0)
-            if (tid < kg_units) {
-                const i64 p0 = (i64)ti.base - KG_PRE + (i64)tid * 16;
-                const i64 nt = (i64)kg.n_text;
-                if (p0 >= 0 && p0 + 16 <= nt && ((((uintptr_t)text) + (u64)p0) & 15) == 0) {
-                    rw = *reinterpret_cast<const uint4 *>(text + p0);
-                } else {
-                    u32 x[4] = {0, 0, 0, 0};
-                    for (int j = 0; j < 16; j++) {
-                        const i64 pp = p0 + j;
-                        const u32 c = (pp >= 0 && pp < nt) ? (u32)text[pp] : 0u;
-                        x[j >> 2] |= c << (8 * (j & 3));
-                    }
-                    rw = make_uint4(x[0], x[1], x[2], x[3]);
+    msd_u32x4 raw = {0, 0, 0, 0}, nraw = {0, 0, 0, 0}, nraw_edge = {0, 0, 0, 0};
+    // KEYGEN: 16 text bytes per thread from position base - KG_PRE + 16 * tid (bytes outside the text: 0).
+    // A tile is an "edge" tile when some unit reaches outside the text or the text is not 16-byte
+    // aligned (first / last tile only): those units are read byte by byte.
+    auto kg_edge = [&](const MsdTileInfo ti) {
+        return ti.base < (u32)KG_PRE || (u64)ti.base - KG_PRE + (u64)kg_units * 16 > (u64)kg.n_text ||
+               ((((uintptr_t)text) + ti.base) & 15) != 0;
+    };
+    auto kg_load_plain = [&](const MsdTileInfo ti) {   // ordinary loads (edge tiles, first tile)
+        msd_u32x4 rw = {0, 0, 0, 0};
+        if (tid < kg_units) {
+            const i64 p0 = (i64)ti.base - KG_PRE + (i64)tid * 16;
+            const i64 nt = (i64)kg.n_text;
+            if (p0 >= 0 && p0 + 16 <= nt && ((((uintptr_t)text) + (u64)p0) & 15) == 0) {
+                rw = *reinterpret_cast<const msd_u32x4 *>(text + p0);
+            } else {
+                u32 x[4] = {0, 0, 0, 0};
+#pragma unroll 1
+                for (int j = 0; j < 16; j++) {
+                    const i64 pp = p0 + j;
+                    const u32 c = (pp >= 0 && pp < nt) ? (u32)text[pp] : 0u;
+                    x[j >> 2] |= c << (8 * (j & 3));
                 }
+                rw.x = x[0]; rw.y = x[1]; rw.z = x[2]; rw.w = x[3];
             }
+        }
+        return rw;
+    };
+    // The prefetch of the next tile is issued by inline asm so that it stays where it is written (the
+    // compiler sinks ordinary loads to their first use, which serialises load latency and tile work).
+    // The compiler does not track these loads, so (i) they are unconditional -- every lane loads from a
+    // clamped, valid address; a register they fill is defined by the asm alone, never merged with
+    // another value before it has landed -- and (ii) every such register passes through land() before
+    // anything reads it.
+    auto prefetch = [&](const MsdTileInfo cur_ti, const MsdTileInfo nx) {
+        if (KEYGEN) {
+            const bool use = nx.valid != 0 && !kg_edge(nx);
+            const u32 base = use ? nx.base : (cur_ti.base >= (u32)KG_PRE && !kg_edge(cur_ti) ? cur_ti.base : 0u);
+            const u32 unit = tid < kg_units ? tid : kg_units - 1;
+            // (fallback address: the start of the text rounded up to 16 bytes -- any valid 16 bytes)
+            const u8 *src = use || base ? text + ((u64)base - KG_PRE + (u64)unit * 16)
+                                        : reinterpret_cast<const u8 *>((((uintptr_t)text) + 15) & ~(uintptr_t)15);
+            asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(nraw) : "v"(src) : "memory");
         } else {
-            const u64 *kt = kin + ti.base;
-            const u32 *vt = vin + ti.base;
+            const u32 nv = nx.valid ? nx.valid : cur_ti.valid;
+            const u32 nb = nx.valid ? nx.base : cur_ti.base;
+            const u64 *kt = kin + nb;
+            const u32 *vt = vin + nb;
 #pragma unroll
             for (int k = 0; k < MSD_ITEMS; k++) {
-                const u32 p = k * MSD_NT + tid;
-                if (p < ti.valid) {
-                    kk[k] = kt[p];
-                    vv[k] = vt[p];
-                }
+                u32 p = k * MSD_NT + tid;
+                p = p < nv ? p : nv - 1;
+                asm volatile("global_load_dwordx2 %0, %1, off" : "=v"(nkey[k]) : "v"(kt + p) : "memory");
+                asm volatile("global_load_dword %0, %1, off" : "=v"(nval[k]) : "v"(vt + p) : "memory");
             }
+        }
+    };
+    auto land = [&]() {
+        if (KEYGEN) {
+            asm volatile("s_waitcnt vmcnt(0)" : "+v"(nraw) : : "memory");
+        } else {
+            static_assert(MSD_ITEMS == 4 || MSD_ITEMS == 8, "land() lists the prefetch registers");
+            asm volatile("s_waitcnt vmcnt(0)"
+                         : "+v"(nkey[0]), "+v"(nkey[1]), "+v"(nkey[2]), "+v"(nkey[3]), "+v"(nval[0]), "+v"(nval[1]),
+                           "+v"(nval[2]), "+v"(nval[3])
+                         :
+                         : "memory");
+            if (MSD_ITEMS == 8)
+                asm volatile("s_waitcnt vmcnt(0)"
+                             : "+v"(nkey[MSD_ITEMS - 4]), "+v"(nkey[MSD_ITEMS - 3]), "+v"(nkey[MSD_ITEMS - 2]),
+                               "+v"(nkey[MSD_ITEMS - 1]), "+v"(nval[MSD_ITEMS - 4]), "+v"(nval[MSD_ITEMS - 3]),
+                               "+v"(nval[MSD_ITEMS - 2]), "+v"(nval[MSD_ITEMS - 1])
+                             :
+                             : "memory");
         }
     };
     auto seg_init = [&](u32 qq) {   // threads < 256
@@ -315,15 +412,29 @@ __global__ __launch_bounds__(MSD_NT) void msd_partition_kernel(MsdLevel L, const
         s_r[tid] = sb & (MSD_GROUP - 1);
     };
     if (tid < 256) seg_init(s_info[0].q);
-    load_tile(s_info[0], key, val, raw);
+    if (KEYGEN) {
+        raw = kg_load_plain(s_info[0]);
+    } else {
+        const MsdTileInfo f = s_info[0];
+#pragma unroll
+        for (int k = 0; k < MSD_ITEMS; k++) {
+            const u32 p = k * MSD_NT + tid;
+            if (p < f.valid) {
+                key[k] = kin[f.base + p];
+                val[k] = vin[f.base + p];
+            }
+        }
+    }
 
-    int cur = 0;
-    for (u32 t = t0; t < t1; t++, cur ^= 1) {
-        const MsdTileInfo ti = s_info[cur];
-        const bool more = t + 1 < t1;
-        if (tid == 0 && more) q = msd_tile_info(L, t + 1, t1, q, &s_info[cur ^ 1]);
-        __syncthreads();   // (B0) next tile's info visible; s_cnt zeroed; staging free
-        if (more) load_tile(s_info[cur ^ 1], nkey, nval, nraw);   // in flight while this tile is ranked
+    for (u32 t = t0; t < t1; t++) {
+        const u32 slot = (t - t0) & 3u;
+        const MsdTileInfo ti = s_info[slot];
+        if (tid == 0) msd_cur_info(L, cs, t + 3, t1, &s_info[(slot + 3) & 3u]);
+        __syncthreads();   // (B0) s_cnt zeroed; staging free; carries / ranges of this segment in place
+        const MsdTileInfo nx = s_info[(slot + 1) & 3u];
+        prefetch(ti, nx);   // tile t + 1: in flight while tile t is ranked and staged
+        const bool nx_edge = KEYGEN && nx.valid != 0 && kg_edge(nx);
+        if (nx_edge) nraw_edge = kg_load_plain(nx);
         if (KEYGEN) {
             const i64 nt = (i64)kg.n_text;
             if (tid < kg_units) {
@@ -345,15 +456,19 @@ __global__ __launch_bounds__(MSD_NT) void msd_partition_kernel(MsdLevel L, const
                 uint4 *dc = reinterpret_cast<uint4 *>(k_c + tid * 16);
                 dc[0] = make_uint4(cw[0], cw[1], cw[2], cw[3]);
                 dc[1] = make_uint4(cw[4], cw[5], cw[6], cw[7]);
-                *reinterpret_cast<uint4 *>(k_r + tid * 16) = raw;
+                *reinterpret_cast<uint4 *>(k_r + tid * 16) = make_uint4(raw.x, raw.y, raw.z, raw.w);
             }
             __syncthreads();
             const u32 gslots = KG_PRE + MSD_TILE + kg.P * kg.s;
             const u32 B = kg.B;
-            for (u32 x = tid; x < gslots; x += MSD_NT) {
-                u32 g = 0;
-                for (u32 j = 0; j < kg.s; j++) g = g * B + k_c[x + j];
-                k_g[x] = (u16)g;
+            if (kg.s == 3) {
+                for (u32 x = tid; x < gslots; x += MSD_NT) k_g[x] = (u16)((k_c[x] * B + k_c[x + 1]) * B + k_c[x + 2]);
+            } else {
+                for (u32 x = tid; x < gslots; x += MSD_NT) {
+                    u32 g = 0;
+                    for (u32 j = 0; j < kg.s; j++) g = g * B + k_c[x + j];
+                    k_g[x] = (u16)g;
+                }
             }
             __syncthreads();
 #pragma unroll
@@ -380,31 +495,18 @@ __global__ __launch_bounds__(MSD_NT) void msd_partition_kernel(MsdLevel L, const
             if (p < ti.valid) rnk[k] = atomicAdd(&s_cnt[dig[k]], 1u);
         }
         __syncthreads();   // (B1)
-        // (S2) per digit: start in the staging area, whole groups to store, carry jobs
+        // (S2) start of every digit's segment in the staging area
         if (tid < 256) {
-            const u32 c = s_cnt[tid], r = s_r[tid];
-            const u32 ng = (r + c) >> 5;
-            const u32 packed = c | (ng << 13) | ((c ? 1u : 0u) << 23);
-            const u32 inc = wave_incl_sum(packed);
+            const u32 c = s_cnt[tid];
+            const u32 inc = wave_incl_sum(c);
             if ((tid & 63) == 63) s_scan[tid >> 6] = inc;
-            s_dstart[tid] = inc - packed;   // wave-relative for now
-            s_ng[tid] = ng;
+            s_dstart[tid] = inc - c;   // wave-relative for now
         }
         __syncthreads();   // (B2a)
         if (tid < 256) {
             u32 base = 0;
             for (u32 i = 0; i < (tid >> 6); i++) base += s_scan[i];
-            const u32 ex = s_dstart[tid] + base;
-            const u32 ds = ex & 0x1fffu, go = (ex >> 13) & 0x3ffu, jo = ex >> 23;
-            s_dstart[tid] = ds;
-            s_goff[tid] = go;
-            const u32 ng = s_ng[tid];
-            for (u32 k = 0; k < ng; k++) s_gmap[go + k] = (u16)tid;
-            if (s_cnt[tid]) s_jmap[jo] = (u16)tid;
-            if (tid == 255) {
-                s_tot[0] = go + ng;
-                s_tot[1] = jo + (s_cnt[tid] ? 1u : 0u);
-            }
+            s_dstart[tid] += base;
         }
         __syncthreads();   // (B2)
         // (S3) the tile, sorted by digit, into the staging area
@@ -417,54 +519,60 @@ __global__ __launch_bounds__(MSD_NT) void msd_partition_kernel(MsdLevel L, const
                 s_vals[o] = val[k];
             }
         }
-        __syncthreads();   // (B3)
-        // (S4) whole groups leave: group k of digit d = elements [32k, 32k + 32) of (carry ++ segment)
-        {
-            const u32 Gt = s_tot[0];
-            for (u32 g = hw; g < Gt; g += MSD_NT / 32) {
-                const u32 d = s_gmap[g];
-                const u32 k = g - s_goff[d], r = s_r[d];
-                const u32 e = k * MSD_GROUP + l5;
-                u64 kk;
-                u32 vv;
-                if (e < r) {
-                    kk = c_keys[d * MSD_GROUP + e];
-                    vv = c_vals[d * MSD_GROUP + e];
-                } else {
-                    const u32 o = s_dstart[d] + e - r;
-                    kk = s_keys[o];
-                    vv = s_vals[o];
-                }
-                if (k > 0 || l5 >= s_ph[d]) {
-                    const u32 pos = s_cur[d] + e;
-                    kout[pos] = kk;
-                    vout[pos] = vv;
-                }
+        // the next tile's pairs take the registers over; nothing younger than their loads is outstanding
+        land();
+        if (KEYGEN) {
+            raw = nx_edge ? nraw_edge : nraw;
+        } else {
+#pragma unroll
+            for (int k = 0; k < MSD_ITEMS; k++) {
+                key[k] = nkey[k];
+                val[k] = nval[k];
             }
         }
-        __syncthreads();   // (B4) carry read before it is rewritten
-        // (S5) what is left of every touched digit becomes its carry
+        __syncthreads();   // (B3)
+        // (S4) every digit belongs to one lane group of MSD_GROUP lanes (digits g, g + NG, ...): it stores
+        // the whole groups of (carry ++ segment) -- group k = elements [G k, G k + G) -- and then keeps what
+        // is left as the new carry.  No other lane group touches the digit's state: no barrier in between.
         {
-            const u32 nj = s_tot[1];
-            for (u32 j = hw; j < nj; j += MSD_NT / 32) {
-                const u32 d = s_jmap[j];
-                const u32 c = s_cnt[d], r = s_r[d], ng = s_ng[d], ds = s_dstart[d];
+            constexpr u32 NG = MSD_NT / MSD_GROUP;
+            const u32 lg = tid / MSD_GROUP, l = tid % MSD_GROUP;
+            for (u32 d = lg; d < 256; d += NG) {
+                const u32 c = s_cnt[d];
+                if (c == 0) continue;
+                const u32 r = s_r[d], ds = s_dstart[d], cur = s_cur[d], ph = s_ph[d];
+                const u32 ng = (r + c) >> MSD_GLOG;
+                for (u32 k = 0; k < ng; k++) {
+                    const u32 e = k * MSD_GROUP + l;
+                    u64 kk;
+                    u32 vv;
+                    if (e < r) {
+                        kk = c_keys[d * MSD_GROUP + e];
+                        vv = c_vals[d * MSD_GROUP + e];
+                    } else {
+                        kk = s_keys[ds + e - r];
+                        vv = s_vals[ds + e - r];
+                    }
+                    if (k > 0 || l >= ph) {
+                        kout[cur + e] = kk;
+                        vout[cur + e] = vv;
+                    }
+                }
                 const u32 newr = ng ? ((r + c) & (MSD_GROUP - 1)) : r + c;
                 if (ng) {
-                    if (l5 < newr) {
-                        const u32 o = ds + (ng * MSD_GROUP - r) + l5;
-                        c_keys[d * MSD_GROUP + l5] = s_keys[o];
-                        c_vals[d * MSD_GROUP + l5] = s_vals[o];
+                    if (l < newr) {
+                        const u32 o = ds + (ng * MSD_GROUP - r) + l;
+                        c_keys[d * MSD_GROUP + l] = s_keys[o];
+                        c_vals[d * MSD_GROUP + l] = s_vals[o];
                     }
-                } else if (l5 >= r && l5 < newr) {
-                    const u32 o = ds + l5 - r;
-                    c_keys[d * MSD_GROUP + l5] = s_keys[o];
-                    c_vals[d * MSD_GROUP + l5] = s_vals[o];
+                } else if (l >= r && l < newr) {
+                    c_keys[d * MSD_GROUP + l] = s_keys[ds + l - r];
+                    c_vals[d * MSD_GROUP + l] = s_vals[ds + l - r];
                 }
-                if (l5 == 0) {
+                if (l == 0) {
                     s_r[d] = newr;
                     if (ng) {
-                        s_cur[d] += ng * MSD_GROUP;
+                        s_cur[d] = cur + ng * MSD_GROUP;
                         s_ph[d] = 0;
                     }
                     s_cnt[d] = 0;
@@ -476,7 +584,7 @@ __global__ __launch_bounds__(MSD_NT) void msd_partition_kernel(MsdLevel L, const
             // segment and digit); then the next segment's ranges are taken
             __syncthreads();
             for (u32 x = tid; x < 256 * MSD_GROUP; x += MSD_NT) {
-                const u32 d = x >> 5, j = x & 31;
+                const u32 d = x / MSD_GROUP, j = x % MSD_GROUP;
                 if (j >= s_ph[d] && j < s_r[d]) {
                     const u32 pos = s_cur[d] + j;
                     kout[pos] = c_keys[x];
@@ -484,15 +592,7 @@ __global__ __launch_bounds__(MSD_NT) void msd_partition_kernel(MsdLevel L, const
                 }
             }
             __syncthreads();
-            if (more && tid < 256) seg_init(s_info[cur ^ 1].q);
-        }
-        if (more) {
-#pragma unroll
-            for (int k = 0; k < MSD_ITEMS; k++) {
-                key[k] = nkey[k];
-                val[k] = nval[k];
-            }
-            raw = nraw;
+            if (t + 1 < t1 && tid < 256) seg_init(s_info[(slot + 1) & 3u].q);
         }
     }
 }
@@ -512,85 +612,120 @@ struct MsdFinishArgs {
     u32 *counters;       // [1] bit 2: a bucket above MSDF_CAP was met (the caller takes the LSD path)
 };
 
-// One wave per bucket: counting sort by field 3 (bits 39..32) into the wave's LDS image, ranks inside
-// the bins by all 32 remaining bits (39..8), then SA / last column leave coalesced.  Members with equal
-// remaining bits are tied beyond the key: (slot, suffix, group = first slot of the equal run) go to
-// the tied list exactly as finish_kernel emits them.
+// One workgroup per level-3 parent; its buckets (the children) are taken in chunks of consecutive
+// children -- at most MSDF_CH of them, at most MSDF_TILE pairs -- which are contiguous in memory.  A
+// chunk is counting-sorted in LDS by (child, field 3) = key bits 47..32, one bin per value: the bins
+// lie in key order, so a pair's final place is its bin's start plus its rank inside the (~4-member) bin
+// by all 32 remaining bits (39..8).  SA / last column leave coalesced.  Members with equal remaining
+// bits are tied beyond the key: (slot, suffix, group = first slot of the equal run) go to the tied list
+// exactly as finish_kernel emits them.
 __global__ __launch_bounds__(MSDF_NT) void msd_finish_kernel(MsdFinishArgs a) {
-    constexpr int NW = MSDF_NT / 64;
-    __shared__ u32 s_off[NW][256];
-    __shared__ u32 s_low[NW][MSDF_CAP];   // remaining key bits, in bin order
-    __shared__ u32 s_idx[NW][MSDF_CAP];   // suffix starts, in final order
-    __shared__ u8 s_L[NW][MSDF_CAP];      // preceding bytes, in final order
+    __shared__ u32 s_off[MSDF_CH * 256 + 4];
+    __shared__ u32 s_low[MSDF_TILE];   // remaining key bits, in bin order
+    __shared__ u32 s_idx[MSDF_TILE];   // suffix starts, in final order
+    __shared__ u8 s_L[MSDF_TILE];      // preceding bytes, in final order
+    __shared__ u32 s_cc[256], s_cs[256];
+    __shared__ u32 s_chunk[5];         // first child, children spanned, first position, pairs, next child
+    __shared__ u32 s_scan[MSDF_NT / 64 + 1];
     const u32 q = blockIdx.x;
     if (a.pcnt[q] == 0) return;
-    const int w = threadIdx.x >> 6, l = threadIdx.x & 63;
-    u32 *off = s_off[w], *low = s_low[w], *sidx = s_idx[w];
-    u8 *sl = s_L[w];
+    const u32 tid = threadIdx.x, l = tid & 63;
+    for (u32 i = tid; i < 256; i += MSDF_NT) {
+        s_cc[i] = a.ccnt[(size_t)q * 256 + i];
+        s_cs[i] = a.cstart[(size_t)q * 256 + i];
+    }
     const u32 region = blockIdx.x % FIN_REGIONS;
     u32 *rctr = a.rcount + region * FIN_RSTRIDE;
     const u32 rbase = region * a.rcap;
-    for (u32 ch = w; ch < 256; ch += NW) {
-        const size_t cid = (size_t)q * 256 + ch;
-        const u32 c = a.ccnt[cid];
-        if (c == 0) continue;
-        if (c > MSDF_CAP) {
-            if (l == 0) atomicOr(&a.counters[1], 4u);
-            continue;
+    u32 ch = 0;
+    while (true) {
+        __syncthreads();   // (also: the previous chunk's copy-out has read the LDS images)
+        if (tid == 0) {
+            while (ch < 256 && s_cc[ch] == 0) ch++;
+            u32 c0 = ch, tot = 0, span = 0;
+            if (ch < 256 && s_cc[ch] > MSDF_TILE) {   // a bucket no chunk can hold: the caller takes the LSD way
+                atomicOr(&a.counters[1], 4u);
+                ch++;
+                span = 1;
+            } else {
+                while (ch < 256 && span < MSDF_CH && tot + s_cc[ch] <= MSDF_TILE) {
+                    tot += s_cc[ch];
+                    ch++;
+                    span++;
+                }
+            }
+            s_chunk[0] = c0; s_chunk[1] = span; s_chunk[2] = c0 < 256 ? s_cs[c0] : 0; s_chunk[3] = tot; s_chunk[4] = ch;
         }
-        const u32 bs = a.cstart[cid];
-        const u64 *kp = a.keys + bs;
-        const u32 *vp = a.vals + bs;
+        __syncthreads();
+        const u32 c0 = s_chunk[0], span = s_chunk[1], start = s_chunk[2], tot = s_chunk[3];
+        ch = s_chunk[4];
+        if (c0 >= 256) break;
+        if (tot == 0) continue;
+        const u32 nbins = span * 256;
+        for (u32 i = tid; i <= nbins; i += MSDF_NT) s_off[i] = 0;
+        __syncthreads();
         u64 key[MSDF_ITEMS];
         u32 val[MSDF_ITEMS], pos[MSDF_ITEMS];
+        const u64 *kp = a.keys + start;
+        const u32 *vp = a.vals + start;
 #pragma unroll
         for (int k = 0; k < MSDF_ITEMS; k++) {
-            const u32 i = k * 64 + l;
-            if (k * 64 < (int)c && i < c) {
+            const u32 i = k * MSDF_NT + tid;
+            if (i < tot) {
                 key[k] = kp[i];
                 val[k] = vp[i];
             }
         }
-        off[l] = 0; off[64 + l] = 0; off[128 + l] = 0; off[192 + l] = 0;
-        __builtin_amdgcn_wave_barrier();
 #pragma unroll
         for (int k = 0; k < MSDF_ITEMS; k++) {
-            const u32 i = k * 64 + l;
-            if (k * 64 < (int)c && i < c) pos[k] = atomicAdd(&off[(u32)(key[k] >> 32) & 255u], 1u);
+            const u32 i = k * MSDF_NT + tid;
+            if (i < tot) pos[k] = atomicAdd(&s_off[((u32)(key[k] >> 32) & 0xffffu) - (c0 << 8)], 1u);
         }
-        __builtin_amdgcn_wave_barrier();
-        {   // counts -> exclusive offsets (4 bins per lane); the end of bin 255 is c
-            const u32 h0 = off[4 * l], h1 = off[4 * l + 1], h2 = off[4 * l + 2], h3 = off[4 * l + 3];
-            const u32 sm = h0 + h1 + h2 + h3;
-            const u32 ex = wave_incl_sum(sm) - sm;
-            __builtin_amdgcn_wave_barrier();
-            off[4 * l] = ex; off[4 * l + 1] = ex + h0; off[4 * l + 2] = ex + h0 + h1; off[4 * l + 3] = ex + h0 + h1 + h2;
+        __syncthreads();
+        {   // counts -> exclusive offsets; s_off[nbins] = tot
+            constexpr int BPT = MSDF_CH * 256 / MSDF_NT;   // bins per thread
+            static_assert(BPT * MSDF_NT == MSDF_CH * 256, "bins must divide among the threads");
+            const u32 b0 = tid * BPT;
+            u32 h[BPT], sum = 0;
+#pragma unroll
+            for (int j = 0; j < BPT; j++) {
+                h[j] = b0 + j < nbins ? s_off[b0 + j] : 0u;
+                sum += h[j];
+            }
+            u32 all;
+            u32 ex = block_excl_sum<MSDF_NT>(sum, s_scan, &all);
+#pragma unroll
+            for (int j = 0; j < BPT; j++) {
+                if (b0 + j < nbins) s_off[b0 + j] = ex;
+                ex += h[j];
+            }
+            if (tid == 0) s_off[nbins] = tot;
         }
-        __builtin_amdgcn_wave_barrier();
+        __syncthreads();
 #pragma unroll
         for (int k = 0; k < MSDF_ITEMS; k++) {
-            const u32 i = k * 64 + l;
-            if (k * 64 < (int)c && i < c) {
-                pos[k] += off[(u32)(key[k] >> 32) & 255u];
-                low[pos[k]] = (u32)(key[k] >> 8);
+            const u32 i = k * MSDF_NT + tid;
+            if (i < tot) {
+                pos[k] += s_off[((u32)(key[k] >> 32) & 0xffffu) - (c0 << 8)];
+                s_low[pos[k]] = (u32)(key[k] >> 8);
             }
         }
-        __builtin_amdgcn_wave_barrier();
+        __syncthreads();
 #pragma unroll
         for (int k = 0; k < MSDF_ITEMS; k++) {
-            if (k * 64 < (int)c) {   // (wave-uniform)
-                const u32 i = k * 64 + l;
-                const bool in = i < c;
+            if (k * MSDF_NT < tot) {   // (block-uniform)
+                const u32 i = k * MSDF_NT + tid;
+                const bool in = i < tot;
                 u32 s = 0, e = 0, lt = 0, eqb = 0, eq = 0;
                 const u32 mine = (u32)(key[k] >> 8);
                 if (in) {
-                    const u32 f = (u32)(key[k] >> 32) & 255u;
-                    s = off[f];
-                    e = f == 255u ? c : off[f + 1];
+                    const u32 bin = ((u32)(key[k] >> 32) & 0xffffu) - (c0 << 8);
+                    s = s_off[bin];
+                    e = s_off[bin + 1];
                 }
                 for (u32 u = s; __any(u < e); u++) {
                     if (u < e) {
-                        const u32 y = low[u];
+                        const u32 y = s_low[u];
                         lt += y < mine;
                         eq += y == mine;
                         eqb += (y == mine) & (u < pos[k]);
@@ -598,8 +733,8 @@ __global__ __launch_bounds__(MSDF_NT) void msd_finish_kernel(MsdFinishArgs a) {
                 }
                 const u32 rank = s + lt + eqb;
                 if (in) {
-                    sidx[rank] = val[k];
-                    sl[rank] = (u8)(key[k] & 0xff);
+                    s_idx[rank] = val[k];
+                    s_L[rank] = (u8)(key[k] & 0xff);
                 }
                 const bool td = in && eq > 1;   // equal on all key bits: tied beyond the key
                 const u64 tb = __ballot(td);
@@ -610,20 +745,19 @@ __global__ __launch_bounds__(MSDF_NT) void msd_finish_kernel(MsdFinishArgs a) {
                     if (td) {
                         const u32 o = base + (u32)__popcll(tb & lanemask_lt());
                         if (o < a.rcap) {
-                            a.out_slot[rbase + o] = bs + rank;
+                            a.out_slot[rbase + o] = start + rank;
                             a.out_idx[rbase + o] = val[k];
-                            a.out_grp[rbase + o] = bs + s + lt;
+                            a.out_grp[rbase + o] = start + s + lt;
                         }
                     }
                 }
             }
         }
-        __builtin_amdgcn_wave_barrier();
-        for (u32 i = l; i < c; i += 64) {
-            a.sa_out[bs + i] = sidx[i];
-            a.L[bs + i] = sl[i];
+        __syncthreads();
+        for (u32 i = tid; i < tot; i += MSDF_NT) {
+            a.sa_out[start + i] = s_idx[i];
+            a.L[start + i] = s_L[i];
         }
-        __builtin_amdgcn_wave_barrier();
     }
 }
 
