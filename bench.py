@@ -89,7 +89,10 @@ def self_launch(a):
     env.setdefault("OMP_NUM_THREADS", "4")
     env["TC_BENCH_SELF_LAUNCHED"] = "1"
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(a.gpus),
-           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__),
+           # (rebuilt from the parsed values: torchrun's own parser chokes on abbreviations such as --n)
+           "--gpus", str(a.gpus), "--steps", str(a.steps), "--warmup", str(a.warmup), "--record-bytes", str(a.n),
+           "--cpu-sample", str(a.cpu_sample)] + (["--no-cpu-baseline"] if a.no_cpu_baseline else [])
     p = subprocess.run(cmd, env=env)
     sys.exit(p.returncode)
 
