@@ -242,16 +242,22 @@ def main():
             avg_ms = st.ms_radix / launches
             per_launch = radix_launch_bytes(st, n)
             ach = per_launch / (avg_ms * 1e-3) / 1e9
-            roof = {"bound": "hbm", "kernel": "radix_pass_kernel", "achieved": round(ach, 1), "peak": 8000.0,
+            kname = "msd_partition_kernel" if getattr(st, "msd_path", 0) else "radix_pass_kernel"
+            roof = {"bound": "hbm", "kernel": kname, "achieved": round(ach, 1), "peak": 8000.0,
                     "unit": "GB/s", "frac": round(ach / 8000.0, 4), "traffic": None,
                     "launches_per_step": launches, "avg_launch_ms": round(avg_ms, 4),
                     "algorithmic_bytes_per_launch": int(per_launch), "first_pass_builds_keys": bool(st.keygen_fused),
                     "pipeline_algorithmic_bytes": A, "pipeline_bytes_per_input_byte": round(A / n, 1),
                     "pipeline_achieved_GBps": round(A / (dt / a.steps) / 1e9, 1)}
+            # HBM bytes per launch from the PMC counters cannot be collected inside a timed run (rocprofv3
+            # --pmc serialises the kernels): the figure is the one recorded by scripts/pmc_traffic.sh for this
+            # kernel on this workload (profiles/traffic_latest.json, which names the commit it was taken on)
             pj = os.path.join(ROOT, "profiles", "traffic_latest.json")
-            if os.path.exists(pj) and n == GIB:   # counters were collected on the 1 GiB workload
+            if os.path.exists(pj) and n == GIB:
                 try:
-                    roof["traffic"] = json.load(open(pj)).get("radix_pass_kernel_bytes_per_launch")
+                    tj = json.load(open(pj))
+                    roof["traffic"] = tj.get(kname + "_bytes_per_launch")
+                    roof["traffic_source"] = "recorded: profiles/traffic_latest.json (%s), not measured in this run" % tj.get("commit", "?")
                 except Exception:
                     pass
         out = {

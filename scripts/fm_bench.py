@@ -49,6 +49,7 @@ if len(sub):
         sfx = mp[:, m - L:].contiguous()
         so = (torch.arange(len(sub) + 1, device="cuda", dtype=torch.int64) * L).contiguous()
         o = torch.zeros(len(sub), dtype=torch.int64, device="cuda")
+        torch.cuda.synchronize()   # the library runs on its own stream: torch's kernels above must be done
         assert lib.tc_fm_count_dev(ctx.handle, fm._h, C.c_void_p(sfx.data_ptr()), C.c_void_p(so.data_ptr()), len(sub), C.c_void_p(o.data_ptr())) == 0
         z = o.cpu().numpy() == 0
         last[alive & z] = L; alive &= ~z

@@ -23,9 +23,17 @@ for k,d in sorted(tot.items(), key=lambda kv:-max(kv[1]["WRITE_SIZE"]+[0])-2*max
     if fe+wr < 1e8: continue
     print("%-62s %8d %12.2f %12.2f %12.2f"%(k,len(d["WRITE_SIZE"]),fe/1e9,wr/1e9,(fe+wr)/1e9))
     out[k]={"fetch_bytes":fe,"write_bytes":wr}
-rp=[v for k,v in out.items() if "radix_pass_kernel<false" in k]
-if rp:
-    json.dump({"radix_pass_kernel_bytes_per_launch": rp[0]["fetch_bytes"]+rp[0]["write_bytes"], "detail": out,
-               "note": "largest dispatch of each kernel, 1 GiB ACGTN bench; traffic = 2*FETCH_SIZE + WRITE_SIZE"},
-              open("gpurun_out/traffic_latest.json","w"), indent=1)
+res={"detail": out, "commit": __import__("os").environ.get("TC_COMMIT", "?"),
+     "note": "1 GiB ACGTN bench; traffic = 2*FETCH_SIZE + WRITE_SIZE of the largest dispatch of each kernel; "
+             "*_bytes_per_launch = mean over that kernel's full-length launches of one step"}
+# mean over the launches of one step (the partition levels differ: level 1 reads the text, not a key array)
+for name,pat in (("radix_pass_kernel","radix_pass_kernel<false"),("msd_partition_kernel","msd_partition_kernel")):
+    fe=[];wr=[]
+    for k,d in tot.items():
+        if pat in k:
+            big=max(d["WRITE_SIZE"]+[0])
+            for f,w in zip(sorted(d["FETCH_SIZE"])[::-1], sorted(d["WRITE_SIZE"])[::-1]):
+                if w > 0.5*big: fe.append(2*f); wr.append(w)
+    if wr: res[name+"_bytes_per_launch"]=(sum(fe)+sum(wr))/len(wr); res[name+"_launches"]=len(wr)
+json.dump(res, open("gpurun_out/traffic_latest.json","w"), indent=1)
 PY

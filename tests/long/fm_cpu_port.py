@@ -36,6 +36,7 @@ pats, d_offs = c4_patterns_dev(ctx, d_text, npat, m)
 fm = ctx.fm_build(text)
 d_out = torch.zeros(npat, dtype=torch.int64, device="cuda")
 ctx.lib.tc_fm_count_dev.argtypes = [C.c_void_p] * 4 + [C.c_uint64, C.c_void_p]
+torch.cuda.synchronize()   # the library runs on its own stream
 assert ctx.lib.tc_fm_count_dev(ctx.handle, fm._h, C.c_void_p(pats.data_ptr()), C.c_void_p(d_offs.data_ptr()), npat,
                                C.c_void_p(d_out.data_ptr())) == 0
 dev = d_out.cpu().numpy()

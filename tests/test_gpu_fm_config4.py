@@ -19,6 +19,7 @@ def _count_dev(ctx, fm, pats, d_offs, npat):
     import torch
     d_out = torch.zeros(npat, dtype=torch.int64, device="cuda")
     ctx.lib.tc_fm_count_dev.argtypes = [C.c_void_p] * 4 + [C.c_uint64, C.c_void_p]
+    torch.cuda.synchronize()   # the library runs on its own stream
     rc = ctx.lib.tc_fm_count_dev(ctx.handle, fm._h, C.c_void_p(pats.data_ptr()), C.c_void_p(d_offs.data_ptr()),
                                  npat, C.c_void_p(d_out.data_ptr()))
     assert rc == 0, ctx.lib.tc_last_error(ctx.handle)

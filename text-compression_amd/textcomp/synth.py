@@ -35,6 +35,9 @@ def c4_patterns_dev(ctx, d_text, npat, m=100):
     miss = torch.arange(99, npat, 100, device=dev)
     if len(miss):
         d_rand = torch.empty(len(miss) * m, dtype=torch.uint8, device=dev)
+        # the library writes d_rand on ITS stream: torch's kernels above must be done first (the block may
+        # be recycled from a temporary that a queued gather still reads)
+        torch.cuda.synchronize()
         rc = ctx.lib.tc_generate_dev(ctx.handle, 0, 0xC4F1, len(miss) * m, C.c_void_p(d_rand.data_ptr()))
         assert rc == 0
         torch.cuda.synchronize()
