@@ -257,6 +257,17 @@ int tc_fm_locate(tc_ctx *ctx, const tc_fm *fm, const uint8_t *pats, const uint64
 int tc_fm_info(const tc_fm *fm, uint64_t *N, uint32_t *sigma, int16_t *c_sym, uint64_t *c_val,
                uint64_t *primary);
 
+/* Replication of a built index over the GPUs of a node (FM-count shards by pattern batch,
+ * the index is broadcast once): the index as ONE device byte string (header, C / code tables, rank
+ * bit-vectors; with_locate != 0 adds the last column and the suffix array that tc_fm_locate needs) and
+ * back.  The caller moves the bytes (RCCL broadcast); tc_fm_import_dev checks the header
+ * (TC_ERR_MALFORMED) and copies out of d_in, which may be released afterwards.  An index imported
+ * without the locate part answers tc_fm_count only (tc_fm_locate: TC_ERR_ARG).  Buffers 16-byte
+ * aligned.  *bytes: in = capacity, out = bytes used (TC_ERR_CAPACITY: bytes needed). */
+uint64_t tc_fm_export_bound(const tc_fm *fm, int with_locate);
+int tc_fm_export_dev(tc_ctx *ctx, const tc_fm *fm, int with_locate, uint8_t *d_out, uint64_t *bytes);
+int tc_fm_import_dev(tc_ctx *ctx, const uint8_t *d_in, uint64_t bytes, tc_fm **out);
+
 /* ---- synthetic inputs, generated on the device ------------- */
 /* kind 0: iid ACGTN, kind 1: printable ASCII.  d_out is a device pointer. */
 int tc_generate_dev(tc_ctx *ctx, int kind, uint64_t seed, uint64_t n, uint8_t *d_out);

@@ -59,3 +59,37 @@ def test_product_never_imports_oracle():
             if f.endswith((".py", ".hip", ".hpp", ".h", ".hs")):
                 txt = open(os.path.join(d, f)).read().lower()
                 assert "oracle" not in txt, (d, f)
+
+
+def _c_prototypes():
+    """name -> number of parameters, from include/textcomp.h"""
+    src = open(os.path.join(ROOT, "include", "textcomp.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    out = {}
+    for m in re.finditer(r"\b(tc_[a-z0-9_]+)\s*\(([^;{]*?)\)\s*;", src, flags=re.S):
+        params = m.group(2).strip()
+        out[m.group(1)] = 0 if params in ("", "void") else params.count(",") + 1
+    return out
+
+
+def test_haskell_ffi_imports_match_header():
+    """hs/.../FFI.hs cannot be compiled here (no GHC): at least every `foreign import` names a function
+    the header declares, with as many arguments, and GPU.hs calls only imported names."""
+    hs = os.path.join(ROOT, "text-compression_amd", "hs", "Data", "TextCompression")
+    ffi = open(os.path.join(hs, "FFI.hs")).read()
+    protos = _c_prototypes()
+    imports = re.findall(r'foreign import ccall (?:safe|unsafe) "(tc_[a-z0-9_]+)"\s*\n?\s*(c_tc_[a-z0-9_]+)\s*::\s*([^\n]+(?:\n\s{4,}[^\n]+)*)', ffi)
+    assert len(imports) >= 20
+    assert len(imports) == ffi.count("foreign import")
+    for cname, hname, sig in imports:
+        assert hname == "c_" + cname
+        assert cname in protos, "FFI.hs imports %s, which include/textcomp.h does not declare" % cname
+        assert sig.count("->") == protos[cname], (cname, sig, protos[cname])
+    gpu = open(os.path.join(hs, "GPU.hs")).read()
+    used = set(re.findall(r"\bc_tc_[a-z0-9_]+", gpu))
+    assert used and used <= {h for _, h, _ in imports}, used - {h for _, h, _ in imports}
+    # the ByteString surface is complete: these too
+    for fn in ("bytestringFMIndexLocateS", "bytestringFMIndexLocateP", "bytestringFromByteStringBWT",
+               "bytestringToBWTToFMIndexB"):
+        assert re.search(r"^%s ::" % fn, gpu, flags=re.M), fn
+    assert "NOINLINE theCtx" in gpu      # one process-global context

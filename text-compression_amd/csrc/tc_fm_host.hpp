@@ -102,6 +102,43 @@ __device__ __forceinline__ u64 fm_occ(const u64 *__restrict__ bits, u64 lines, u
     return r;
 }
 
+// Occ(c, k1) and Occ(c, k2), k1 <= k2, of one backward-search step.  Once the range [s, e] has
+// narrowed (after ~13 steps on a 2^28 DNA text it is a single row) both positions lie in the same
+// 64-byte line: it is fetched once.  Lanes whose positions straddle two lines fetch the second one.
+__device__ __forceinline__ void fm_occ2(const u64 *__restrict__ bits, u64 lines, u32 c, u64 k1, u64 k2,
+                                        u64 *r1, u64 *r2) {
+    const u64 line1 = k1 / FM_LINE_BITS, line2 = k2 / FM_LINE_BITS;
+    const u32 off1 = (u32)(k1 - line1 * FM_LINE_BITS), off2 = (u32)(k2 - line2 * FM_LINE_BITS);
+    const ulonglong2 *p = reinterpret_cast<const ulonglong2 *>(bits + ((u64)c * lines + line1) * 8);
+    ulonglong2 a = p[0], b = p[1], cc = p[2], d = p[3];
+    {
+        const u64 w[7] = {a.y, b.x, b.y, cc.x, cc.y, d.x, d.y};
+        u64 r = a.x;
+        const u32 full = off1 >> 6, rem = off1 & 63;
+#pragma unroll
+        for (int i = 0; i < 7; i++) {
+            const u64 m = ((u32)i < full) ? ~0ull : (((u32)i == full) ? ((1ull << rem) - 1ull) : 0ull);
+            r += (u64)__popcll(w[i] & m);
+        }
+        *r1 = r;
+    }
+    if (line2 != line1) {
+        const ulonglong2 *q = reinterpret_cast<const ulonglong2 *>(bits + ((u64)c * lines + line2) * 8);
+        a = q[0]; b = q[1]; cc = q[2]; d = q[3];
+    }
+    {
+        const u64 w[7] = {a.y, b.x, b.y, cc.x, cc.y, d.x, d.y};
+        u64 r = a.x;
+        const u32 full = off2 >> 6, rem = off2 & 63;
+#pragma unroll
+        for (int i = 0; i < 7; i++) {
+            const u64 m = ((u32)i < full) ? ~0ull : (((u32)i == full) ? ((1ull << rem) - 1ull) : 0ull);
+            r += (u64)__popcll(w[i] & m);
+        }
+        *r2 = r;
+    }
+}
+
 // countFMIndex (FMIndex/Internal.hs:347-438), one pattern per lane.
 // ranges (optional): [2p] = s, [2p+1] = e (1-based inclusive) for non-empty results.
 __global__ __launch_bounds__(256) void fm_count_kernel(const u64 *__restrict__ bits, u64 lines,
@@ -131,10 +168,10 @@ __global__ __launch_bounds__(256) void fm_count_kernel(const u64 *__restrict__ b
             e = C + (i64)s_tab[512 + c];
             first = false;
         } else {                        // :424-432
-            i64 ns = C + (i64)fm_occ(bits, lines, c, (u64)(s - 1)) + 1;
-            i64 ne = C + (i64)fm_occ(bits, lines, c, (u64)e);
-            s = ns;
-            e = ne;
+            u64 o1, o2;   // (s <= e here: s - 1 < e)
+            fm_occ2(bits, lines, c, (u64)(s - 1), (u64)e, &o1, &o2);
+            s = C + (i64)o1 + 1;
+            e = C + (i64)o2;
         }
     }
     i64 cnt = (first || (e - s + 1) == 0 || flag) ? 0 : (e - s + 1);  // :366-371

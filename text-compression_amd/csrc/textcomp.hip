@@ -1296,6 +1296,103 @@ int tc_fm_build(tc_ctx *ctx, const uint8_t *text, uint64_t n, tc_fm **out) {
 
 void tc_fm_free(tc_fm *fm) { fm_release(fm); }
 
+// ---- the index as one device byte string (replication over the GPUs of a node) ----------------
+struct FmWire {
+    char magic[8];   // "TCFMI01\0"
+    u64 n, N, primary, lines, bytes;
+    u32 sigma_bytes, with_locate;
+    u32 counts[256];
+    i16 sym_of_code[256];
+    u32 tab[768];
+};
+static const char kFmMagic[8] = {'T', 'C', 'F', 'M', 'I', '0', '1', 0};
+static inline u64 fm_wire_align(u64 v) { return (v + 255) & ~(u64)255; }
+static u64 fm_wire_bytes(const tc_fm *fm, int with_locate) {
+    u64 b = fm_wire_align(sizeof(FmWire));
+    if (fm->n == 0) return b;
+    b += fm_wire_align((u64)fm->sigma_bytes * fm->lines * 64);
+    if (with_locate) b += fm_wire_align(fm->N + 16) + fm_wire_align(fm->N * sizeof(u32));
+    return b;
+}
+
+uint64_t tc_fm_export_bound(const tc_fm *fm, int with_locate) { return fm ? fm_wire_bytes(fm, with_locate) : 0; }
+
+int tc_fm_export_dev(tc_ctx *ctx, const tc_fm *fm, int with_locate, uint8_t *d_out, uint64_t *bytes) {
+    TC_API_BEGIN(ctx)
+    if (!fm || !bytes) TC_FAIL(ctx, TC_ERR_ARG, "bad argument");
+    const u64 need = fm_wire_bytes(fm, with_locate), cap = *bytes;
+    *bytes = need;
+    if (cap < need) TC_FAIL(ctx, TC_ERR_CAPACITY, "index export needs %llu bytes, have %llu", (unsigned long long)need, (unsigned long long)cap);
+    if (!d_out || ((uintptr_t)d_out & 15)) TC_FAIL(ctx, TC_ERR_ARG, "export buffer must be 16-byte aligned");
+    FmWire h = {};
+    memcpy(h.magic, kFmMagic, 8);
+    h.n = fm->n; h.N = fm->N; h.primary = fm->primary; h.lines = fm->lines; h.bytes = need;
+    h.sigma_bytes = fm->sigma_bytes; h.with_locate = (fm->n && with_locate) ? 1u : 0u;
+    memcpy(h.counts, fm->counts, sizeof h.counts);
+    memcpy(h.sym_of_code, fm->sym_of_code, sizeof h.sym_of_code);
+    hipStream_t s = ctx->stream;
+    if (fm->n) TC_HIP(ctx, hipMemcpyAsync(h.tab, fm->d_tab, sizeof h.tab, hipMemcpyDeviceToHost, s));
+    TC_HIP(ctx, hipStreamSynchronize(s));
+    TC_HIP(ctx, hipMemcpyAsync(d_out, &h, sizeof h, hipMemcpyHostToDevice, s));
+    u64 o = fm_wire_align(sizeof(FmWire));
+    if (fm->n) {
+        const u64 bb = (u64)fm->sigma_bytes * fm->lines * 64;
+        TC_HIP(ctx, hipMemcpyAsync(d_out + o, fm->d_bits, bb, hipMemcpyDeviceToDevice, s));
+        o += fm_wire_align(bb);
+        if (with_locate) {
+            TC_HIP(ctx, hipMemcpyAsync(d_out + o, fm->d_L, fm->N, hipMemcpyDeviceToDevice, s));
+            o += fm_wire_align(fm->N + 16);
+            TC_HIP(ctx, hipMemcpyAsync(d_out + o, fm->d_sa, fm->N * sizeof(u32), hipMemcpyDeviceToDevice, s));
+        }
+    }
+    TC_HIP(ctx, hipStreamSynchronize(s));   // h is a stack object
+    TC_API_END(ctx)
+}
+
+int tc_fm_import_dev(tc_ctx *ctx, const uint8_t *d_in, uint64_t bytes, tc_fm **out) {
+    TC_API_BEGIN(ctx)
+    if (!out || !d_in || bytes < sizeof(FmWire)) TC_FAIL(ctx, TC_ERR_ARG, "bad argument");
+    *out = nullptr;
+    FmWire h;
+    hipStream_t s = ctx->stream;
+    TC_HIP(ctx, hipMemcpyAsync(&h, d_in, sizeof h, hipMemcpyDeviceToHost, s));
+    TC_HIP(ctx, hipStreamSynchronize(s));
+    if (memcmp(h.magic, kFmMagic, 8) != 0 || h.bytes > bytes || h.N != (h.n ? h.n + 1 : 0) || h.n > TC_MAX_N ||
+        h.sigma_bytes > 256 || (h.n && h.lines != h.N / FM_LINE_BITS + 1))
+        TC_FAIL(ctx, TC_ERR_MALFORMED, "not an exported FM-index");
+    tc_fm *fm = new tc_fm();
+    fm->device = ctx->device;
+    fm->n = h.n; fm->N = h.N; fm->primary = h.primary; fm->lines = h.lines; fm->sigma_bytes = h.sigma_bytes;
+    memcpy(fm->counts, h.counts, sizeof h.counts);
+    memcpy(fm->sym_of_code, h.sym_of_code, sizeof h.sym_of_code);
+    try {
+        if (fm->n) {
+            tc_fm probe = *fm;
+            if (fm_wire_bytes(&probe, (int)h.with_locate) != h.bytes) TC_FAIL(ctx, TC_ERR_MALFORMED, "exported FM-index: size mismatch");
+            const u64 bb = (u64)fm->sigma_bytes * fm->lines * 64;
+            TC_HIP(ctx, hipMalloc((void **)&fm->d_tab, 768 * sizeof(u32)));
+            TC_HIP(ctx, hipMalloc((void **)&fm->d_bits, bb));
+            TC_HIP(ctx, hipMemcpyAsync(fm->d_tab, h.tab, sizeof h.tab, hipMemcpyHostToDevice, s));
+            u64 o = fm_wire_align(sizeof(FmWire));
+            TC_HIP(ctx, hipMemcpyAsync(fm->d_bits, d_in + o, bb, hipMemcpyDeviceToDevice, s));
+            o += fm_wire_align(bb);
+            if (h.with_locate) {
+                TC_HIP(ctx, hipMalloc((void **)&fm->d_L, fm->N + 16));
+                TC_HIP(ctx, hipMalloc((void **)&fm->d_sa, fm->N * sizeof(u32)));
+                TC_HIP(ctx, hipMemcpyAsync(fm->d_L, d_in + o, fm->N, hipMemcpyDeviceToDevice, s));
+                o += fm_wire_align(fm->N + 16);
+                TC_HIP(ctx, hipMemcpyAsync(fm->d_sa, d_in + o, fm->N * sizeof(u32), hipMemcpyDeviceToDevice, s));
+            }
+            TC_HIP(ctx, hipStreamSynchronize(s));
+        }
+    } catch (...) {
+        fm_release(fm);
+        throw;
+    }
+    *out = fm;
+    TC_API_END(ctx)
+}
+
 int tc_fm_count_dev(tc_ctx *ctx, const tc_fm *fm, const uint8_t *d_pats, const uint64_t *d_offs,
                     uint64_t npat, int64_t *d_out) {
     TC_API_BEGIN(ctx)
@@ -1355,6 +1452,7 @@ int tc_fm_locate(tc_ctx *ctx, const tc_fm *fm, const uint8_t *pats, const uint64
         memset(hit_offs, 0, (npat + 1) * sizeof(u64));
         return TC_OK;
     }
+    if (!fm->d_sa) TC_FAIL(ctx, TC_ERR_ARG, "this index was imported without its locate part");
     const u64 total = offs[npat];
     const u64 tiles = tc_cdiv(npat, SCAN_TILE);
     u8 *d_pats = nullptr;

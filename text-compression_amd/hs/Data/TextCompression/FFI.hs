@@ -21,6 +21,8 @@ foreign import ccall safe "tc_bwt_encode"
   c_tc_bwt_encode :: Ptr TcCtx -> Ptr Word8 -> Word64 -> Ptr Word8 -> Ptr Word64 -> IO Int32
 foreign import ccall safe "tc_bwt_decode_sym"
   c_tc_bwt_decode_sym :: Ptr TcCtx -> Ptr Int16 -> Word64 -> Ptr Word8 -> Ptr Word64 -> IO Int32
+foreign import ccall safe "tc_suffix_array"
+  c_tc_suffix_array :: Ptr TcCtx -> Ptr Word8 -> Word64 -> Ptr Word32 -> IO Int32
 -- Data.MTF
 foreign import ccall safe "tc_mtf_encode_sym"
   c_tc_mtf_encode_sym :: Ptr TcCtx -> Ptr Int16 -> Word64 -> Ptr Word16 -> Ptr Int16 -> Ptr Word32 -> IO Int32
@@ -39,6 +41,8 @@ foreign import ccall safe "tc_fm_count"
 foreign import ccall safe "tc_fm_free" c_tc_fm_free :: Ptr TcFm -> IO ()
 foreign import ccall safe "tc_fm_locate"
   c_tc_fm_locate :: Ptr TcCtx -> Ptr TcFm -> Ptr Word8 -> Ptr Word64 -> Word64 -> Ptr Word64 -> Ptr Word64 -> Ptr Word64 -> IO Int32
+foreign import ccall unsafe "tc_fm_info"
+  c_tc_fm_info :: Ptr TcFm -> Ptr Word64 -> Ptr Word32 -> Ptr Int16 -> Ptr Word64 -> Ptr Word64 -> IO Int32
 -- stored / shipped form (no counterpart in the reference): one record, or any length cut into records
 foreign import ccall unsafe "tc_container_bound"
   c_tc_container_bound :: Word64 -> Word32 -> Word64

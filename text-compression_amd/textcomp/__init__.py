@@ -37,6 +37,7 @@ class Context:
         if rc != 0:
             raise TcError(rc, "tc_ctx_create(device=%d): no usable HIP device" % device)
         self._h = h
+        self.device = device
 
     def close(self):
         if getattr(self, "_h", None):
@@ -291,13 +292,47 @@ class Context:
 class FMIndexHandle:
     """`tc_fm`: the device-resident FM-index of one text."""
 
-    def __init__(self, ctx, text):
+    def __init__(self, ctx, text, _handle=None, _n=0):
         self._ctx = ctx
+        if _handle is not None:      # an index that arrived from another GPU (textcomp.fmshard)
+            self._h, self.n = _handle, _n
+            return
         t = _u8(text)
         h = C.c_void_p()
         ctx._check(ctx.lib.tc_fm_build(ctx.handle, _ptr(t) if len(t) else None, len(t), C.byref(h)))
         self._h = h
         self.n = len(t)
+
+    def export_dev(self, with_locate=False):
+        """The index as one device byte string (torch uint8 tensor) -- what a broadcast moves."""
+        import torch
+        ctx = self._ctx
+        nb = int(ctx.lib.tc_fm_export_bound(self._h, int(with_locate)))
+        buf = torch.empty(nb, dtype=torch.uint8, device="cuda:%d" % ctx.device)
+        torch.cuda.synchronize()
+        used = C.c_uint64(nb)
+        ctx._check(ctx.lib.tc_fm_export_dev(ctx.handle, self._h, int(with_locate), C.c_void_p(buf.data_ptr()), C.byref(used)))
+        return buf[:used.value]
+
+    @classmethod
+    def import_dev(cls, ctx, buf, n=0):
+        """Inverse of export_dev on this rank's device; `buf` may be released afterwards."""
+        import torch
+        torch.cuda.synchronize()
+        h = C.c_void_p()
+        ctx._check(ctx.lib.tc_fm_import_dev(ctx.handle, C.c_void_p(buf.data_ptr()), buf.numel(), C.byref(h)))
+        return cls(ctx, None, _handle=h, _n=n)
+
+    def count_dev(self, d_pats, d_offs, npat):
+        """patterns resident on the device (flat uint8 tensor, uint64/int64 offsets [npat + 1]) -> int64 tensor"""
+        import torch
+        ctx = self._ctx
+        out = torch.zeros(max(npat, 1), dtype=torch.int64, device=d_pats.device)[:npat]
+        torch.cuda.synchronize()
+        if npat:
+            ctx._check(ctx.lib.tc_fm_count_dev(ctx.handle, self._h, C.c_void_p(d_pats.data_ptr()),
+                                               C.c_void_p(d_offs.data_ptr()), npat, C.c_void_p(out.data_ptr())))
+        return out
 
     def close(self):
         if getattr(self, "_h", None):

@@ -91,6 +91,9 @@ SYMBOLS = [
     ("tc_fm_count_dev", _INT, [_P, _P, _P, _P, _U64, _P]),
     ("tc_fm_locate", _INT, [_P, _P, _P, _P, _U64, _P, _P, _PU64]),
     ("tc_fm_info", _INT, [_P, _PU64, _PU32, _P, _P, _PU64]),
+    ("tc_fm_export_bound", _U64, [_P, _INT]),
+    ("tc_fm_export_dev", _INT, [_P, _P, _INT, _P, _PU64]),
+    ("tc_fm_import_dev", _INT, [_P, _P, _U64, C.POINTER(_P)]),
     ("tc_generate_dev", _INT, [_P, _INT, _U64, _U64, _P]),
 ]
 
