@@ -369,7 +369,16 @@ static void sa_run(tc_ctx *ctx, SaBuffers &b, const u8 *d_text, u64 n, u32 *d_sa
             // SA / last column for the untied suffixes and the tied set in act[1] (64 regions).  A text
             // whose level-3 buckets are too long for the MSD finish falls through to the LSD way.
             u32 *counters = reinterpret_cast<u32 *>(ctx->d_scalars + 12);
-            const bool try_msd = msd_cand && cfg.P == 7;
+            // The MSD way is for texts that look iid at the depth of its levels: (i) the entropy estimate
+            // puts a level-3 bucket well under the finish kernel's chunk, (ii) the sample met next to no
+            // repeated 12-symbol prefix (repeat-rich DNA has dozens among 8192; iid text of this length
+            // none) -- otherwise the attempt would be paid for and then thrown away.
+            const double lvl_bits = (cfg.entropy * cfg.s < 8.0 ? cfg.entropy * cfg.s : 8.0) * MSD_LEVELS;
+            const bool msd_fits = (double)N / exp2(lvl_bits) <= (double)MSDF_CAP / 3.0;
+            // (what an iid text of this entropy leaves among SAMP_N samples at the sampled depth, with slack)
+            const double iid_dups = (double)SAMP_N * SAMP_N / 2.0 / exp2((cfg.entropy * cfg.s < 8.0 ? cfg.entropy * cfg.s : 8.0) * (topbits / 8));
+            const bool msd_iid = (double)st.sample_dups <= (double)env_int("TC_SA_MSD_MAX_DUPS", 8) + 3.0 * iid_dups;
+            const bool try_msd = msd_cand && cfg.P == 7 && (env_int("TC_SA_MSD", 1) == 2 || (msd_fits && msd_iid));
             for (int way = try_msd ? 0 : 1; way < 2 && !have_groups; way++) {
             const bool msd = way == 0;
             const int tb = msd ? 8 * MSD_LEVELS : topbits;   // key bits that are globally ordered

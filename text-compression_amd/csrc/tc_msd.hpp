@@ -614,13 +614,22 @@ struct MsdFinishArgs {
 
 // One workgroup per level-3 parent; its buckets (the children) are taken in chunks of consecutive
 // children -- at most MSDF_CH of them, at most MSDF_TILE pairs -- which are contiguous in memory.  A
-// chunk is counting-sorted in LDS by (child, field 3) = key bits 47..32, one bin per value: the bins
-// lie in key order, so a pair's final place is its bin's start plus its rank inside the (~4-member) bin
-// by all 32 remaining bits (39..8).  SA / last column leave coalesced.  Members with equal remaining
-// bits are tied beyond the key: (slot, suffix, group = first slot of the equal run) go to the tied list
-// exactly as finish_kernel emits them.
+// chunk is counting-sorted in LDS by (child, field 3, top MSDF_XB bits of field 4) = 16 + MSDF_XB key bits
+// from bit 47 down, one bin per value (16-bit counters, two per LDS word): the bins lie in key order, so
+// a pair's final place is its bin's start plus its rank inside the (~1-member) bin by all 32 remaining
+// bits (39..8).  SA / last column leave coalesced.  Members with equal remaining bits are tied beyond
+// the key: (slot, suffix, group = first slot of the equal run) go to the tied list exactly as
+// finish_kernel emits them.
+#ifndef MSDF_XB
+#define MSDF_XB 1
+#endif
 __global__ __launch_bounds__(MSDF_NT) void msd_finish_kernel(MsdFinishArgs a) {
-    __shared__ u32 s_off[MSDF_CH * 256 + 4];
+    constexpr u32 BINS_PER_CHILD = 256u << MSDF_XB;
+    constexpr u32 MAXBINS = MSDF_CH * BINS_PER_CHILD;
+    constexpr int BPT = MAXBINS / MSDF_NT;   // bins per thread in the scan (even)
+    static_assert(BPT * MSDF_NT == MAXBINS && BPT % 2 == 0, "bins must divide among the threads in pairs");
+    static_assert(MSDF_TILE < 65536, "16-bit bin counters");
+    __shared__ u32 s_off[MAXBINS / 2 + 2];   // [bin] u16: count, then exclusive offset; [nbins] = pairs
     __shared__ u32 s_low[MSDF_TILE];   // remaining key bits, in bin order
     __shared__ u32 s_idx[MSDF_TILE];   // suffix starts, in final order
     __shared__ u8 s_L[MSDF_TILE];      // preceding bytes, in final order
@@ -637,6 +646,8 @@ __global__ __launch_bounds__(MSDF_NT) void msd_finish_kernel(MsdFinishArgs a) {
     const u32 region = blockIdx.x % FIN_REGIONS;
     u32 *rctr = a.rcount + region * FIN_RSTRIDE;
     const u32 rbase = region * a.rcap;
+    auto bin_of = [](u64 key, u32 c0) { return ((u32)(key >> (32 - MSDF_XB)) & ((0x10000u << MSDF_XB) - 1u)) - c0 * BINS_PER_CHILD; };
+    auto off_at = [&](u32 bin) { return (s_off[bin >> 1] >> (16 * (bin & 1))) & 0xffffu; };
     u32 ch = 0;
     while (true) {
         __syncthreads();   // (also: the previous chunk's copy-out has read the LDS images)
@@ -661,8 +672,8 @@ __global__ __launch_bounds__(MSDF_NT) void msd_finish_kernel(MsdFinishArgs a) {
         ch = s_chunk[4];
         if (c0 >= 256) break;
         if (tot == 0) continue;
-        const u32 nbins = span * 256;
-        for (u32 i = tid; i <= nbins; i += MSDF_NT) s_off[i] = 0;
+        const u32 nbins = span * BINS_PER_CHILD;
+        for (u32 i = tid; i <= nbins / 2; i += MSDF_NT) s_off[i] = 0;
         __syncthreads();
         u64 key[MSDF_ITEMS];
         u32 val[MSDF_ITEMS], pos[MSDF_ITEMS];
@@ -679,34 +690,37 @@ __global__ __launch_bounds__(MSDF_NT) void msd_finish_kernel(MsdFinishArgs a) {
 #pragma unroll
         for (int k = 0; k < MSDF_ITEMS; k++) {
             const u32 i = k * MSDF_NT + tid;
-            if (i < tot) pos[k] = atomicAdd(&s_off[((u32)(key[k] >> 32) & 0xffffu) - (c0 << 8)], 1u);
+            if (i < tot) {
+                const u32 bin = bin_of(key[k], c0);
+                const u32 old = atomicAdd(&s_off[bin >> 1], (bin & 1) ? 0x10000u : 1u);
+                pos[k] = (old >> (16 * (bin & 1))) & 0xffffu;
+            }
         }
         __syncthreads();
-        {   // counts -> exclusive offsets; s_off[nbins] = tot
-            constexpr int BPT = MSDF_CH * 256 / MSDF_NT;   // bins per thread
-            static_assert(BPT * MSDF_NT == MSDF_CH * 256, "bins must divide among the threads");
-            const u32 b0 = tid * BPT;
-            u32 h[BPT], sum = 0;
+        {   // counts -> exclusive offsets; entry nbins = tot
+            const u32 w0 = tid * (BPT / 2);
+            u32 wv[BPT / 2], sum = 0;
 #pragma unroll
-            for (int j = 0; j < BPT; j++) {
-                h[j] = b0 + j < nbins ? s_off[b0 + j] : 0u;
-                sum += h[j];
+            for (int j = 0; j < BPT / 2; j++) {
+                wv[j] = (w0 + j) * 2 < nbins ? s_off[w0 + j] : 0u;
+                sum += (wv[j] & 0xffffu) + (wv[j] >> 16);
             }
             u32 all;
             u32 ex = block_excl_sum<MSDF_NT>(sum, s_scan, &all);
 #pragma unroll
-            for (int j = 0; j < BPT; j++) {
-                if (b0 + j < nbins) s_off[b0 + j] = ex;
-                ex += h[j];
+            for (int j = 0; j < BPT / 2; j++) {
+                const u32 lo = wv[j] & 0xffffu, hi = wv[j] >> 16;
+                if ((w0 + j) * 2 < nbins) s_off[w0 + j] = ex | ((ex + lo) << 16);
+                ex += lo + hi;
             }
-            if (tid == 0) s_off[nbins] = tot;
+            if (tid == 0) s_off[nbins / 2] = tot;   // (nbins is even)
         }
         __syncthreads();
 #pragma unroll
         for (int k = 0; k < MSDF_ITEMS; k++) {
             const u32 i = k * MSDF_NT + tid;
             if (i < tot) {
-                pos[k] += s_off[((u32)(key[k] >> 32) & 0xffffu) - (c0 << 8)];
+                pos[k] += off_at(bin_of(key[k], c0));
                 s_low[pos[k]] = (u32)(key[k] >> 8);
             }
         }
@@ -716,29 +730,27 @@ __global__ __launch_bounds__(MSDF_NT) void msd_finish_kernel(MsdFinishArgs a) {
             if (k * MSDF_NT < tot) {   // (block-uniform)
                 const u32 i = k * MSDF_NT + tid;
                 const bool in = i < tot;
-                u32 s = 0, e = 0, lt = 0, eqb = 0, eq = 0;
+                u32 s = 0, e = 0, lt = 0, eq = 0;
                 const u32 mine = (u32)(key[k] >> 8);
                 if (in) {
-                    const u32 bin = ((u32)(key[k] >> 32) & 0xffffu) - (c0 << 8);
-                    s = s_off[bin];
-                    e = s_off[bin + 1];
+                    const u32 bin = bin_of(key[k], c0);
+                    s = off_at(bin);
+                    e = off_at(bin + 1);
                 }
                 for (u32 u = s; __any(u < e); u++) {
                     if (u < e) {
                         const u32 y = s_low[u];
                         lt += y < mine;
                         eq += y == mine;
-                        eqb += (y == mine) & (u < pos[k]);
                     }
                 }
-                const u32 rank = s + lt + eqb;
-                if (in) {
-                    s_idx[rank] = val[k];
-                    s_L[rank] = (u8)(key[k] & 0xff);
-                }
+                u32 rank = s + lt;
                 const bool td = in && eq > 1;   // equal on all key bits: tied beyond the key
                 const u64 tb = __ballot(td);
                 if (tb) {
+                    // (rare) members of an equal run take consecutive places in the order of their bin slots
+                    if (td)
+                        for (u32 u = s; u < pos[k]; u++) rank += s_low[u] == mine;
                     u32 base = 0;
                     if (l == 0) base = atomicAdd(rctr, (u32)__popcll(tb));
                     base = __shfl(base, 0, 64);
@@ -750,6 +762,10 @@ __global__ __launch_bounds__(MSDF_NT) void msd_finish_kernel(MsdFinishArgs a) {
                             a.out_grp[rbase + o] = start + s + lt;
                         }
                     }
+                }
+                if (in) {
+                    s_idx[rank] = val[k];
+                    s_L[rank] = (u8)(key[k] & 0xff);
                 }
             }
         }
