@@ -329,7 +329,7 @@ __global__ __launch_bounds__(MSD_NT) void msd_partition_kernel(MsdLevel L, const
 
     u64 key[MSD_ITEMS], nkey[MSD_ITEMS];
     u32 val[MSD_ITEMS], nval[MSD_ITEMS];
-    msd_u32x4 raw = {0, 0, 0, 0}, nraw = {0, 0, 0, 0}, nraw_edge = {0, 0, 0, 0};
+    msd_u32x4 raw = {0, 0, 0, 0}, nraw = {0, 0, 0, 0};
     // KEYGEN: 16 text bytes per thread from position base - KG_PRE + 16 * tid (bytes outside the text: 0).
     // A tile is an "edge" tile when some unit reaches outside the text or the text is not 16-byte
     // aligned (first / last tile only): those units are read byte by byte.
@@ -413,7 +413,7 @@ __global__ __launch_bounds__(MSD_NT) void msd_partition_kernel(MsdLevel L, const
     };
     if (tid < 256) seg_init(s_info[0].q);
     if (KEYGEN) {
-        raw = kg_load_plain(s_info[0]);
+        if (!kg_edge(s_info[0])) raw = kg_load_plain(s_info[0]);
     } else {
         const MsdTileInfo f = s_info[0];
 #pragma unroll
@@ -433,9 +433,58 @@ __global__ __launch_bounds__(MSD_NT) void msd_partition_kernel(MsdLevel L, const
         __syncthreads();   // (B0) s_cnt zeroed; staging free; carries / ranges of this segment in place
         const MsdTileInfo nx = s_info[(slot + 1) & 3u];
         prefetch(ti, nx);   // tile t + 1: in flight while tile t is ranked and staged
-        const bool nx_edge = KEYGEN && nx.valid != 0 && kg_edge(nx);
-        if (nx_edge) nraw_edge = kg_load_plain(nx);
-        if (KEYGEN) {
+        if (KEYGEN && kg_edge(ti)) raw = kg_load_plain(ti);   // first / last tile: ordinary loads, bounds-checked
+        const bool fastkg = KEYGEN && kg.s <= 3 && MSD_ITEMS == 8 && !kg_edge(ti);
+        if (fastkg) {
+            // interior tile, fields of <= 3 symbols: thread t builds the keys of the 8 CONSECUTIVE suffixes
+            // 8 t .. 8 t + 7 (which thread handles which pair is free: the tile is permuted anyway) from the
+            // 8 + 7 s - 1 symbols they span -- one LUT read per symbol, everything else in registers
+            if (tid < kg_units) *reinterpret_cast<uint4 *>(k_r + tid * 16) = make_uint4(raw.x, raw.y, raw.z, raw.w);
+            __syncthreads();
+            const u64 *rp = reinterpret_cast<const u64 *>(k_r + KG_PRE + 8 * tid - 8);
+            const u64 w[5] = {rp[0], rp[1], rp[2], rp[3], rp[4]};
+            const u32 B = kg.B;
+            auto code = [&](int j) { return (u32)s_klut[(u32)(w[1 + (j >> 3)] >> (8 * (j & 7))) & 255u]; };
+#pragma unroll
+            for (int k = 0; k < 8; k++) {
+                const u32 prev = k == 0 ? (u32)(w[0] >> 56) : (u32)(w[1] >> (8 * (k - 1))) & 255u;
+                key[k] = (u64)prev;
+            }
+            // field value g(j) = the s symbols from j on; it is field f of suffix k = j - s f
+            if (kg.s == 3) {
+                u32 c0 = code(0), c1 = code(1);
+#pragma unroll
+                for (int j = 0; j < 26; j++) {
+                    const u32 c2 = code(j + 2);
+                    const u64 g = (u64)((c0 * B + c1) * B + c2);
+#pragma unroll
+                    for (int f = 0; f < 7; f++)
+                        if (j - 3 * f >= 0 && j - 3 * f < 8) key[j - 3 * f] |= g << (56 - 8 * f);
+                    c0 = c1;
+                    c1 = c2;
+                }
+            } else if (kg.s == 2) {
+                u32 c0 = code(0);
+#pragma unroll
+                for (int j = 0; j < 20; j++) {
+                    const u32 c1 = code(j + 1);
+                    const u64 g = (u64)(c0 * B + c1);
+#pragma unroll
+                    for (int f = 0; f < 7; f++)
+                        if (j - 2 * f >= 0 && j - 2 * f < 8) key[j - 2 * f] |= g << (56 - 8 * f);
+                    c0 = c1;
+                }
+            } else {
+#pragma unroll
+                for (int j = 0; j < 14; j++) {
+                    const u64 g = (u64)code(j);
+#pragma unroll
+                    for (int f = 0; f < 7; f++)
+                        if (j - f >= 0 && j - f < 8) key[j - f] |= g << (56 - 8 * f);
+                }
+            }
+            __syncthreads();   // image dead: the staging area may be written
+        } else if (KEYGEN) {
             const i64 nt = (i64)kg.n_text;
             if (tid < kg_units) {
                 const i64 p0 = (i64)ti.base - KG_PRE + (i64)tid * 16;
@@ -481,7 +530,6 @@ __global__ __launch_bounds__(MSD_NT) void msd_partition_kernel(MsdLevel L, const
                     for (int f = 0; f < 7; f++)
                         if (f < (int)kg.P) kk |= (u64)k_g[x + f * kg.s] << (56 - 8 * f);
                     key[k] = kk | (u64)k_r[x - 1];
-                    val[k] = ti.base + p;
                 }
             }
             __syncthreads();   // image dead: the staging area may be written
@@ -516,13 +564,15 @@ __global__ __launch_bounds__(MSD_NT) void msd_partition_kernel(MsdLevel L, const
             if (p < ti.valid) {
                 const u32 o = s_dstart[dig[k]] + rnk[k];
                 s_keys[o] = key[k];
-                s_vals[o] = val[k];
+                // (KEYGEN: the value is the suffix start -- which suffix slot k of this thread holds
+                // depends on the key-generation form used for the tile)
+                s_vals[o] = KEYGEN ? ti.base + (fastkg ? 8 * tid + k : p) : val[k];
             }
         }
         // the next tile's pairs take the registers over; nothing younger than their loads is outstanding
         land();
         if (KEYGEN) {
-            raw = nx_edge ? nraw_edge : nraw;
+            raw = nraw;
         } else {
 #pragma unroll
             for (int k = 0; k < MSD_ITEMS; k++) {
