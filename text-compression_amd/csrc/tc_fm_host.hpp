@@ -155,12 +155,22 @@ __global__ __launch_bounds__(256) void fm_count_kernel(const u64 *__restrict__ b
     const u64 beg = offs[p], end = offs[p + 1];
     i64 s = -1, e = -1;
     bool first = true, flag = false;
+    // the pattern is read right to left through an aligned 8-byte window: one load per 8 steps instead of
+    // one uncoalesced byte load per step (64 lanes = 64 different lines every time).  The aligned word
+    // that holds a valid byte lies in that byte's page, so reading it whole is always safe.
+    uintptr_t wbase = ~(uintptr_t)0;
+    u64 word = 0;
     for (u64 q = end; q > beg; q--) {  // right to left (:375)
         if (s > e) {                    // :387-389
             flag = true;
             break;
         }
-        u32 c = s_tab[pats[q - 1]];
+        const uintptr_t ad = (uintptr_t)(pats + (q - 1));
+        if ((ad & ~(uintptr_t)7) != wbase) {
+            wbase = ad & ~(uintptr_t)7;
+            word = *reinterpret_cast<const u64 *>(wbase);
+        }
+        u32 c = s_tab[(u32)(word >> (8 * (ad & 7))) & 255u];
         if (c == 0xFFFFFFFFu) break;    // findIndexL = Nothing: the loop just stops (:393,:421)
         i64 C = (i64)s_tab[256 + c];
         if (first) {                    // :391-418
