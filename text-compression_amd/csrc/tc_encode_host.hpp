@@ -77,6 +77,7 @@ struct SaBuffers {
     // MSD round 0 (tc_msd.hpp), carved only for texts long enough to take it
     u32 *msd_pstart[MSD_LEVELS + 1], *msd_pcnt[MSD_LEVELS + 1];   // [l]: parents of level l + 1; [3]: level-3 buckets
     u32 *msd_tpre[MSD_LEVELS], *msd_seg[MSD_LEVELS];
+    u32 *msd_joint;   // [256^3] child counts of the level-3 parents, gathered by the level-2 counting pass
     u32 msd_grid;
 };
 
@@ -121,6 +122,7 @@ static size_t sa_carve(Arena &A, u64 N, SaBuffers &b, bool own_v1) {
                 b.msd_seg[l] = A.get<u32>((np + b.msd_grid) * 256);
             }
         }
+        b.msd_joint = A.get<u32>((size_t)256 * 256 * 256);
     }
     return A.off;
 }
@@ -416,18 +418,26 @@ static void sa_run(tc_ctx *ctx, SaBuffers &b, const u8 *d_text, u64 n, u32 *d_sa
                 u32 *vbuf[2] = {b.v0, va};
                 ctx->pev_used = 0;
                 st.keygen_fused = 1;
+                // the last level is "aligned" (one workgroup per parent): its child counts are gathered by the
+                // level before it, which saves that level's counting pass over the keys (TC_SA_MSD_JOINT=0: off)
+                const bool joint = env_int("TC_SA_MSD_JOINT", 1) != 0;
+                if (joint) tc_memset_async(ctx, b.msd_joint, 0, (size_t)256 * 256 * 256 * sizeof(u32));
                 u32 np = 1;
                 for (int l = 0; l < MSD_LEVELS; l++, np *= 256) {
                     MsdLevel ML;
                     ML.pstart = b.msd_pstart[l]; ML.pcnt = b.msd_pcnt[l]; ML.tpre = b.msd_tpre[l];
                     ML.nparents = np; ML.shift = 56 - 8 * l; ML.seg = b.msd_seg[l];
                     ML.cstart = b.msd_pstart[l + 1]; ML.ccnt = b.msd_pcnt[l + 1];
+                    ML.aligned = (joint && l == MSD_LEVELS - 1) ? 1 : 0;
+                    ML.ntot = (u32)N; ML.cnt_in = b.msd_joint; ML.flags = counters + 1;
                     const u64 *kin = l ? kbuf[(l - 1) & 1] : nullptr;
                     const u32 *vin = l ? vbuf[(l - 1) & 1] : nullptr;
                     msd_prep_kernel<<<1, 1024, 0, s>>>(ML.pcnt, np, b.msd_tpre[l]);
                     TC_LAUNCH_CHECK(ctx);
-                    if (l == 0) msd_count_kernel<true><<<G, MSD_NT, 0, s>>>(ML, nullptr, td);
-                    else msd_count_kernel<false><<<G, MSD_NT, 0, s>>>(ML, kin, td);
+                    if (l == 0) msd_count_kernel<true, false><<<G, MSD_NT, 0, s>>>(ML, nullptr, td, nullptr);
+                    else if (ML.aligned) { /* counts already in msd_joint */ }
+                    else if (joint && l == MSD_LEVELS - 2) msd_count_kernel<false, true><<<G, MSD_NT, 0, s>>>(ML, kin, td, b.msd_joint);
+                    else msd_count_kernel<false, false><<<G, MSD_NT, 0, s>>>(ML, kin, td, nullptr);
                     TC_LAUNCH_CHECK(ctx);
                     msd_scan_kernel<<<np, 256, 0, s>>>(ML, G, l == MSD_LEVELS - 1 ? maxchild : nullptr);
                     TC_LAUNCH_CHECK(ctx);
@@ -473,7 +483,7 @@ static void sa_run(tc_ctx *ctx, SaBuffers &b, const u8 *d_text, u64 n, u32 *d_sa
             tc_d2h(ctx, &ctx->h_scalars[12], ctx->d_scalars + 12, sizeof(u64));
             TC_HIP(ctx, hipStreamSynchronize(s));
             u32 fm = (u32)(ctx->h_scalars[12] & 0xffffffffu), over = (u32)(ctx->h_scalars[12] >> 32);
-            if (msd && (over & 4u)) continue;   // a level-3 bucket beyond MSDF_CAP: the LSD way
+            if (msd && (over & (4u | 8u))) continue;   // a level-3 bucket beyond MSDF_CAP (or counts that overflowed): the LSD way
             u32 slot_bits = (u32)rbits;
             if (!msd && (over & 1u) && fm <= fa.fix_cap && env_int("TC_SA_TIER2", 1) != 0) {
                 // some buckets are longer than a wave window: the second pass turns them into tied

@@ -58,6 +58,14 @@ struct MsdLevel {
     u32 *seg;            // [(nparents + G) * 256] per-segment digit counts, then bases (in place)
     u32 *cstart;         // [nparents * 256] children: first position
     u32 *ccnt;           // [nparents * 256] children: count
+    // "aligned" level: every parent belongs to ONE workgroup -- parent q to workgroup pstart[q] * G / ntot --
+    // so a segment is a whole parent and its digit counts do not depend on where its pairs lie: they come
+    // from cnt_in, filled by the PREVIOUS level's counting pass (joint counts of its digit and the next
+    // one), and this level needs no counting pass of its own.
+    int aligned;
+    u32 ntot;
+    const u32 *cnt_in;   // [nparents * 256] (aligned levels)
+    u32 *flags;          // device word: bit 3 = the joint counts of an aligned level do not add up
 };
 
 #ifdef __HIPCC__
@@ -71,6 +79,32 @@ __global__ void msd_root_kernel(u32 *pstart, u32 *pcnt, u32 N, u32 *maxchild) {
     pstart[0] = 0;
     pcnt[0] = N;
     *maxchild = 0;
+}
+
+// aligned levels: workgroup of parent q, and the first parent of workgroup b
+__device__ __forceinline__ u32 msd_block_of_parent(const MsdLevel &L, u32 q, u32 G) {
+    return (u32)(((u64)L.pstart[q] * G) / L.ntot);
+}
+__device__ __forceinline__ u32 msd_first_parent(const MsdLevel &L, u32 b, u32 G) {
+    if (b == 0) return 0;
+    if (b >= G) return L.nparents;
+    u32 lo = 0, hi = L.nparents;   // first q in [0, nparents] with block_of(q) >= b (pstart is monotone)
+    while (lo < hi) {
+        const u32 mid = (lo + hi) >> 1;
+        if (msd_block_of_parent(L, mid, G) >= b) hi = mid; else lo = mid + 1;
+    }
+    return lo;
+}
+// tiles [t0, t1) of workgroup b (call from one thread)
+__device__ __forceinline__ void msd_block_range(const MsdLevel &L, u32 b, u32 G, u32 *t0, u32 *t1) {
+    if (L.aligned) {
+        *t0 = L.tpre[msd_first_parent(L, b, G)];
+        *t1 = L.tpre[msd_first_parent(L, b + 1, G)];
+    } else {
+        const u32 T = L.tpre[L.nparents];
+        *t0 = (u32)(((u64)T * b) / G);
+        *t1 = (u32)(((u64)T * (b + 1)) / G);
+    }
 }
 
 // tiles per parent -> exclusive prefix.  One block; nparents <= 65536.
@@ -152,15 +186,23 @@ struct MsdTextDigit {
 // symbols in base B, straight from the text (two overlapping word loads per 4 suffixes where the
 // segment lies inside the text; s <= 5 there, else bytes).  A segment = the run of a workgroup's tiles
 // inside one parent = one contiguous range of positions: no per-tile synchronisation.
-template <bool TEXT>
+// JOINT: besides, the counts of (digit, next digit) per parent are accumulated into joint_out
+// [(parent * 256 + digit) * 256 + next digit] -- the child counts of the NEXT level's parents, which is
+// then an aligned level without a counting pass.  LDS table of 16-bit counters, two per word; a cell that
+// overflowed (>= 65536 pairs of one segment in one level-(l+2) bucket: such a text leaves the MSD way
+// anyway) shows as a sum mismatch in the next level's scan.
+template <bool TEXT, bool JOINT>
 __global__ __launch_bounds__(MSD_NT) void msd_count_kernel(MsdLevel L, const u64 *__restrict__ keys,
-                                                           MsdTextDigit td) {
+                                                           MsdTextDigit td, u32 *__restrict__ joint_out) {
     __shared__ u32 s_cnt[256];
     __shared__ u16 s_lut[TEXT ? 256 : 1];
     __shared__ u32 s_seg[4];   // q, lo, hi, next tile
+    __shared__ u32 s_joint[JOINT ? 32768 : 1];
     const u32 tid = threadIdx.x, b = blockIdx.x, G = gridDim.x;
     if (tid < 256) s_cnt[tid] = 0;
     if (TEXT && tid < 256) s_lut[tid] = td.lut[tid];
+    if (JOINT)
+        for (u32 i = tid; i < 32768; i += MSD_NT) s_joint[i] = 0;
     const u32 T = L.tpre[L.nparents];
     const u32 t0 = msd_tile_lo(T, b, G), t1 = msd_tile_lo(T, b + 1, G);
     if (t0 >= t1) return;
@@ -213,22 +255,35 @@ __global__ __launch_bounds__(MSD_NT) void msd_count_kernel(MsdLevel L, const u64
                 atomicAdd(&s_cnt[g], 1u);
             }
         } else {
+            auto add = [&](u64 k) {
+                const u32 dd = (u32)(k >> (L.shift - 8)) & 0xffffu;   // digit, next digit
+                atomicAdd(&s_cnt[dd >> 8], 1u);
+                if (JOINT) atomicAdd(&s_joint[dd >> 1], (dd & 1u) ? 0x10000u : 1u);
+            };
             u32 p = lo + tid;
             for (; p + 3 * MSD_NT < hi; p += 4 * MSD_NT) {
                 const u64 k0 = keys[p], k1 = keys[p + MSD_NT], k2 = keys[p + 2 * MSD_NT], k3 = keys[p + 3 * MSD_NT];
-                atomicAdd(&s_cnt[(u32)(k0 >> L.shift) & 255u], 1u);
-                atomicAdd(&s_cnt[(u32)(k1 >> L.shift) & 255u], 1u);
-                atomicAdd(&s_cnt[(u32)(k2 >> L.shift) & 255u], 1u);
-                atomicAdd(&s_cnt[(u32)(k3 >> L.shift) & 255u], 1u);
+                add(k0); add(k1); add(k2); add(k3);
             }
-            for (; p < hi; p += MSD_NT) atomicAdd(&s_cnt[(u32)(keys[p] >> L.shift) & 255u], 1u);
+            for (; p < hi; p += MSD_NT) add(keys[p]);
         }
         __syncthreads();
         if (tid < 256) {
             L.seg[((size_t)sq + b) * 256 + tid] = s_cnt[tid];
             s_cnt[tid] = 0;
         }
-        // (the next round's barrier orders this reset before the next atomics)
+        if (JOINT) {
+            for (u32 w = tid; w < 32768; w += MSD_NT) {
+                const u32 v = s_joint[w];
+                if (v) {
+                    u32 *o = joint_out + ((size_t)sq * 256 + (w >> 7)) * 256 + (w & 127u) * 2;
+                    if (v & 0xffffu) atomicAdd(o, v & 0xffffu);
+                    if (v >> 16) atomicAdd(o + 1, v >> 16);
+                    s_joint[w] = 0;
+                }
+            }
+        }
+        // (the next round's barrier orders these resets before the next atomics)
     }
 }
 
@@ -242,6 +297,26 @@ __global__ __launch_bounds__(256) void msd_scan_kernel(MsdLevel L, u32 G, u32 *m
     if (cnt == 0) {
         L.ccnt[c] = 0;
         L.cstart[c] = L.pstart[q];
+        return;
+    }
+    if (L.aligned) {   // one segment: the parent itself, counts from the previous level's joint table
+        const u32 tot = L.cnt_in[c];
+        u32 all;
+        const u32 excl = block_excl_sum<256>(tot, s_scan, &all);
+        const u32 start = L.pstart[q] + excl;
+        L.cstart[c] = start;
+        L.ccnt[c] = tot;
+        L.seg[((size_t)q + msd_block_of_parent(L, q, G)) * 256 + d] = start;
+        if (d == 0 && all != cnt) atomicOr(L.flags, 8u);
+        if (maxchild) {
+            u32 m = tot;
+#pragma unroll
+            for (int x = 32; x >= 1; x >>= 1) {
+                const u32 o = __shfl_xor(m, x, 64);
+                m = m > o ? m : o;
+            }
+            if ((d & 63) == 0 && m > MSDF_CAP) atomicMax(maxchild, m);
+        }
         return;
     }
     const u32 T = L.tpre[L.nparents];
@@ -300,6 +375,7 @@ __global__ __launch_bounds__(MSD_NT) void msd_partition_kernel(MsdLevel L, const
     __shared__ u32 s_cnt[256], s_dstart[256], s_r[256], s_cur[256], s_ph[256];
     __shared__ u32 s_scan[8];
     __shared__ u16 s_klut[KEYGEN ? 256 : 1];
+    __shared__ u32 s_scan2[2];
     static_assert(MSD_GROUP == 16 || MSD_GROUP == 32, "group = 16 or 32 pairs");
     static_assert((size_t)MSD_TILE * 12 + 256 * MSD_GROUP * 12 + 8192 <= 163840, "LDS budget");
     __shared__ MsdTileInfo s_info[4];
@@ -307,8 +383,13 @@ __global__ __launch_bounds__(MSD_NT) void msd_partition_kernel(MsdLevel L, const
     const u32 tid = threadIdx.x, b = blockIdx.x, G = gridDim.x;
     if (KEYGEN && tid < 256) s_klut[tid] = kg.lut[tid];
     if (tid < 256) { s_cnt[tid] = 0; s_r[tid] = 0; s_ph[tid] = 0; s_cur[tid] = 0; }
-    const u32 T = L.tpre[L.nparents];
-    const u32 t0 = msd_tile_lo(T, b, G), t1 = msd_tile_lo(T, b + 1, G);
+    if (tid == 0) {
+        u32 ta = 0, tb = 0;
+        if (!(L.aligned && (*L.flags & 8u))) msd_block_range(L, b, G, &ta, &tb);   // bad joint counts: do nothing
+        s_scan2[0] = ta; s_scan2[1] = tb;
+    }
+    __syncthreads();
+    const u32 t0 = s_scan2[0], t1 = s_scan2[1];
     if (t0 >= t1) return;
     MsdCur cs = {};
     if (tid == 0) {
@@ -687,7 +768,7 @@ __global__ __launch_bounds__(MSDF_NT) void msd_finish_kernel(MsdFinishArgs a) {
     __shared__ u32 s_chunk[5];         // first child, children spanned, first position, pairs, next child
     __shared__ u32 s_scan[MSDF_NT / 64 + 1];
     const u32 q = blockIdx.x;
-    if (a.pcnt[q] == 0) return;
+    if (a.pcnt[q] == 0 || (a.counters[1] & 8u)) return;   // (bit 3: the level-3 counts did not add up)
     const u32 tid = threadIdx.x, l = tid & 63;
     for (u32 i = tid; i < 256; i += MSDF_NT) {
         s_cc[i] = a.ccnt[(size_t)q * 256 + i];
