@@ -112,7 +112,7 @@ static size_t sa_carve(Arena &A, u64 N, SaBuffers &b, bool own_v1) {
     b.counts = A.get<u32>(260);
     for (int l = 0; l <= MSD_LEVELS; l++) b.msd_pstart[l] = b.msd_pcnt[l] = nullptr;
     if (msd_wanted(N)) {
-        b.msd_grid = 256;   // fixed for the carve; the launch uses min(this, CUs)
+        b.msd_grid = 256 * MSD_BPC;   // fixed for the carve; the launch uses min(this, CUs x workgroups per CU)
         size_t np = 1;
         for (int l = 0; l <= MSD_LEVELS; l++, np *= 256) {
             b.msd_pstart[l] = A.get<u32>(np);
@@ -408,7 +408,7 @@ static void sa_run(tc_ctx *ctx, SaBuffers &b, const u8 *d_text, u64 n, u32 *d_sa
                 MsdTextDigit td;
                 td.text = d_text; td.n = (u32)n; td.B = cfg.B; td.s = cfg.s;
                 memcpy(td.lut, cfg.lut, sizeof td.lut);
-                u32 G = b.msd_grid < (u32)ctx->num_cus ? b.msd_grid : (u32)ctx->num_cus;
+                u32 G = b.msd_grid < (u32)ctx->num_cus * MSD_BPC ? b.msd_grid : (u32)ctx->num_cus * MSD_BPC;
                 u32 *maxchild = reinterpret_cast<u32 *>(ctx->d_scalars + 15);
                 msd_root_kernel<<<1, 1, 0, s>>>(b.msd_pstart[0], b.msd_pcnt[0], (u32)N, maxchild);
                 TC_LAUNCH_CHECK(ctx);

@@ -32,7 +32,10 @@
 #ifndef MSD_GROUP
 #define MSD_GROUP 16          // pairs per store group: one 128-byte line of keys, half a line of values
 #endif
-#define MSD_GLOG (MSD_GROUP == 32 ? 5 : 4)
+#define MSD_GLOG (MSD_GROUP == 32 ? 5 : MSD_GROUP == 16 ? 4 : 3)
+#ifndef MSD_BPC
+#define MSD_BPC 1             // partition / counting workgroups per CU (LDS permitting)
+#endif
 #define MSD_LEVELS 3
 #ifndef MSDF_NT
 #define MSDF_NT 256
@@ -376,8 +379,8 @@ __global__ __launch_bounds__(MSD_NT) void msd_partition_kernel(MsdLevel L, const
     __shared__ u32 s_scan[8];
     __shared__ u16 s_klut[KEYGEN ? 256 : 1];
     __shared__ u32 s_scan2[2];
-    static_assert(MSD_GROUP == 16 || MSD_GROUP == 32, "group = 16 or 32 pairs");
-    static_assert((size_t)MSD_TILE * 12 + 256 * MSD_GROUP * 12 + 8192 <= 163840, "LDS budget");
+    static_assert(MSD_GROUP == 8 || MSD_GROUP == 16 || MSD_GROUP == 32, "group = 8, 16 or 32 pairs");
+    static_assert(((size_t)MSD_TILE * 12 + 256 * MSD_GROUP * 12 + 8192) * MSD_BPC <= 163840, "LDS budget");
     __shared__ MsdTileInfo s_info[4];
 
     const u32 tid = threadIdx.x, b = blockIdx.x, G = gridDim.x;
