@@ -44,6 +44,7 @@ extern "C" {
 #define TC_ERR_HIP (-4)
 #define TC_ERR_OOM (-5)
 #define TC_ERR_INTERNAL (-6)
+#define TC_ERR_NCCL (-7)     /* RCCL missing or failing (tc_comm_* only) */
 
 #define TC_MAX_N ((uint64_t)0x7ffffff0u) /* indices are 31-bit on the device */
 #define TC_MAX_SIGMA 257                 /* 256 byte values + Nothing */
@@ -267,6 +268,32 @@ int tc_fm_info(const tc_fm *fm, uint64_t *N, uint32_t *sigma, int16_t *c_sym, ui
 uint64_t tc_fm_export_bound(const tc_fm *fm, int with_locate);
 int tc_fm_export_dev(tc_ctx *ctx, const tc_fm *fm, int with_locate, uint8_t *d_out, uint64_t *bytes);
 int tc_fm_import_dev(tc_ctx *ctx, const uint8_t *d_in, uint64_t bytes, tc_fm **out);
+
+/* ---- the exchange of the multi-GPU path ------------------------------------------ */
+/* One process per GPU, one tc_ctx per process, one record per GPU: nothing is exchanged during the
+ * encode.  A tc_comm is an RCCL communicator over the ranks of the job, bound at run time (dlopen: a
+ * process that never calls tc_comm_* never loads RCCL; failures are TC_ERR_NCCL).  Rank 0 obtains an id
+ * with tc_comm_unique_id and hands its TC_COMM_ID_BYTES bytes to the other ranks by whatever channel
+ * started them (environment, file, MPI ...); then every rank calls tc_comm_create (collective).
+ *
+ * tc_comm_gather (collective): the variable-size gather of one container (tc_block_to_container_dev)
+ * per rank on `root`.  Sizes travel by an all-gather of one word per rank (sizes[world], host, out on
+ * every rank); then the root receives rank r's bytes at d_recv + r * slot_bytes (its own container is
+ * copied there too) in ONE group of point-to-point transfers -- it ingests on all of its xGMI links at
+ * once.  A size above slot_bytes is TC_ERR_CAPACITY on EVERY rank (before anything is sent).  The call
+ * returns once the transfers are POSTED on the communicator's own stream: the gather of record k overlaps
+ * the encode of record k + 1; d_container and d_recv belong to the exchange until tc_comm_wait returns.
+ * tc_comm_broadcast (collective, complete on return): `bytes` of d_buf from root to all (an exported
+ * FM-index, tc_fm_export_dev -> tc_fm_import_dev).  All buffers are device pointers. */
+#define TC_COMM_ID_BYTES 128
+typedef struct tc_comm tc_comm;
+int tc_comm_unique_id(tc_ctx *ctx, uint8_t *id /* [TC_COMM_ID_BYTES] */);
+int tc_comm_create(tc_ctx *ctx, const uint8_t *id, int rank, int world, tc_comm **out);
+void tc_comm_destroy(tc_comm *comm);
+int tc_comm_gather(tc_comm *comm, int root, const uint8_t *d_container, uint64_t bytes, uint8_t *d_recv,
+                   uint64_t slot_bytes, uint64_t *sizes);
+int tc_comm_wait(tc_comm *comm);
+int tc_comm_broadcast(tc_comm *comm, int root, uint8_t *d_buf, uint64_t bytes);
 
 /* ---- synthetic inputs, generated on the device ------------- */
 /* kind 0: iid ACGTN, kind 1: printable ASCII.  d_out is a device pointer. */

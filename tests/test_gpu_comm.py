@@ -1,0 +1,60 @@
+"""The exchange of the multi-GPU path behind the C ABI (tc_comm_*), as far as one GPU
+goes: RCCL is found and bound at run time, a communicator of one rank is built from a unique id, the
+container gather (all-gather of the sizes + root copy) and the broadcast run on it, a container larger
+than the slot is TC_ERR_CAPACITY.  The point-to-point transfers need a second GPU: the driver's run."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+import oracle as O
+
+pytestmark = pytest.mark.gpu
+
+
+def test_comm_world1_gather_and_broadcast():
+    import torch
+    import textcomp
+    from textcomp import Block
+    from textcomp.gather import NativeGather
+    ctx = textcomp.Context(0)
+    lib = ctx.lib
+    n = 1 << 20
+    t = O.gen_acgtn(0xC500, n)
+    d_text = torch.from_numpy(t).cuda()
+    cap = n + 2
+    d_cnt = torch.empty(cap, dtype=torch.int32, device="cuda")
+    d_val = torch.empty(cap, dtype=torch.int16, device="cuda")
+    blk = Block()
+    blk.nruns, blk.run_count, blk.run_value = cap, d_cnt.data_ptr(), d_val.data_ptr()
+    torch.cuda.synchronize()
+    assert lib.tc_encode_dev(ctx.handle, C.c_void_p(d_text.data_ptr()), n, C.byref(blk)) == 0
+    pcap = n + n // 4 + 4096
+    packed = torch.empty(pcap, dtype=torch.uint8, device="cuda")
+    torch.cuda.synchronize()
+    nb = C.c_uint64(pcap)
+    assert lib.tc_block_to_container_dev(ctx.handle, C.byref(blk), C.c_void_p(packed.data_ptr()), C.byref(nb)) == 0
+    g = NativeGather(ctx, pcap, torch.device("cuda", 0), depth=2)
+    for step in range(3):       # slots alternate; one exchange in flight
+        assert g.acquire() == step % 2
+        g.submit([nb.value], packed)
+    g.drain()
+    (hdr, got), = g.completed[-1]
+    assert hdr[0] == nb.value and torch.equal(got, packed[:nb.value])
+    back = torch.zeros(n, dtype=torch.uint8, device="cuda")
+    vb = Block()
+    vb.nruns, vb.run_count, vb.run_value = cap, d_cnt.data_ptr(), d_val.data_ptr()
+    pd = got.clone()
+    torch.cuda.synchronize()
+    assert lib.tc_container_to_block_dev(ctx.handle, C.c_void_p(pd.data_ptr()), nb.value, C.byref(vb)) == 0
+    assert lib.tc_decode_dev(ctx.handle, C.byref(vb), C.c_void_p(back.data_ptr())) == 0
+    assert np.array_equal(back.cpu().numpy(), t)
+    with pytest.raises(ValueError):     # larger than the slot: refused before anything moves
+        small = NativeGather(ctx, 1024, torch.device("cuda", 0))
+        small.submit([nb.value], packed)
+    x = torch.arange(1000, dtype=torch.uint8, device="cuda")
+    torch.cuda.synchronize()
+    g.broadcast(x)
+    assert torch.equal(x, torch.arange(1000, dtype=torch.uint8, device="cuda"))
+    g.close()
+    ctx.close()

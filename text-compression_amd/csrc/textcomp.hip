@@ -8,6 +8,7 @@
 #include "tc_decode_host.hpp"
 #include "tc_fm_host.hpp"
 #include "tc_pack.hpp"
+#include "tc_comm.hpp"
 #include "textcomp_debug.h"
 
 // ================================================================== context
@@ -1523,6 +1524,103 @@ int tc_fm_info(const tc_fm *fm, uint64_t *N, uint32_t *sigma, int16_t *c_sym, ui
     return TC_OK;
 }
 
+
+// ======================================================== multi-GPU exchange (RCCL, bound at run time)
+int tc_comm_unique_id(tc_ctx *ctx, uint8_t *id) {
+    TC_API_BEGIN(ctx)
+    if (!id) TC_FAIL(ctx, TC_ERR_ARG, "bad argument");
+    std::string why;
+    RcclApi *api = rccl_api(&why);
+    if (!api) TC_FAIL(ctx, TC_ERR_NCCL, "%s", why.c_str());
+    RcclId u;
+    const int r = api->GetUniqueId(&u);
+    if (r != 0) TC_FAIL(ctx, TC_ERR_NCCL, "ncclGetUniqueId -> %s", api->GetErrorString(r));
+    memcpy(id, u.internal, TC_COMM_ID_BYTES);
+    TC_API_END(ctx)
+}
+
+int tc_comm_create(tc_ctx *ctx, const uint8_t *id, int rank, int world, tc_comm **out) {
+    TC_API_BEGIN(ctx)
+    if (!id || !out || world < 1 || rank < 0 || rank >= world) TC_FAIL(ctx, TC_ERR_ARG, "bad argument");
+    *out = nullptr;
+    std::string why;
+    RcclApi *api = rccl_api(&why);
+    if (!api) TC_FAIL(ctx, TC_ERR_NCCL, "%s", why.c_str());
+    tc_comm *c = new tc_comm();
+    c->ctx = ctx; c->api = api; c->rank = rank; c->world = world;
+    try {
+        TC_HIP(ctx, hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+        TC_HIP(ctx, hipMalloc((void **)&c->d_words, (size_t)(1 + world) * sizeof(u64)));
+        TC_HIP(ctx, hipHostMalloc((void **)&c->h_words, (size_t)(1 + world) * sizeof(u64), hipHostMallocDefault));
+        RcclId u;
+        memcpy(u.internal, id, TC_COMM_ID_BYTES);
+        TC_NCCL(c, api->CommInitRank(&c->comm, world, u, rank));
+    } catch (...) {
+        comm_release(c);
+        throw;
+    }
+    *out = c;
+    TC_API_END(ctx)
+}
+
+void tc_comm_destroy(tc_comm *comm) { comm_release(comm); }
+
+int tc_comm_wait(tc_comm *c) {
+    if (!c) return TC_ERR_ARG;
+    tc_ctx *ctx = c->ctx;
+    TC_API_BEGIN(ctx)
+    TC_HIP(ctx, hipStreamSynchronize(c->stream));
+    c->inflight = false;
+    TC_API_END(ctx)
+}
+
+int tc_comm_gather(tc_comm *c, int root, const uint8_t *d_container, uint64_t bytes, uint8_t *d_recv,
+                   uint64_t slot_bytes, uint64_t *sizes) {
+    if (!c) return TC_ERR_ARG;
+    tc_ctx *ctx = c->ctx;
+    TC_API_BEGIN(ctx)
+    if (root < 0 || root >= c->world || !sizes || (bytes && !d_container) || (c->rank == root && !d_recv))
+        TC_FAIL(ctx, TC_ERR_ARG, "bad argument");
+    if (c->inflight) TC_FAIL(ctx, TC_ERR_ARG, "the previous gather has not been waited for");
+    hipStream_t s = c->stream;
+    // what the encoder produced on its stream must be there before the exchange reads it
+    TC_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    c->h_words[0] = bytes;
+    TC_HIP(ctx, hipMemcpyAsync(c->d_words, c->h_words, sizeof(u64), hipMemcpyHostToDevice, s));
+    TC_NCCL(c, c->api->AllGather(c->d_words, c->d_words + 1, 1, kNcclUint64, c->comm, s));
+    TC_HIP(ctx, hipMemcpyAsync(c->h_words + 1, c->d_words + 1, (size_t)c->world * sizeof(u64), hipMemcpyDeviceToHost, s));
+    TC_HIP(ctx, hipStreamSynchronize(s));
+    bool over = false;
+    for (int r = 0; r < c->world; r++) {
+        sizes[r] = c->h_words[1 + r];
+        over = over || sizes[r] > slot_bytes;
+    }
+    if (over) TC_FAIL(ctx, TC_ERR_CAPACITY, "a container exceeds the gather slot of %llu bytes", (unsigned long long)slot_bytes);
+    TC_NCCL(c, c->api->GroupStart());
+    if (c->rank == root) {
+        for (int r = 0; r < c->world; r++)
+            if (r != root && sizes[r])
+                TC_NCCL(c, c->api->Recv(d_recv + (size_t)r * slot_bytes, (size_t)sizes[r], kNcclUint8, r, c->comm, s));
+    } else if (bytes) {
+        TC_NCCL(c, c->api->Send(d_container, (size_t)bytes, kNcclUint8, root, c->comm, s));
+    }
+    TC_NCCL(c, c->api->GroupEnd());
+    if (c->rank == root && bytes)
+        TC_HIP(ctx, hipMemcpyAsync(d_recv + (size_t)root * slot_bytes, d_container, bytes, hipMemcpyDeviceToDevice, s));
+    c->inflight = true;
+    TC_API_END(ctx)
+}
+
+int tc_comm_broadcast(tc_comm *c, int root, uint8_t *d_buf, uint64_t bytes) {
+    if (!c) return TC_ERR_ARG;
+    tc_ctx *ctx = c->ctx;
+    TC_API_BEGIN(ctx)
+    if (root < 0 || root >= c->world || (bytes && !d_buf)) TC_FAIL(ctx, TC_ERR_ARG, "bad argument");
+    TC_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    if (bytes) TC_NCCL(c, c->api->Broadcast(d_buf, d_buf, (size_t)bytes, kNcclUint8, root, c->comm, c->stream));
+    TC_HIP(ctx, hipStreamSynchronize(c->stream));
+    TC_API_END(ctx)
+}
 
 int tc_dbg_checksum64_dev(tc_ctx *ctx, const void *d_p, uint64_t bytes, uint64_t *out) {
     TC_API_BEGIN(ctx)

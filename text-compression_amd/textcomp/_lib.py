@@ -7,13 +7,14 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(os.path.dirname(_HERE), "libtextcomp.so")
 
 TC_OK = 0
-TC_ERR_ARG, TC_ERR_CAPACITY, TC_ERR_MALFORMED, TC_ERR_HIP, TC_ERR_OOM, TC_ERR_INTERNAL = (
-    -1, -2, -3, -4, -5, -6)
+TC_ERR_ARG, TC_ERR_CAPACITY, TC_ERR_MALFORMED, TC_ERR_HIP, TC_ERR_OOM, TC_ERR_INTERNAL, TC_ERR_NCCL = (
+    -1, -2, -3, -4, -5, -6, -7)
+TC_COMM_ID_BYTES = 128
 TC_MAX_SIGMA = 257
 TC_MAX_ROUNDS = 40
 
 ERR_NAMES = {-1: "TC_ERR_ARG", -2: "TC_ERR_CAPACITY", -3: "TC_ERR_MALFORMED", -4: "TC_ERR_HIP",
-             -5: "TC_ERR_OOM", -6: "TC_ERR_INTERNAL"}
+             -5: "TC_ERR_OOM", -6: "TC_ERR_INTERNAL", -7: "TC_ERR_NCCL"}
 
 
 class TcError(RuntimeError):
@@ -91,6 +92,12 @@ SYMBOLS = [
     ("tc_fm_count_dev", _INT, [_P, _P, _P, _P, _U64, _P]),
     ("tc_fm_locate", _INT, [_P, _P, _P, _P, _U64, _P, _P, _PU64]),
     ("tc_fm_info", _INT, [_P, _PU64, _PU32, _P, _P, _PU64]),
+    ("tc_comm_unique_id", _INT, [_P, _P]),
+    ("tc_comm_create", _INT, [_P, _P, _INT, _INT, C.POINTER(_P)]),
+    ("tc_comm_destroy", None, [_P]),
+    ("tc_comm_gather", _INT, [_P, _INT, _P, _U64, _P, _U64, _PU64]),
+    ("tc_comm_wait", _INT, [_P]),
+    ("tc_comm_broadcast", _INT, [_P, _INT, _P, _U64]),
     ("tc_fm_export_bound", _U64, [_P, _INT]),
     ("tc_fm_export_dev", _INT, [_P, _P, _INT, _P, _PU64]),
     ("tc_fm_import_dev", _INT, [_P, _P, _U64, C.POINTER(_P)]),

@@ -131,3 +131,78 @@ def shard_patterns(npat, world, rank):
     per = (npat + world - 1) // world
     lo = min(rank * per, npat)
     return lo, min(lo + per, npat)
+
+
+class NativeGather:
+    """Same contract as BlockGather (acquire / submit / drain / completed), with the exchange done by the
+    library's own RCCL communicator behind the C ABI (tc_comm_*: what a Haskell or C caller would use).
+    torch.distributed only carries the 128-byte communicator id from rank 0 to the others, once.
+    One exchange is in flight at a time; it overlaps the encode of the next record."""
+
+    def __init__(self, ctx, cap_bytes, device, depth=2, group=None):
+        import ctypes as C
+        from . import _lib
+        self._C, self.ctx, self.lib = C, ctx, ctx.lib
+        self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        self.rank = dist.get_rank(group) if dist.is_initialized() else 0
+        self.device, self.cap, self.depth = device, (int(cap_bytes) + 255) & ~255, depth
+        idbuf = (C.c_uint8 * _lib.TC_COMM_ID_BYTES)()
+        if self.rank == 0:
+            ctx._check(self.lib.tc_comm_unique_id(ctx.handle, idbuf))
+        if self.world > 1:
+            box = [bytes(idbuf)]
+            dist.broadcast_object_list(box, src=0, group=group)
+            idbuf = (C.c_uint8 * _lib.TC_COMM_ID_BYTES).from_buffer_copy(box[0])
+        h = C.c_void_p()
+        ctx._check(self.lib.tc_comm_create(ctx.handle, idbuf, self.rank, self.world, C.byref(h)))
+        self._h = h
+        self._recv = ([torch.empty(self.world * self.cap, dtype=torch.uint8, device=device) for _ in range(depth)]
+                      if self.rank == 0 else [None] * depth)
+        self._pending = None    # (slot, sizes)
+        self._step = 0
+        self.completed = []
+
+    def _finish(self):
+        if self._pending is None:
+            return
+        slot, sizes = self._pending
+        self.ctx._check(self.lib.tc_comm_wait(self._h))
+        self._pending = None
+        if self.rank == 0:
+            buf = self._recv[slot]
+            self.completed.append([((int(sizes[r]),), buf[r * self.cap:r * self.cap + int(sizes[r])]) for r in range(self.world)])
+            while len(self.completed) > self.depth:
+                self.completed.pop(0)
+
+    def acquire(self):
+        self._finish()      # one exchange in flight: the caller's buffers and ours are free again
+        return self._step % self.depth
+
+    def submit(self, header, payload):
+        C = self._C
+        self._finish()
+        slot = self._step % self.depth
+        self._step += 1
+        sizes = (C.c_uint64 * self.world)()
+        recv = self._recv[slot]
+        rc = self.lib.tc_comm_gather(self._h, 0, C.c_void_p(payload.data_ptr()), int(header[0]),
+                                     C.c_void_p(recv.data_ptr()) if recv is not None else None, self.cap, sizes)
+        if rc == -2:
+            raise ValueError("packed block(s) exceed the gather capacity %d: sizes = %s" % (self.cap, list(sizes)))
+        self.ctx._check(rc)
+        self._pending = (slot, list(sizes))
+
+    def prime(self):
+        pass                # tc_comm_create has already built the communicator
+
+    def drain(self):
+        self._finish()
+
+    def broadcast(self, buf, root=0):
+        self.ctx._check(self.lib.tc_comm_broadcast(self._h, root, self._C.c_void_p(buf.data_ptr()), buf.numel()))
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._finish()
+            self.lib.tc_comm_destroy(self._h)
+            self._h = None
