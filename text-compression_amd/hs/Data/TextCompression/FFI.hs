@@ -11,6 +11,7 @@ import Foreign.Ptr (Ptr)
 
 data TcCtx
 data TcFm
+data TcComm
 
 foreign import ccall safe "tc_ctx_create"  c_tc_ctx_create  :: Int32 -> Ptr (Ptr TcCtx) -> IO Int32
 foreign import ccall safe "tc_ctx_destroy" c_tc_ctx_destroy :: Ptr TcCtx -> IO ()
@@ -60,3 +61,20 @@ foreign import ccall safe "tc_stream_info"
   c_tc_stream_info :: Ptr TcCtx -> Ptr Word8 -> Word64 -> Ptr Word64 -> Ptr Word64 -> IO Int32
 foreign import ccall safe "tc_decode_stream"
   c_tc_decode_stream :: Ptr TcCtx -> Ptr Word8 -> Word64 -> Ptr Word8 -> Ptr Word64 -> IO Int32
+-- the exchange of the multi-GPU path (one process per GPU; include/textcomp.h, tc_comm_*)
+foreign import ccall safe "tc_comm_unique_id"
+  c_tc_comm_unique_id :: Ptr TcCtx -> Ptr Word8 -> IO Int32
+foreign import ccall safe "tc_comm_create"
+  c_tc_comm_create :: Ptr TcCtx -> Ptr Word8 -> Int32 -> Int32 -> Ptr (Ptr TcComm) -> IO Int32
+foreign import ccall safe "tc_comm_destroy" c_tc_comm_destroy :: Ptr TcComm -> IO ()
+foreign import ccall safe "tc_comm_gather"
+  c_tc_comm_gather :: Ptr TcComm -> Int32 -> Ptr Word8 -> Word64 -> Ptr Word8 -> Word64 -> Ptr Word64 -> IO Int32
+foreign import ccall safe "tc_comm_wait" c_tc_comm_wait :: Ptr TcComm -> IO Int32
+foreign import ccall safe "tc_comm_broadcast"
+  c_tc_comm_broadcast :: Ptr TcComm -> Int32 -> Ptr Word8 -> Word64 -> IO Int32
+foreign import ccall unsafe "tc_fm_export_bound"
+  c_tc_fm_export_bound :: Ptr TcFm -> Int32 -> Word64
+foreign import ccall safe "tc_fm_export_dev"
+  c_tc_fm_export_dev :: Ptr TcCtx -> Ptr TcFm -> Int32 -> Ptr Word8 -> Ptr Word64 -> IO Int32
+foreign import ccall safe "tc_fm_import_dev"
+  c_tc_fm_import_dev :: Ptr TcCtx -> Ptr Word8 -> Word64 -> Ptr (Ptr TcFm) -> IO Int32
