@@ -278,7 +278,8 @@ def main():
             "gather": gathered,
             "stages_ms": {"suffix_sort+bwt": round(st.ms_sa, 3), "mtf": round(st.ms_mtf, 3), "rle": round(st.ms_rle, 3),
                           "rounds": int(st.rounds), "m": [int(st.m[i]) for i in range(st.rounds)],
-                          "passes": [int(st.passes[i]) for i in range(st.rounds)], "runs": int(st.runs)},
+                          "passes": [int(st.passes[i]) for i in range(st.rounds)], "runs": int(st.runs),
+                          "ticket_fallbacks": int(st.ticket_fallbacks)},
         }
         if not a.no_cpu_baseline and world == 1:   # the CPU port is timed at N = 1 only
             out["cpu_baseline"] = cpu_baseline(min(a.cpu_sample, n), seed)

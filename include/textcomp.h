@@ -80,6 +80,9 @@ typedef struct tc_stats {
                                         long texts over a small alphabet); radix_launches / ms_radix then time
                                         msd_partition_kernel (first launch reads the text: 1 + 12 B per suffix,
                                         the others 12 + 12 B) */
+    uint32_t ticket_fallbacks;       /* suffix sorts of this ctx that had to be redone with the single tile-ticket
+                                        counter because a look-back of the XCD-grouped ticket order ran into its
+                                        spin limit (LSD passes only; 0 in a healthy run, cumulative per ctx) */
 } tc_stats;
 
 /* The encoded block of the fused BWT -> MTF -> RLE pipeline.  The reference has

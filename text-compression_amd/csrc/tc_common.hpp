@@ -35,6 +35,7 @@ struct tc_ctx {
     int profile = 0;
     int num_cus = 0;
     int safe_tickets = 0;  // set after a look-back spin overflow: single ticket counter
+    u32 ticket_fallbacks = 0;  // how often that happened (reported in tc_stats)
     int pev_used = 0;
     std::string err;
     tc_stats stats = {};

@@ -193,9 +193,11 @@ static void sa_build(tc_ctx *ctx, Arena &A, const u8 *d_text, u64 n, u32 *d_sa, 
         if ((u32)ctx->h_scalars[62] & 2u) {
             tc_memset_async(ctx, ctx->d_err, 0, sizeof(u32));
             ctx->safe_tickets = 1;
+            ctx->ticket_fallbacks++;
             sa_run(ctx, b, d_text, n, d_sa, d_L, primary, counts256_out);
         }
     }
+    ctx->stats.ticket_fallbacks = ctx->ticket_fallbacks;
 }
 
 static void sa_run(tc_ctx *ctx, SaBuffers &b, const u8 *d_text, u64 n, u32 *d_sa, u8 *d_L,
