@@ -33,6 +33,9 @@
 #define MSD_GROUP 16          // pairs per store group: one 128-byte line of keys, half a line of values
 #endif
 #define MSD_GLOG (MSD_GROUP == 32 ? 5 : MSD_GROUP == 16 ? 4 : 3)
+#ifndef MSD_SUB
+#define MSD_SUB 1             // ranking counters per digit (1, 2 or 4)
+#endif
 #ifndef MSD_BPC
 #define MSD_BPC 1             // partition / counting workgroups per CU (LDS permitting)
 #endif
@@ -69,6 +72,7 @@ struct MsdLevel {
     u32 ntot;
     const u32 *cnt_in;   // [nparents * 256] (aligned levels)
     u32 *flags;          // device word: bit 3 = the joint counts of an aligned level do not add up
+    u64 *dbg;            // MSD_PROFILE builds: [8] cycles per phase of workgroup 0, wave 0
 };
 
 #ifdef __HIPCC__
@@ -375,8 +379,12 @@ __global__ __launch_bounds__(MSD_NT) void msd_partition_kernel(MsdLevel L, const
     // segment's first group are phantoms standing for the positions before the segment's range)
     __shared__ __attribute__((aligned(16))) u64 c_keys[256 * MSD_GROUP];
     __shared__ __attribute__((aligned(16))) u32 c_vals[256 * MSD_GROUP];
-    __shared__ u32 s_cnt[256], s_dstart[256], s_r[256], s_cur[256], s_ph[256];
-    __shared__ u32 s_scan[8];
+    // MSD_SUB counters per digit (a lane uses counter lane % MSD_SUB): fewer lanes of a wave meet on one
+    // LDS address in the ranking atomics; a digit's sub-segments lie side by side in the staging area
+    __shared__ u32 s_cnt[256 * MSD_SUB], s_dstart[256 * MSD_SUB], s_r[256], s_cur[256], s_ph[256];
+    __shared__ u32 s_scan[16];
+    __shared__ u64 s_lmask[4];
+    __shared__ u16 s_live[256];
     __shared__ u16 s_klut[KEYGEN ? 256 : 1];
     __shared__ u32 s_scan2[2];
     static_assert(MSD_GROUP == 8 || MSD_GROUP == 16 || MSD_GROUP == 32, "group = 8, 16 or 32 pairs");
@@ -385,7 +393,8 @@ __global__ __launch_bounds__(MSD_NT) void msd_partition_kernel(MsdLevel L, const
 
     const u32 tid = threadIdx.x, b = blockIdx.x, G = gridDim.x;
     if (KEYGEN && tid < 256) s_klut[tid] = kg.lut[tid];
-    if (tid < 256) { s_cnt[tid] = 0; s_r[tid] = 0; s_ph[tid] = 0; s_cur[tid] = 0; }
+    if (tid < 256) { s_r[tid] = 0; s_ph[tid] = 0; s_cur[tid] = 0; }
+    for (u32 i = tid; i < 256 * MSD_SUB; i += MSD_NT) s_cnt[i] = 0;
     if (tid == 0) {
         u32 ta = 0, tb = 0;
         if (!(L.aligned && (*L.flags & 8u))) msd_block_range(L, b, G, &ta, &tb);   // bad joint counts: do nothing
@@ -494,8 +503,27 @@ __global__ __launch_bounds__(MSD_NT) void msd_partition_kernel(MsdLevel L, const
         s_cur[tid] = sb & ~(u32)(MSD_GROUP - 1);
         s_ph[tid] = sb & (MSD_GROUP - 1);
         s_r[tid] = sb & (MSD_GROUP - 1);
+        // the digits this parent has at all (a DNA field: 125 of 256): they are dealt to the lane groups of
+        // the store phase in turn, so that every lane group serves the same number of digits
+        const u64 m = __ballot(L.ccnt[(size_t)qq * 256 + tid] != 0);
+        if ((tid & 63) == 0) s_lmask[tid >> 6] = m;
     };
     if (tid < 256) seg_init(s_info[0].q);
+    // The first tile comes by ordinary loads.  Their registers then pass through an empty asm: the compiler
+    // waits for them HERE and from then on regards them as asm-defined.  Otherwise its wait-count model
+    // carries "may still be in flight" into the loop and puts a vmcnt wait in front of the first use of
+    // every key register -- which, the asm-issued prefetch being invisible to that model, waits for the
+    // whole prefetch of the next tile: the overlap was gone (measured: 13 000 of a tile's 24 000 cycles).
+    auto detach = [&]() {
+        if (KEYGEN) {
+            asm volatile("" : "+v"(raw) : : "memory");
+        } else {
+            asm volatile("" : "+v"(key[0]), "+v"(key[1]), "+v"(key[2]), "+v"(key[3]), "+v"(val[0]), "+v"(val[1]), "+v"(val[2]), "+v"(val[3]) : : "memory");
+            if (MSD_ITEMS == 8)
+                asm volatile("" : "+v"(key[MSD_ITEMS - 4]), "+v"(key[MSD_ITEMS - 3]), "+v"(key[MSD_ITEMS - 2]), "+v"(key[MSD_ITEMS - 1]),
+                                  "+v"(val[MSD_ITEMS - 4]), "+v"(val[MSD_ITEMS - 3]), "+v"(val[MSD_ITEMS - 2]), "+v"(val[MSD_ITEMS - 1]) : : "memory");
+        }
+    };
     if (KEYGEN) {
         if (!kg_edge(s_info[0])) raw = kg_load_plain(s_info[0]);
     } else {
@@ -503,21 +531,31 @@ __global__ __launch_bounds__(MSD_NT) void msd_partition_kernel(MsdLevel L, const
 #pragma unroll
         for (int k = 0; k < MSD_ITEMS; k++) {
             const u32 p = k * MSD_NT + tid;
+            key[k] = 0;
+            val[k] = 0;
             if (p < f.valid) {
                 key[k] = kin[f.base + p];
                 val[k] = vin[f.base + p];
             }
         }
     }
+    detach();
 
     for (u32 t = t0; t < t1; t++) {
         const u32 slot = (t - t0) & 3u;
         const MsdTileInfo ti = s_info[slot];
+#ifdef MSD_PROFILE
+        u64 tq[8];
+        tq[0] = __builtin_readcyclecounter();
+#endif
         if (tid == 0) msd_cur_info(L, cs, t + 3, t1, &s_info[(slot + 3) & 3u]);
         __syncthreads();   // (B0) s_cnt zeroed; staging free; carries / ranges of this segment in place
         const MsdTileInfo nx = s_info[(slot + 1) & 3u];
         prefetch(ti, nx);   // tile t + 1: in flight while tile t is ranked and staged
-        if (KEYGEN && kg_edge(ti)) raw = kg_load_plain(ti);   // first / last tile: ordinary loads, bounds-checked
+        if (KEYGEN && kg_edge(ti)) {   // first / last tile: ordinary loads, bounds-checked
+            raw = kg_load_plain(ti);
+            detach();
+        }
         const bool fastkg = KEYGEN && kg.s <= 3 && MSD_ITEMS == 8 && !kg_edge(ti);
         if (fastkg) {
             // interior tile, fields of <= 3 symbols: thread t builds the keys of the 8 CONSECUTIVE suffixes
@@ -618,43 +656,70 @@ __global__ __launch_bounds__(MSD_NT) void msd_partition_kernel(MsdLevel L, const
             }
             __syncthreads();   // image dead: the staging area may be written
         }
+#ifdef MSD_PROFILE
+        tq[1] = __builtin_readcyclecounter();
+#endif
         // (S1) digit + rank inside the digit (any order: the partition need not be stable)
         u32 dig[MSD_ITEMS], rnk[MSD_ITEMS];
 #pragma unroll
         for (int k = 0; k < MSD_ITEMS; k++) {
             const u32 p = k * MSD_NT + tid;
             dig[k] = (u32)(key[k] >> L.shift) & 255u;
-            if (p < ti.valid) rnk[k] = atomicAdd(&s_cnt[dig[k]], 1u);
+            if (p < ti.valid) rnk[k] = atomicAdd(&s_cnt[dig[k] * MSD_SUB + (tid % MSD_SUB)], 1u);
         }
         __syncthreads();   // (B1)
-        // (S2) start of every digit's segment in the staging area
-        if (tid < 256) {
-            const u32 c = s_cnt[tid];
-            const u32 inc = wave_incl_sum(c);
-            if ((tid & 63) == 63) s_scan[tid >> 6] = inc;
-            s_dstart[tid] = inc - c;   // wave-relative for now
-        }
-        __syncthreads();   // (B2a)
-        if (tid < 256) {
-            u32 base = 0;
-            for (u32 i = 0; i < (tid >> 6); i++) base += s_scan[i];
-            s_dstart[tid] += base;
+#ifdef MSD_PROFILE
+        tq[2] = __builtin_readcyclecounter();
+#endif
+        // (S2) start of every (digit, sub-counter) segment in the staging area
+        {
+            constexpr u32 NC = 256 * MSD_SUB;
+            if (tid < NC) {
+                const u32 c = s_cnt[tid];
+                const u32 inc = wave_incl_sum(c);
+                if ((tid & 63) == 63) s_scan[tid >> 6] = inc;
+                s_dstart[tid] = inc - c;   // wave-relative for now
+            }
+            __syncthreads();   // (B2a)
+            if (tid < NC) {
+                u32 base = 0;
+                for (u32 i = 0; i < (tid >> 6); i++) base += s_scan[i];
+                s_dstart[tid] += base;
+            }
+            if (tid < 256) {   // list of the parent's digits (rebuilt per tile: a few instructions)
+                const u32 w = tid >> 6;
+                const u64 mine = s_lmask[w];
+                if ((mine >> (tid & 63)) & 1ull) {
+                    u32 pos = (u32)__popcll(mine & ((1ull << (tid & 63)) - 1ull));
+                    for (u32 i = 0; i < w; i++) pos += (u32)__popcll(s_lmask[i]);
+                    s_live[pos] = (u16)tid;
+                }
+            }
         }
         __syncthreads();   // (B2)
+#ifdef MSD_PROFILE
+        tq[3] = __builtin_readcyclecounter();
+#endif
         // (S3) the tile, sorted by digit, into the staging area
 #pragma unroll
         for (int k = 0; k < MSD_ITEMS; k++) {
             const u32 p = k * MSD_NT + tid;
             if (p < ti.valid) {
-                const u32 o = s_dstart[dig[k]] + rnk[k];
+                const u32 o = s_dstart[dig[k] * MSD_SUB + (tid % MSD_SUB)] + rnk[k];
                 s_keys[o] = key[k];
                 // (KEYGEN: the value is the suffix start -- which suffix slot k of this thread holds
                 // depends on the key-generation form used for the tile)
                 s_vals[o] = KEYGEN ? ti.base + (fastkg ? 8 * tid + k : p) : val[k];
             }
         }
+#ifdef MSD_PROFILE
+        tq[4] = __builtin_readcyclecounter();
+#endif
         // the next tile's pairs take the registers over; nothing younger than their loads is outstanding
         land();
+#ifdef MSD_PROFILE
+        tq[5] = __builtin_readcyclecounter();
+#endif
         if (KEYGEN) {
             raw = nraw;
         } else {
@@ -665,16 +730,23 @@ __global__ __launch_bounds__(MSD_NT) void msd_partition_kernel(MsdLevel L, const
             }
         }
         __syncthreads();   // (B3)
+#ifdef MSD_PROFILE
+        tq[6] = __builtin_readcyclecounter();
+#endif
         // (S4) every digit belongs to one lane group of MSD_GROUP lanes (digits g, g + NG, ...): it stores
         // the whole groups of (carry ++ segment) -- group k = elements [G k, G k + G) -- and then keeps what
         // is left as the new carry.  No other lane group touches the digit's state: no barrier in between.
         {
             constexpr u32 NG = MSD_NT / MSD_GROUP;
             const u32 lg = tid / MSD_GROUP, l = tid % MSD_GROUP;
-            for (u32 d = lg; d < 256; d += NG) {
-                const u32 c = s_cnt[d];
+            const u32 nlive = (u32)(__popcll(s_lmask[0]) + __popcll(s_lmask[1]) + __popcll(s_lmask[2]) + __popcll(s_lmask[3]));
+            for (u32 j = lg; j < nlive; j += NG) {
+                const u32 d = s_live[j];
+                u32 c = 0;
+#pragma unroll
+                for (int x = 0; x < MSD_SUB; x++) c += s_cnt[d * MSD_SUB + x];
                 if (c == 0) continue;
-                const u32 r = s_r[d], ds = s_dstart[d], cur = s_cur[d], ph = s_ph[d];
+                const u32 r = s_r[d], ds = s_dstart[d * MSD_SUB], cur = s_cur[d], ph = s_ph[d];
                 const u32 ng = (r + c) >> MSD_GLOG;
                 for (u32 k = 0; k < ng; k++) {
                     const u32 e = k * MSD_GROUP + l;
@@ -709,10 +781,20 @@ __global__ __launch_bounds__(MSD_NT) void msd_partition_kernel(MsdLevel L, const
                         s_cur[d] = cur + ng * MSD_GROUP;
                         s_ph[d] = 0;
                     }
-                    s_cnt[d] = 0;
+#pragma unroll
+                    for (int x = 0; x < MSD_SUB; x++) s_cnt[d * MSD_SUB + x] = 0;
                 }
             }
         }
+#ifdef MSD_PROFILE
+        tq[7] = __builtin_readcyclecounter();
+        if (b == 0 && tid == 0 && L.dbg) {
+            // [0] top..B0 (tile cursor, barrier)  [1] key generation  [2] S1 + B1  [3] S2 + barriers
+            // [4] S3  [5] wait for the prefetch  [6] B3  [7] S4
+            L.dbg[0] += tq[1] - tq[0]; L.dbg[2] += tq[2] - tq[1]; L.dbg[3] += tq[3] - tq[2]; L.dbg[4] += tq[4] - tq[3];
+            L.dbg[5] += tq[5] - tq[4]; L.dbg[6] += tq[6] - tq[5]; L.dbg[7] += tq[7] - tq[6]; L.dbg[1] += 1;
+        }
+#endif
         if (ti.last) {
             // end of the segment: the carries go to their exact places (partial lines, once per
             // segment and digit); then the next segment's ranges are taken
