@@ -432,7 +432,7 @@ static void sa_run(tc_ctx *ctx, SaBuffers &b, const u8 *d_text, u64 n, u32 *d_sa
                     ML.cstart = b.msd_pstart[l + 1]; ML.ccnt = b.msd_pcnt[l + 1];
                     ML.aligned = (joint && l == MSD_LEVELS - 1) ? 1 : 0;
                     ML.ntot = (u32)N; ML.cnt_in = b.msd_joint; ML.flags = counters + 1;
-                    ML.dbg = ctx->d_scalars + 32 + 8 * l;
+                    ML.dbg = ctx->d_scalars + 64 + 16 * l;
                     const u64 *kin = l ? kbuf[(l - 1) & 1] : nullptr;
                     const u32 *vin = l ? vbuf[(l - 1) & 1] : nullptr;
                     msd_prep_kernel<<<1, 1024, 0, s>>>(ML.pcnt, np, b.msd_tpre[l]);
@@ -469,15 +469,19 @@ static void sa_run(tc_ctx *ctx, SaBuffers &b, const u8 *d_text, u64 n, u32 *d_sa
                 st.msd_path = 1;
 #ifdef MSD_PROFILE
                 {   // cycles per phase of workgroup 0 / thread 0, per level (diagnostic build only)
-                    u64 h[24];
-                    tc_d2h(ctx, h, ctx->d_scalars + 32, sizeof h);
+                    u64 h[48];
+                    tc_d2h(ctx, h, ctx->d_scalars + 64, sizeof h);
                     TC_HIP(ctx, hipStreamSynchronize(s));
                     for (int l = 0; l < MSD_LEVELS; l++)
                         fprintf(stderr, "msd level %d: tiles %llu | cursor+B0 %llu keygen/S1+B1 %llu S2 %llu S3 %llu land %llu B3 %llu S4 %llu (cycles per tile)\n", l + 1,
-                                (unsigned long long)h[8 * l + 1], (unsigned long long)(h[8 * l] / (h[8 * l + 1] | 1)), (unsigned long long)(h[8 * l + 2] / (h[8 * l + 1] | 1)),
-                                (unsigned long long)(h[8 * l + 3] / (h[8 * l + 1] | 1)), (unsigned long long)(h[8 * l + 4] / (h[8 * l + 1] | 1)), (unsigned long long)(h[8 * l + 5] / (h[8 * l + 1] | 1)),
-                                (unsigned long long)(h[8 * l + 6] / (h[8 * l + 1] | 1)), (unsigned long long)(h[8 * l + 7] / (h[8 * l + 1] | 1)));
-                    tc_memset_async(ctx, ctx->d_scalars + 32, 0, sizeof h);
+                                (unsigned long long)h[16 * l + 1], (unsigned long long)(h[16 * l] / (h[16 * l + 1] | 1)), (unsigned long long)(h[16 * l + 2] / (h[16 * l + 1] | 1)),
+                                (unsigned long long)(h[16 * l + 3] / (h[16 * l + 1] | 1)), (unsigned long long)(h[16 * l + 4] / (h[16 * l + 1] | 1)), (unsigned long long)(h[16 * l + 5] / (h[16 * l + 1] | 1)),
+                                (unsigned long long)(h[16 * l + 6] / (h[16 * l + 1] | 1)), (unsigned long long)(h[16 * l + 7] / (h[16 * l + 1] | 1)));
+                    for (int l = 0; l < MSD_LEVELS; l++)
+                        fprintf(stderr, "   level %d, S1 alone per tile: wave 0 %llu, last wave %llu cycles; slowest wave B0 -> before B1 %llu, B0 -> prefetch issued %llu\n", l + 1,
+                                (unsigned long long)(h[16 * l + 8] / (h[16 * l + 1] | 1)), (unsigned long long)(h[16 * l + 9] / (h[16 * l + 1] | 1)),
+                                (unsigned long long)(h[16 * l + 10] / (h[16 * l + 1] | 1)), (unsigned long long)(h[16 * l + 11] / (h[16 * l + 1] | 1)));
+                    tc_memset_async(ctx, ctx->d_scalars + 64, 0, sizeof h);
                 }
 #endif
             } else {

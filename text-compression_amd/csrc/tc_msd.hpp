@@ -72,7 +72,7 @@ struct MsdLevel {
     u32 ntot;
     const u32 *cnt_in;   // [nparents * 256] (aligned levels)
     u32 *flags;          // device word: bit 3 = the joint counts of an aligned level do not add up
-    u64 *dbg;            // MSD_PROFILE builds: [8] cycles per phase of workgroup 0, wave 0
+    u64 *dbg;            // MSD_PROFILE builds: [16] cycles per phase of workgroup 0 (wave 0; [9]: the last wave)
 };
 
 #ifdef __HIPCC__
@@ -384,6 +384,10 @@ __global__ __launch_bounds__(MSD_NT) void msd_partition_kernel(MsdLevel L, const
     __shared__ u32 s_cnt[256 * MSD_SUB], s_dstart[256 * MSD_SUB], s_r[256], s_cur[256], s_ph[256];
     __shared__ u32 s_scan[16];
     __shared__ u64 s_lmask[4];
+#ifdef MSD_PROFILE
+    __shared__ u64 s_dbg[2];
+    if (threadIdx.x == 0) { s_dbg[0] = 0; s_dbg[1] = 0; }
+#endif
     __shared__ u16 s_live[256];
     __shared__ u16 s_klut[KEYGEN ? 256 : 1];
     __shared__ u32 s_scan2[2];
@@ -420,8 +424,8 @@ __global__ __launch_bounds__(MSD_NT) void msd_partition_kernel(MsdLevel L, const
     static_assert(KG_SLOTS * 5 <= MSD_TILE * 8, "key-generation image must fit under the staging keys");
     const u32 kg_units = KEYGEN ? (KG_PRE + MSD_TILE + kg.P * kg.s + kg.s + 15) / 16 : 0;
 
-    u64 key[MSD_ITEMS], nkey[MSD_ITEMS];
-    u32 val[MSD_ITEMS], nval[MSD_ITEMS];
+    u64 key[MSD_ITEMS];
+    u32 val[MSD_ITEMS];
     msd_u32x4 raw = {0, 0, 0, 0}, nraw = {0, 0, 0, 0};
     // KEYGEN: 16 text bytes per thread from position base - KG_PRE + 16 * tid (bytes outside the text: 0).
     // A tile is an "edge" tile when some unit reaches outside the text or the text is not 16-byte
@@ -456,6 +460,29 @@ __global__ __launch_bounds__(MSD_NT) void msd_partition_kernel(MsdLevel L, const
     // clamped, valid address; a register they fill is defined by the asm alone, never merged with
     // another value before it has landed -- and (ii) every such register passes through land() before
     // anything reads it.
+    // plain levels: thread t holds the pairs of two quads of 4 CONSECUTIVE positions (4 t .. 4 t + 3 of each
+    // 4096-pair half): 16-byte loads -- 6 load instructions per thread and tile instead of 16, so the waves
+    // get past the issue of the prefetch quickly (with 16 narrow loads per thread the load queue filled up
+    // and every wave sat at the issue until HBM had taken the burst: ~10 000 of a tile's 24 000 cycles)
+    msd_u32x4 nk4[MSD_ITEMS / 2], nv4[MSD_ITEMS / 4];
+    auto pof = [&](int k) -> u32 {
+        return KEYGEN ? (u32)k * MSD_NT + tid : (u32)(k >> 2) * (4 * MSD_NT) + 4 * tid + (u32)(k & 3);
+    };
+    // a tile whose whole extent lies inside the arrays can be fetched without bounds (pairs past `valid`
+    // are read and ignored); the one tile that reaches past the arrays' end is loaded pair by pair
+    auto tile_safe = [&](const MsdTileInfo x) { return x.valid != 0 && (u64)x.base + MSD_TILE <= (u64)L.ntot; };
+    auto load_plain = [&](const MsdTileInfo f) {
+#pragma unroll
+        for (int k = 0; k < MSD_ITEMS; k++) {
+            const u32 p = pof(k);
+            key[k] = 0;
+            val[k] = 0;
+            if (p < f.valid) {
+                key[k] = kin[f.base + p];
+                val[k] = vin[f.base + p];
+            }
+        }
+    };
     auto prefetch = [&](const MsdTileInfo cur_ti, const MsdTileInfo nx) {
         if (KEYGEN) {
             const bool use = nx.valid != 0 && !kg_edge(nx);
@@ -466,16 +493,14 @@ __global__ __launch_bounds__(MSD_NT) void msd_partition_kernel(MsdLevel L, const
                                         : reinterpret_cast<const u8 *>((((uintptr_t)text) + 15) & ~(uintptr_t)15);
             asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(nraw) : "v"(src) : "memory");
         } else {
-            const u32 nv = nx.valid ? nx.valid : cur_ti.valid;
-            const u32 nb = nx.valid ? nx.base : cur_ti.base;
-            const u64 *kt = kin + nb;
-            const u32 *vt = vin + nb;
+            const u32 nb = tile_safe(nx) ? nx.base : 0u;   // (an unsafe or absent next tile: any valid tile)
 #pragma unroll
-            for (int k = 0; k < MSD_ITEMS; k++) {
-                u32 p = k * MSD_NT + tid;
-                p = p < nv ? p : nv - 1;
-                asm volatile("global_load_dwordx2 %0, %1, off" : "=v"(nkey[k]) : "v"(kt + p) : "memory");
-                asm volatile("global_load_dword %0, %1, off" : "=v"(nval[k]) : "v"(vt + p) : "memory");
+            for (int g = 0; g < MSD_ITEMS / 4; g++) {
+                const u64 *kp = kin + nb + (u32)g * (4 * MSD_NT) + 4 * tid;
+                const u32 *vp = vin + nb + (u32)g * (4 * MSD_NT) + 4 * tid;
+                asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(nk4[2 * g]) : "v"(kp) : "memory");
+                asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(nk4[2 * g + 1]) : "v"(kp + 2) : "memory");
+                asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(nv4[g]) : "v"(vp) : "memory");
             }
         }
     };
@@ -484,18 +509,14 @@ __global__ __launch_bounds__(MSD_NT) void msd_partition_kernel(MsdLevel L, const
             asm volatile("s_waitcnt vmcnt(0)" : "+v"(nraw) : : "memory");
         } else {
             static_assert(MSD_ITEMS == 4 || MSD_ITEMS == 8, "land() lists the prefetch registers");
-            asm volatile("s_waitcnt vmcnt(0)"
-                         : "+v"(nkey[0]), "+v"(nkey[1]), "+v"(nkey[2]), "+v"(nkey[3]), "+v"(nval[0]), "+v"(nval[1]),
-                           "+v"(nval[2]), "+v"(nval[3])
-                         :
-                         : "memory");
             if (MSD_ITEMS == 8)
                 asm volatile("s_waitcnt vmcnt(0)"
-                             : "+v"(nkey[MSD_ITEMS - 4]), "+v"(nkey[MSD_ITEMS - 3]), "+v"(nkey[MSD_ITEMS - 2]),
-                               "+v"(nkey[MSD_ITEMS - 1]), "+v"(nval[MSD_ITEMS - 4]), "+v"(nval[MSD_ITEMS - 3]),
-                               "+v"(nval[MSD_ITEMS - 2]), "+v"(nval[MSD_ITEMS - 1])
+                             : "+v"(nk4[0]), "+v"(nk4[1]), "+v"(nk4[MSD_ITEMS / 2 - 2]), "+v"(nk4[MSD_ITEMS / 2 - 1]), "+v"(nv4[0]),
+                               "+v"(nv4[MSD_ITEMS / 4 - 1])
                              :
                              : "memory");
+            else
+                asm volatile("s_waitcnt vmcnt(0)" : "+v"(nk4[0]), "+v"(nk4[1]), "+v"(nv4[0]) : : "memory");
         }
     };
     auto seg_init = [&](u32 qq) {   // threads < 256
@@ -527,17 +548,7 @@ __global__ __launch_bounds__(MSD_NT) void msd_partition_kernel(MsdLevel L, const
     if (KEYGEN) {
         if (!kg_edge(s_info[0])) raw = kg_load_plain(s_info[0]);
     } else {
-        const MsdTileInfo f = s_info[0];
-#pragma unroll
-        for (int k = 0; k < MSD_ITEMS; k++) {
-            const u32 p = k * MSD_NT + tid;
-            key[k] = 0;
-            val[k] = 0;
-            if (p < f.valid) {
-                key[k] = kin[f.base + p];
-                val[k] = vin[f.base + p];
-            }
-        }
+        load_plain(s_info[0]);
     }
     detach();
 
@@ -550,10 +561,17 @@ __global__ __launch_bounds__(MSD_NT) void msd_partition_kernel(MsdLevel L, const
 #endif
         if (tid == 0) msd_cur_info(L, cs, t + 3, t1, &s_info[(slot + 3) & 3u]);
         __syncthreads();   // (B0) s_cnt zeroed; staging free; carries / ranges of this segment in place
+#ifdef MSD_PROFILE
+        const u64 t_b0 = __builtin_readcyclecounter();
+#endif
         const MsdTileInfo nx = s_info[(slot + 1) & 3u];
         prefetch(ti, nx);   // tile t + 1: in flight while tile t is ranked and staged
         if (KEYGEN && kg_edge(ti)) {   // first / last tile: ordinary loads, bounds-checked
             raw = kg_load_plain(ti);
+            detach();
+        }
+        if (!KEYGEN && t != t0 && !tile_safe(ti)) {   // the tile that reaches past the arrays' end: pair by pair
+            load_plain(ti);
             detach();
         }
         const bool fastkg = KEYGEN && kg.s <= 3 && MSD_ITEMS == 8 && !kg_edge(ti);
@@ -663,13 +681,22 @@ __global__ __launch_bounds__(MSD_NT) void msd_partition_kernel(MsdLevel L, const
         u32 dig[MSD_ITEMS], rnk[MSD_ITEMS];
 #pragma unroll
         for (int k = 0; k < MSD_ITEMS; k++) {
-            const u32 p = k * MSD_NT + tid;
+            const u32 p = pof(k);
             dig[k] = (u32)(key[k] >> L.shift) & 255u;
             if (p < ti.valid) rnk[k] = atomicAdd(&s_cnt[dig[k] * MSD_SUB + (tid % MSD_SUB)], 1u);
         }
+#ifdef MSD_PROFILE
+        const u64 t_s1 = __builtin_readcyclecounter();   // S1 issued and its LDS returns waited for (s_memtime is lgkm too)
+        if ((tid & 63) == 0) {   // slowest wave from the end of B0 to its arrival at B1, and to the end of the prefetch issue
+            atomicMax((unsigned long long *)&s_dbg[0], (unsigned long long)(t_s1 - t_b0));
+            atomicMax((unsigned long long *)&s_dbg[1], (unsigned long long)(tq[1] - t_b0));
+        }
+#endif
         __syncthreads();   // (B1)
 #ifdef MSD_PROFILE
         tq[2] = __builtin_readcyclecounter();
+        if (b == 0 && L.dbg && (tid == 0 || tid == MSD_NT - 64)) L.dbg[tid == 0 ? 8 : 9] += t_s1 - tq[1];
+        if (b == 0 && L.dbg && tid == 0) { L.dbg[10] += s_dbg[0]; L.dbg[11] += s_dbg[1]; s_dbg[0] = 0; s_dbg[1] = 0; }
 #endif
         // (S2) start of every (digit, sub-counter) segment in the staging area
         {
@@ -703,7 +730,7 @@ __global__ __launch_bounds__(MSD_NT) void msd_partition_kernel(MsdLevel L, const
         // (S3) the tile, sorted by digit, into the staging area
 #pragma unroll
         for (int k = 0; k < MSD_ITEMS; k++) {
-            const u32 p = k * MSD_NT + tid;
+            const u32 p = pof(k);
             if (p < ti.valid) {
                 const u32 o = s_dstart[dig[k] * MSD_SUB + (tid % MSD_SUB)] + rnk[k];
                 s_keys[o] = key[k];
@@ -725,8 +752,10 @@ __global__ __launch_bounds__(MSD_NT) void msd_partition_kernel(MsdLevel L, const
         } else {
 #pragma unroll
             for (int k = 0; k < MSD_ITEMS; k++) {
-                key[k] = nkey[k];
-                val[k] = nval[k];
+                const msd_u32x4 q4 = nk4[k >> 1];
+                key[k] = (k & 1) ? ((u64)q4.w << 32 | q4.z) : ((u64)q4.y << 32 | q4.x);
+                const msd_u32x4 v4 = nv4[k >> 2];
+                val[k] = (k & 3) == 0 ? v4.x : (k & 3) == 1 ? v4.y : (k & 3) == 2 ? v4.z : v4.w;
             }
         }
         __syncthreads();   // (B3)

@@ -340,10 +340,10 @@ int tc_ctx_create(int device, tc_ctx **out) {
         }
         TC_HIP(ctx, hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking));
         TC_HIP(ctx, hipMalloc((void **)&ctx->d_err, 256));
-        TC_HIP(ctx, hipMalloc((void **)&ctx->d_scalars, 64 * sizeof(u64)));
+        TC_HIP(ctx, hipMalloc((void **)&ctx->d_scalars, 128 * sizeof(u64)));
         TC_HIP(ctx, hipHostMalloc((void **)&ctx->h_scalars, 64 * sizeof(u64), hipHostMallocDefault));
         TC_HIP(ctx, hipMemsetAsync(ctx->d_err, 0, 256, ctx->stream));
-        TC_HIP(ctx, hipMemsetAsync(ctx->d_scalars, 0, 64 * sizeof(u64), ctx->stream));
+        TC_HIP(ctx, hipMemsetAsync(ctx->d_scalars, 0, 128 * sizeof(u64), ctx->stream));
         for (int i = 0; i < 8; i++) TC_HIP(ctx, hipEventCreate(&ctx->ev[i]));
         for (int i = 0; i < 32; i++) TC_HIP(ctx, hipEventCreate(&ctx->pev[i]));
         TC_HIP(ctx, hipStreamSynchronize(ctx->stream));
