@@ -1,26 +1,36 @@
 // tc_msd.hpp -- round 0 of the suffix sort for small alphabets as an MSD radix sort.
 //
-// Replaces (for long texts over <= 15 byte values: DNA records) the LSD passes of tc_radix.hpp +
-// finish_kernel in front of `DS.unstableSortOn snd` (reference BWT/Internal.hs:130).
+// Replaces (for long texts over <= 15 byte values that look iid: the DNA benchmark record) the LSD
+// passes of tc_radix.hpp + finish_kernel in front of `DS.unstableSortOn snd` (reference
+// BWT/Internal.hs:130).
 //
 // Why MSD here.  An LSD pass must be STABLE, which on a GPU means: ranks by wave-ordered match,
 // tiles in ticket order, a decoupled look-back per digit, and scattered segments of ~33 pairs that
 // start at arbitrary alignment (every seam a partially written 128-byte line; measured in round 1:
 // 7.8 ms for the access pattern alone against 5.0 ms for the same bytes in whole lines).  An MSD
 // pass only has to PARTITION: the order inside a bucket is irrelevant, because the bucket is sorted
-// again by the next field.  That removes the look-back, the ticket and the stable ranking, and it
-// allows software write combining: a workgroup keeps, per digit, the pairs that do not yet fill a
-// 32-pair group (256 B of keys + 128 B of values) in LDS and only ever stores whole, line-aligned
-// groups.  Positions are exact (no atomics, no holes): a counting kernel with the SAME static
-// work split gives every (workgroup, parent bucket) segment its private range in every child.
+// again by the next field.  That removes the look-back, the ticket and the stable ranking (one LDS
+// atomic per pair ranks it), and it allows software write combining: a workgroup keeps, per digit,
+// the pairs that do not yet fill a 16-pair group (128 B of keys + 64 B of values) in LDS and only
+// ever stores whole, aligned groups.  Positions are exact (no atomics, no holes): a counting kernel
+// with the SAME static work split gives every (workgroup, parent bucket) segment its private range in
+// every child.  Measured (1 GiB ACGTN): HBM traffic = 1.007 x the algorithmic bytes, and a level runs at
+// ~0.8 of the device's copy rate -- its tile is a read burst and a write burst that HBM serves one
+// after the other, with the LDS work hidden behind them.
 //
 //   level 1   text -> (key, idx) partitioned by field 0           1 B read, 12 B written per suffix
-//   level 2,3 partitioned inside each parent by field 1, 2        12 B read, 12 B written
-//   finish    each level-3 bucket (9 symbols on DNA, ~550 suffixes at 1 GiB) is ordered by the
-//             remaining 32 key bits inside one wave's LDS image (counting sort by field 3, then
-//             ranks inside the ~4-member bins); SA, last column and the tied set leave from there
-//             (same contract as finish_kernel)                    12 B read, 5 B written
-// A text whose level-3 buckets exceed MSDF_CAP (repeats, runs) takes the LSD path instead.
+//   level 2   inside each level-1 bucket by field 1; its counting pass also gathers the joint
+//             (field 1, field 2) counts, i.e. level 3's child counts  12 B read, 12 B written (+ 8 B counted)
+//   level 3   inside each level-2 bucket by field 2; "aligned": every parent belongs to one
+//             workgroup, so it needs no counting pass of its own   12 B read, 12 B written
+//   finish    the level-3 buckets (9 symbols on DNA, ~550 suffixes at 1 GiB) are taken in chunks of
+//             <= MSDF_CH consecutive buckets / MSDF_TILE pairs and ordered by the remaining 32 key bits
+//             in LDS (counting sort by 17 key bits, then ranks inside the ~2-member bins); SA, last
+//             column and the tied set leave from there (same contract as finish_kernel)
+//                                                                 12 B read, 5 B written
+// A text with a level-3 bucket above MSDF_CAP, or with more than 2^18 suffixes tied beyond the key
+// (repeats, runs), takes the LSD way instead; the host does not even try when the byte entropy or the
+// collision sample say the text is not iid-like (tc_encode_host.hpp).
 #pragma once
 #include "tc_sa.hpp"
 
