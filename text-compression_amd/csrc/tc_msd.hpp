@@ -945,10 +945,9 @@ __global__ __launch_bounds__(MSDF_NT) void msd_finish_kernel(MsdFinishArgs a) {
 #pragma unroll
         for (int k = 0; k < MSDF_ITEMS; k++) {
             const u32 i = k * MSDF_NT + tid;
-            if (i < tot) {
+            if (i < tot) {   // (the packed result is taken apart later: no wait between the atomics)
                 const u32 bin = bin_of(key[k], c0);
-                const u32 old = atomicAdd(&s_off[bin >> 1], (bin & 1) ? 0x10000u : 1u);
-                pos[k] = (old >> (16 * (bin & 1))) & 0xffffu;
+                pos[k] = atomicAdd(&s_off[bin >> 1], (bin & 1) ? 0x10000u : 1u);
             }
         }
         __syncthreads();
@@ -975,7 +974,8 @@ __global__ __launch_bounds__(MSDF_NT) void msd_finish_kernel(MsdFinishArgs a) {
         for (int k = 0; k < MSDF_ITEMS; k++) {
             const u32 i = k * MSDF_NT + tid;
             if (i < tot) {
-                pos[k] += off_at(bin_of(key[k], c0));
+                const u32 bin = bin_of(key[k], c0);
+                pos[k] = ((pos[k] >> (16 * (bin & 1))) & 0xffffu) + off_at(bin);
                 s_low[pos[k]] = (u32)(key[k] >> 8);
             }
         }
