@@ -503,11 +503,17 @@ __global__ __launch_bounds__(MSD_NT) void msd_partition_kernel(MsdLevel L, const
                                         : reinterpret_cast<const u8 *>((((uintptr_t)text) + 15) & ~(uintptr_t)15);
             asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(nraw) : "v"(src) : "memory");
         } else {
-            const u32 nb = tile_safe(nx) ? nx.base : 0u;   // (an unsafe or absent next tile: any valid tile)
+            const bool safe = tile_safe(nx);
+            const u32 nb = safe ? nx.base : 0u;   // (an unsafe or absent next tile: any valid tile)
+            const u32 nv = safe ? nx.valid : (u32)MSD_TILE;
 #pragma unroll
             for (int g = 0; g < MSD_ITEMS / 4; g++) {
-                const u64 *kp = kin + nb + (u32)g * (4 * MSD_NT) + 4 * tid;
-                const u32 *vp = vin + nb + (u32)g * (4 * MSD_NT) + 4 * tid;
+                // (a quad wholly past the tile's last pair -- the last tile of a parent -- re-reads the
+                // tile's first quad instead of the next parent's pairs: no HBM traffic for ignored data)
+                u32 gs = (u32)g * (4 * MSD_NT) + 4 * tid;
+                gs = gs < nv ? gs : 0u;
+                const u64 *kp = kin + nb + gs;
+                const u32 *vp = vin + nb + gs;
                 asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(nk4[2 * g]) : "v"(kp) : "memory");
                 asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(nk4[2 * g + 1]) : "v"(kp + 2) : "memory");
                 asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(nv4[g]) : "v"(vp) : "memory");
