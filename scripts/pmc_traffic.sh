@@ -34,6 +34,7 @@ for name,pat in (("radix_pass_kernel","radix_pass_kernel<false"),("msd_partition
             big=max(d["WRITE_SIZE"]+[0])
             for f,w in zip(sorted(d["FETCH_SIZE"])[::-1], sorted(d["WRITE_SIZE"])[::-1]):
                 if w > 0.5*big: fe.append(2*f); wr.append(w)
-    if wr: res[name+"_bytes_per_launch"]=(sum(fe)+sum(wr))/len(wr); res[name+"_launches"]=len(wr)
+    if wr and sum(wr) / len(wr) > 1e9:   # (full-length launches only: the refinement's small sorts reuse the kernel)
+        res[name+"_bytes_per_launch"]=(sum(fe)+sum(wr))/len(wr); res[name+"_launches"]=len(wr)
 json.dump(res, open("gpurun_out/traffic_latest.json","w"), indent=1)
 PY
