@@ -87,3 +87,19 @@ def test_default_threshold_keeps_small_records_on_lsd(ctx):
     t = O.gen_acgtn(3, 1 << 20)
     ctx.suffix_array(t)
     assert ctx.stats().msd_path == 0
+
+
+@pytest.mark.parametrize("n,sigma", [(40000, 4), (300000, 4), ((1 << 22) + 3, 4), (300000, 5), (300000, 2)])
+def test_msd_big_finish_instance(ctx, n, sigma, monkeypatch):
+    """the finish instance for buckets of a few thousand pairs (4-letter DNA at 1 GiB: ~4096 per 9-mer), which
+    also writes the keys in final order so that rank lookups are binary searches; forced here at small sizes"""
+    monkeypatch.setenv("TC_SA_MSD_MIN_LOG2", "10")
+    monkeypatch.setenv("TC_SA_MSD_BIG", "1")
+    rng = np.random.default_rng(n + sigma)
+    alpha = np.frombuffer(b"ACGTN", np.uint8)[:sigma] if sigma <= 5 else rng.permutation(256)[:sigma]
+    t = alpha[rng.integers(0, sigma, n)].copy()
+    for _ in range(20):      # copies beyond the 21 key symbols: tied groups, refined through the sorted keys
+        ln = int(rng.integers(22, 200))
+        a, b = int(rng.integers(0, n - ln)), int(rng.integers(0, n - ln))
+        t[b:b + ln] = t[a:a + ln].copy()
+    _check(ctx, t, True)

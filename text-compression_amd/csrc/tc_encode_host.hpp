@@ -378,7 +378,12 @@ static void sa_run(tc_ctx *ctx, SaBuffers &b, const u8 *d_text, u64 n, u32 *d_sa
             // repeated 12-symbol prefix (repeat-rich DNA has dozens among 8192; iid text of this length
             // none) -- otherwise the attempt would be paid for and then thrown away.
             const double lvl_bits = (cfg.entropy * cfg.s < 8.0 ? cfg.entropy * cfg.s : 8.0) * MSD_LEVELS;
-            const bool msd_fits = (double)N / exp2(lvl_bits) <= (double)MSDF_CAP / 3.0;
+            // expected level-3 bucket: a third of a small chunk (5-letter DNA at 1 GiB) -> the small finish
+            // instance; up to ~5/8 of a big chunk (4-letter DNA at 1 GiB: 4096) -> the big one, which also
+            // writes the keys in final order (rank lookups by binary search: its buckets are too long to scan)
+            const double msd_bucket = (double)N / exp2(lvl_bits);
+            const bool msd_big = msd_bucket > (double)MSDF_CAP_SMALL / 3.0 || env_int("TC_SA_MSD_BIG", 0) != 0;
+            const bool msd_fits = msd_bucket <= (double)MSDF_CAP_BIG * 0.8;
             // (what an iid text of this entropy leaves among SAMP_N samples at the sampled depth, with slack)
             const double iid_dups = (double)SAMP_N * SAMP_N / 2.0 / exp2((cfg.entropy * cfg.s < 8.0 ? cfg.entropy * cfg.s : 8.0) * (topbits / 8));
             const bool msd_iid = (double)st.sample_dups <= (double)env_int("TC_SA_MSD_MAX_DUPS", 8) + 3.0 * iid_dups;
@@ -403,6 +408,7 @@ static void sa_run(tc_ctx *ctx, SaBuffers &b, const u8 *d_text, u64 n, u32 *d_sa
             tc_memset_async(ctx, ctx->d_scalars + 12, 0, 2 * sizeof(u64));
             tc_memset_async(ctx, b.fin_rc, 0, (FIN_REGIONS * FIN_RSTRIDE + 128) * sizeof(u32));
             int npass_stat = 0;
+            const u64 *kbuf_sorted = nullptr;
             if (msd) {
                 RadixKeyGen kg;
                 kg.n_text = (u32)n; kg.B = cfg.B; kg.w = cfg.w; kg.s = cfg.s; kg.P = cfg.P;
@@ -463,7 +469,10 @@ static void sa_run(tc_ctx *ctx, SaBuffers &b, const u8 *d_text, u64 n, u32 *d_sa
                 mf.sa_out = va; mf.L = d_L;
                 mf.out_slot = fa.out_slot; mf.out_idx = fa.out_idx; mf.out_grp = fa.out_grp;
                 mf.rcount = fa.rcount; mf.rcap = fa.rcap; mf.counters = counters;
-                msd_finish_kernel<<<np / 256, MSDF_NT, 0, s>>>(mf);
+                mf.kout = kbuf[MSD_LEVELS & 1];   // (the key buffer the last level did not write)
+                kbuf_sorted = mf.kout;
+                if (msd_big) msd_finish_kernel<MSDF_BIG_NT, MSDF_BIG_ITEMS, 1, 5, true><<<np / 256, MSDF_BIG_NT, 0, s>>>(mf);
+                else msd_finish_kernel<256, 8, 4, 1, false><<<np / 256, 256, 0, s>>>(mf);
                 TC_LAUNCH_CHECK(ctx);
                 npass_stat = MSD_LEVELS;
                 st.msd_path = 1;
@@ -503,7 +512,7 @@ static void sa_run(tc_ctx *ctx, SaBuffers &b, const u8 *d_text, u64 n, u32 *d_sa
             tc_d2h(ctx, &ctx->h_scalars[12], ctx->d_scalars + 12, sizeof(u64));
             TC_HIP(ctx, hipStreamSynchronize(s));
             u32 fm = (u32)(ctx->h_scalars[12] & 0xffffffffu), over = (u32)(ctx->h_scalars[12] >> 32);
-            if (msd && (over & (4u | 8u))) continue;   // a level-3 bucket beyond MSDF_CAP (or counts that overflowed): the LSD way
+            if (msd && (over & (4u | 8u))) continue;   // a level-3 bucket beyond the finish chunk (or counts that overflowed): the LSD way
             u32 slot_bits = (u32)rbits;
             if (!msd && (over & 1u) && fm <= fa.fix_cap && env_int("TC_SA_TIER2", 1) != 0) {
                 // some buckets are longer than a wave window: the second pass turns them into tied
@@ -531,15 +540,19 @@ static void sa_run(tc_ctx *ctx, SaBuffers &b, const u8 *d_text, u64 n, u32 *d_sa
             }
             // (MSD: rank lookups of untied suffixes count inside an UNSORTED level-3 bucket, ~550 keys
             // each: fine for the few ties of an iid text, hopeless for millions -- the LSD way then)
-            if (msd && fm > (1u << 18)) continue;
+            if (msd && !msd_big && fm > (1u << 18)) continue;
             if (!(over & 1u) && fm <= b.sparse_cap - 1024) {
                 m = fm - fm_dropped;
                 // whole buckets were emitted as tied groups: they share only the globally sorted
                 // symbols, so the doubling starts from those
                 if (over & 2u) h_start = (u64)(tb / (int)cfg.w) * cfg.s;
                 have_groups = true;
-                tkeys = rb.keys;
-                tkeys_shift = 64 - tb;
+                if (msd && msd_big) {   // keys in final order: ranks of untied suffixes by binary search
+                    skeys = kbuf_sorted;
+                } else {
+                    tkeys = rb.keys;
+                    tkeys_shift = 64 - tb;
+                }
                 st.finish_pass = 1;
                 st.rounds = 1;
                 st.m[0] = N; st.key_bytes[0] = 8; st.passes[0] = (u32)npass_stat; st.h[0] = 0;

@@ -50,17 +50,14 @@
 #define MSD_BPC 1             // partition / counting workgroups per CU (LDS permitting)
 #endif
 #define MSD_LEVELS 3
-#ifndef MSDF_NT
-#define MSDF_NT 256
+#define MSDF_CAP_SMALL 2048                // pairs per chunk of the finish kernel's instance for small buckets
+#ifndef MSDF_BIG_NT
+#define MSDF_BIG_NT 512
 #endif
-#ifndef MSDF_ITEMS
-#define MSDF_ITEMS 8
+#ifndef MSDF_BIG_ITEMS
+#define MSDF_BIG_ITEMS 12
 #endif
-#define MSDF_TILE (MSDF_NT * MSDF_ITEMS)   // pairs per chunk of the finish kernel
-#ifndef MSDF_CH
-#define MSDF_CH 4                          // level-3 buckets per chunk at most
-#endif
-#define MSDF_CAP MSDF_TILE                 // largest level-3 bucket the finish kernel orders
+#define MSDF_CAP_BIG (MSDF_BIG_NT * MSDF_BIG_ITEMS)   // ... and of the one for buckets of a few thousand pairs
 
 // One partition level.  Parents are numbered by their digit path (level 1: one parent; level 2:
 // 256; level 3: 65536); an absent path is a parent with count 0.  Tiles never straddle parents.
@@ -332,7 +329,7 @@ __global__ __launch_bounds__(256) void msd_scan_kernel(MsdLevel L, u32 G, u32 *m
                 const u32 o = __shfl_xor(m, x, 64);
                 m = m > o ? m : o;
             }
-            if ((d & 63) == 0 && m > MSDF_CAP) atomicMax(maxchild, m);
+            if ((d & 63) == 0 && m > MSDF_CAP_SMALL) atomicMax(maxchild, m);
         }
         return;
     }
@@ -362,7 +359,7 @@ __global__ __launch_bounds__(256) void msd_scan_kernel(MsdLevel L, u32 G, u32 *m
             const u32 o = __shfl_xor(m, x, 64);
             m = m > o ? m : o;
         }
-        if ((d & 63) == 0 && m > MSDF_CAP) atomicMax(maxchild, m);
+        if ((d & 63) == 0 && m > MSDF_CAP_SMALL) atomicMax(maxchild, m);
     }
 }
 
@@ -870,7 +867,8 @@ struct MsdFinishArgs {
     u32 *out_slot, *out_idx, *out_grp;   // tied set, FIN_REGIONS regions of rcap entries
     u32 *rcount;
     u32 rcap;
-    u32 *counters;       // [1] bit 2: a bucket above MSDF_CAP was met (the caller takes the LSD path)
+    u32 *counters;       // [1] bit 2: a bucket above the instance's chunk was met (the caller takes the LSD path)
+    u64 *kout;           // SORTEDKEYS: the keys in final order
 };
 
 // One workgroup per level-3 parent; its buckets (the children) are taken in chunks of consecutive
@@ -881,10 +879,14 @@ struct MsdFinishArgs {
 // bits (39..8).  SA / last column leave coalesced.  Members with equal remaining bits are tied beyond
 // the key: (slot, suffix, group = first slot of the equal run) go to the tied list exactly as
 // finish_kernel emits them.
-#ifndef MSDF_XB
-#define MSDF_XB 1
-#endif
+// Two instances: <256, 8, 4, 1> for buckets of a few hundred pairs (5-letter DNA at 1 GiB: ~550; chunks of <= 4
+// buckets / 2048 pairs, several workgroups per CU) and <1024, 8, 1, 5> for buckets of a few thousand (4-letter
+// DNA at 1 GiB: ~4096; one bucket per chunk of <= 8192 pairs, 8192 bins).  SORTEDKEYS: the keys are also
+// written in their final order (kout), so that rank lookups of the doubling rounds are a binary search
+// instead of a count inside an unsorted bucket.
+template <int MSDF_NT, int MSDF_ITEMS, int MSDF_CH, int MSDF_XB, bool SORTEDKEYS>
 __global__ __launch_bounds__(MSDF_NT) void msd_finish_kernel(MsdFinishArgs a) {
+    constexpr u32 MSDF_TILE = MSDF_NT * MSDF_ITEMS;
     constexpr u32 BINS_PER_CHILD = 256u << MSDF_XB;
     constexpr u32 MAXBINS = MSDF_CH * BINS_PER_CHILD;
     constexpr int BPT = MAXBINS / MSDF_NT;   // bins per thread in the scan (even)
@@ -1027,6 +1029,7 @@ __global__ __launch_bounds__(MSDF_NT) void msd_finish_kernel(MsdFinishArgs a) {
                 if (in) {
                     s_idx[rank] = val[k];
                     s_L[rank] = (u8)(key[k] & 0xff);
+                    if (SORTEDKEYS) a.kout[start + rank] = key[k];
                 }
             }
         }
