@@ -103,3 +103,24 @@ def test_msd_big_finish_instance(ctx, n, sigma, monkeypatch):
         a, b = int(rng.integers(0, n - ln)), int(rng.integers(0, n - ln))
         t[b:b + ln] = t[a:a + ln].copy()
     _check(ctx, t, True)
+
+
+def test_msd_big_instance_keeps_long_buckets(ctx, monkeypatch):
+    """a poly-A tract of 12000 symbols and a repeat family: level-3 buckets far above the finish chunk leave the
+    big instance as whole tied groups (in place, ordered by the doubling rounds from 9 symbols on) -- the MSD
+    way is kept"""
+    monkeypatch.setenv("TC_SA_MSD_MIN_LOG2", "10")
+    monkeypatch.setenv("TC_SA_MSD_BIG", "1")
+    rng = np.random.default_rng(99)
+    n = 600000
+    t = np.frombuffer(b"ACGT", np.uint8)[rng.integers(0, 4, n)].copy()
+    t[1000:13000] = ord("A")
+    fam = np.frombuffer(b"ACGT", np.uint8)[rng.integers(0, 4, 300)]
+    for _ in range(80):
+        a = int(rng.integers(30000, n - 400))
+        c = fam.copy()
+        mut = rng.random(300) < 0.1
+        c[mut] = np.frombuffer(b"ACGT", np.uint8)[rng.integers(0, 4, int(mut.sum()))]
+        t[a:a + 300] = c
+    _check(ctx, t, True)
+    assert ctx.stats().rounds >= 3

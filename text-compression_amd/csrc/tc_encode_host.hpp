@@ -1,6 +1,7 @@
 // tc_encode_host.hpp -- host orchestration of the encode path (device pointers in,
 // device pointers out).  Included by textcomp.hip only.
 #pragma once
+#include <chrono>
 #include <math.h>
 #include <stdlib.h>
 
@@ -387,6 +388,10 @@ static void sa_run(tc_ctx *ctx, SaBuffers &b, const u8 *d_text, u64 n, u32 *d_sa
             // (what an iid text of this entropy leaves among SAMP_N samples at the sampled depth, with slack)
             const double iid_dups = (double)SAMP_N * SAMP_N / 2.0 / exp2((cfg.entropy * cfg.s < 8.0 ? cfg.entropy * cfg.s : 8.0) * (topbits / 8));
             const bool msd_iid = (double)st.sample_dups <= (double)env_int("TC_SA_MSD_MAX_DUPS", 8) + 3.0 * iid_dups;
+            // (the big instance copes with repeats -- over-long buckets leave as tied groups, ranks of untied
+            // suffixes come by binary search in its sorted keys -- but repeat-rich DNA is slower this way
+            // than by the LSD way, whose finish orders 14+ symbols instead of 12: 1 GiB genome-like
+            // 188 ms against 116 ms.  So the sample decides for both instances.)
             const bool try_msd = msd_cand && cfg.P == 7 && (env_int("TC_SA_MSD", 1) == 2 || (msd_fits && msd_iid));
             for (int way = try_msd ? 0 : 1; way < 2 && !have_groups; way++) {
             const bool msd = way == 0;
@@ -428,7 +433,24 @@ static void sa_run(tc_ctx *ctx, SaBuffers &b, const u8 *d_text, u64 n, u32 *d_sa
                 st.keygen_fused = 1;
                 // the last level is "aligned" (one workgroup per parent): its child counts are gathered by the
                 // level before it, which saves that level's counting pass over the keys (TC_SA_MSD_JOINT=0: off)
-                const bool joint = env_int("TC_SA_MSD_JOINT", 1) != 0;
+                // (its LDS table has a row per digit made of real symbols only: sigma^s <= 128 of them)
+                MsdJointRows jr;
+                u32 nrows = 0;
+                {
+                    memset(jr.row, 0xff, sizeof jr.row);
+                    memset(jr.dig, 0, sizeof jr.dig);
+                    u32 nd = 1;
+                    for (u32 j = 0; j < cfg.s; j++) nd *= cfg.B;
+                    for (u32 d = 0; d < nd && d < 256; d++) {
+                        bool real = true;
+                        for (u32 v = d, j = 0; j < cfg.s; j++, v /= cfg.B) real = real && (v % cfg.B) != 0;
+                        if (real) {
+                            if (nrows < 128) { jr.row[d] = (u8)nrows; jr.dig[nrows] = (u8)d; }
+                            nrows++;
+                        }
+                    }
+                }
+                const bool joint = env_int("TC_SA_MSD_JOINT", 1) != 0 && nrows <= 128;
                 if (joint) tc_memset_async(ctx, b.msd_joint, 0, (size_t)256 * 256 * 256 * sizeof(u32));
                 u32 np = 1;
                 for (int l = 0; l < MSD_LEVELS; l++, np *= 256) {
@@ -443,10 +465,10 @@ static void sa_run(tc_ctx *ctx, SaBuffers &b, const u8 *d_text, u64 n, u32 *d_sa
                     const u32 *vin = l ? vbuf[(l - 1) & 1] : nullptr;
                     msd_prep_kernel<<<1, 1024, 0, s>>>(ML.pcnt, np, b.msd_tpre[l]);
                     TC_LAUNCH_CHECK(ctx);
-                    if (l == 0) msd_count_kernel<true, false><<<G, MSD_NT, 0, s>>>(ML, nullptr, td, nullptr);
+                    if (l == 0) msd_count_kernel<true, false><<<G, MSD_NT, 0, s>>>(ML, nullptr, td, nullptr, jr);
                     else if (ML.aligned) { /* counts already in msd_joint */ }
-                    else if (joint && l == MSD_LEVELS - 2) msd_count_kernel<false, true><<<G, MSD_NT, 0, s>>>(ML, kin, td, b.msd_joint);
-                    else msd_count_kernel<false, false><<<G, MSD_NT, 0, s>>>(ML, kin, td, nullptr);
+                    else if (joint && l == MSD_LEVELS - 2) msd_count_kernel<false, true><<<G, MSD_NT, 0, s>>>(ML, kin, td, b.msd_joint, jr);
+                    else msd_count_kernel<false, false><<<G, MSD_NT, 0, s>>>(ML, kin, td, nullptr, jr);
                     TC_LAUNCH_CHECK(ctx);
                     msd_scan_kernel<<<np, 256, 0, s>>>(ML, G, l == MSD_LEVELS - 1 ? maxchild : nullptr);
                     TC_LAUNCH_CHECK(ctx);
@@ -512,6 +534,9 @@ static void sa_run(tc_ctx *ctx, SaBuffers &b, const u8 *d_text, u64 n, u32 *d_sa
             tc_d2h(ctx, &ctx->h_scalars[12], ctx->d_scalars + 12, sizeof(u64));
             TC_HIP(ctx, hipStreamSynchronize(s));
             u32 fm = (u32)(ctx->h_scalars[12] & 0xffffffffu), over = (u32)(ctx->h_scalars[12] >> 32);
+            if (env_int("TC_SA_TRACE", 0))
+                fprintf(stderr, "textcomp: round 0 %s way%s: tied %u, flags 0x%x (1 over-long bucket left to the fix pass, 2 whole buckets tied, 4 bucket above the finish chunk, 8 joint counts off)\n",
+                        msd ? "MSD" : "LSD", msd && msd_big ? " (big finish)" : "", fm, over);
             if (msd && (over & (4u | 8u))) continue;   // a level-3 bucket beyond the finish chunk (or counts that overflowed): the LSD way
             u32 slot_bits = (u32)rbits;
             if (!msd && (over & 1u) && fm <= fa.fix_cap && env_int("TC_SA_TIER2", 1) != 0) {
@@ -602,6 +627,18 @@ static void sa_run(tc_ctx *ctx, SaBuffers &b, const u8 *d_text, u64 n, u32 *d_sa
         st.m[0] = N; st.key_bytes[0] = 8; st.passes[0] = (u32)plan.npass; st.h[0] = 0;
     }
 
+    // (TC_SA_TRACE: wall time per step, each closed by a stream sync -- experiments only)
+    const bool trace_on = env_int("TC_SA_TRACE", 0) != 0;
+    auto trace_t0 = std::chrono::steady_clock::now();
+    auto trace = [&](const char *what, u64 count) {
+        if (!trace_on) return;
+        (void)hipStreamSynchronize(s);
+        auto t1 = std::chrono::steady_clock::now();
+        fprintf(stderr, "textcomp:   %-28s %10llu  %8.3f ms\n", what, (unsigned long long)count,
+                std::chrono::duration<double, std::milli>(t1 - trace_t0).count());
+        trace_t0 = t1;
+    };
+    trace("(sync before the rank table)", m);
     // 5. ranks: dense ISA when many suffixes are tied, else a sparse table of the tied
     //    positions + a search for everything else (sorted round-0 keys, or the SA itself)
     const bool dense = m > b.sparse_cap - 1024 || env_int("TC_SA_DENSE", 0) != 0;
@@ -658,6 +695,7 @@ static void sa_run(tc_ctx *ctx, SaBuffers &b, const u8 *d_text, u64 n, u32 *d_sa
         }
     }
 
+    trace(dense ? "ranks: dense ISA" : "ranks: sparse table", m);
     // 6. prefix doubling on the tied suffixes
     int cur = 0;
     if (env_int("TC_SA_H_START", 0) > 0) h_start = (u64)env_int("TC_SA_H_START", 0);  // experiments: any h <= sorted depth is valid
@@ -688,10 +726,12 @@ static void sa_run(tc_ctx *ctx, SaBuffers &b, const u8 *d_text, u64 n, u32 *d_sa
             else key2_kernel<false><<<kgrid, 256, 0, s>>>(b.act[cur][1], b.act[cur][2], rl, mm, hh, k2, vals_idx ? kv : nullptr, pd2, b.hist);
         }
         TC_LAUNCH_CHECK(ctx);
+        trace("round: keys (rank lookups)", mm);
         RadixBuffers r2;
         r2.keys = k2; r2.keys_alt = k2alt; r2.vals = kv; r2.vals_alt = kvalt;
         r2.hist = b.hist; r2.status = b.rstatus;
         radix_sort_pairs(ctx, r2, mm, p2, /*gen_idx=*/!vals_idx, /*hist_ready=*/fuse_hist);
+        trace("round: radix passes", mm);
         GroupArgs gr = {};
         gr.keys = r2.keys; gr.count = mm; gr.vals = r2.vals; gr.vals_are_idx = vals_idx ? 1 : 0;
         gr.in_slot = b.act[cur][0]; gr.in_idx = b.act[cur][1]; gr.in_tpos = b.act[cur][3];
@@ -703,6 +743,7 @@ static void sa_run(tc_ctx *ctx, SaBuffers &b, const u8 *d_text, u64 n, u32 *d_sa
         st.h[st.rounds] = hh;
         st.rounds++;
         m = fetch_m();
+        trace("round: groups", mm);
         cur ^= 1;
         h *= 2;
     }

@@ -202,12 +202,18 @@ struct MsdTextDigit {
 // inside one parent = one contiguous range of positions: no per-tile synchronisation.
 // JOINT: besides, the counts of (digit, next digit) per parent are accumulated into joint_out
 // [(parent * 256 + digit) * 256 + next digit] -- the child counts of the NEXT level's parents, which is
-// then an aligned level without a counting pass.  LDS table of 16-bit counters, two per word; a cell that
-// overflowed (>= 65536 pairs of one segment in one level-(l+2) bucket: such a text leaves the MSD way
-// anyway) shows as a sum mismatch in the next level's scan.
+// then an aligned level without a counting pass.  LDS table of 128 rows x 256 32-bit counters (no cell can
+// overflow, whatever the text: a poly-A tract puts millions of pairs into one cell): the rows are the digits
+// whose symbols are all real (sigma^s <= 128 of them; MsdJointRows maps digit -> row); a digit that
+// contains the end marker belongs to one of the text's last suffixes and goes to joint_out directly.
+struct MsdJointRows {
+    u8 row[256];   // digit -> row of the LDS table, 0xff: none
+    u8 dig[128];   // row -> digit
+};
 template <bool TEXT, bool JOINT>
 __global__ __launch_bounds__(MSD_NT) void msd_count_kernel(MsdLevel L, const u64 *__restrict__ keys,
-                                                           MsdTextDigit td, u32 *__restrict__ joint_out) {
+                                                           MsdTextDigit td, u32 *__restrict__ joint_out,
+                                                           MsdJointRows jr) {
     __shared__ u32 s_cnt[256];
     __shared__ u16 s_lut[TEXT ? 256 : 1];
     __shared__ u32 s_seg[4];   // q, lo, hi, next tile
@@ -215,8 +221,11 @@ __global__ __launch_bounds__(MSD_NT) void msd_count_kernel(MsdLevel L, const u64
     const u32 tid = threadIdx.x, b = blockIdx.x, G = gridDim.x;
     if (tid < 256) s_cnt[tid] = 0;
     if (TEXT && tid < 256) s_lut[tid] = td.lut[tid];
-    if (JOINT)
+    __shared__ u8 s_row[JOINT ? 256 : 1];
+    if (JOINT) {
         for (u32 i = tid; i < 32768; i += MSD_NT) s_joint[i] = 0;
+        if (tid < 256) s_row[tid] = jr.row[tid];
+    }
     const u32 T = L.tpre[L.nparents];
     const u32 t0 = msd_tile_lo(T, b, G), t1 = msd_tile_lo(T, b + 1, G);
     if (t0 >= t1) return;
@@ -272,7 +281,11 @@ __global__ __launch_bounds__(MSD_NT) void msd_count_kernel(MsdLevel L, const u64
             auto add = [&](u64 k) {
                 const u32 dd = (u32)(k >> (L.shift - 8)) & 0xffffu;   // digit, next digit
                 atomicAdd(&s_cnt[dd >> 8], 1u);
-                if (JOINT) atomicAdd(&s_joint[dd >> 1], (dd & 1u) ? 0x10000u : 1u);
+                if (JOINT) {
+                    const u32 r = s_row[dd >> 8];
+                    if (r != 0xffu) atomicAdd(&s_joint[(r << 8) | (dd & 255u)], 1u);
+                    else atomicAdd(&joint_out[((size_t)sq * 256 + (dd >> 8)) * 256 + (dd & 255u)], 1u);
+                }
             };
             u32 p = lo + tid;
             for (; p + 3 * MSD_NT < hi; p += 4 * MSD_NT) {
@@ -290,9 +303,7 @@ __global__ __launch_bounds__(MSD_NT) void msd_count_kernel(MsdLevel L, const u64
             for (u32 w = tid; w < 32768; w += MSD_NT) {
                 const u32 v = s_joint[w];
                 if (v) {
-                    u32 *o = joint_out + ((size_t)sq * 256 + (w >> 7)) * 256 + (w & 127u) * 2;
-                    if (v & 0xffffu) atomicAdd(o, v & 0xffffu);
-                    if (v >> 16) atomicAdd(o + 1, v >> 16);
+                    atomicAdd(&joint_out[((size_t)sq * 256 + jr.dig[w >> 8]) * 256 + (w & 255u)], v);
                     s_joint[w] = 0;
                 }
             }
@@ -917,10 +928,15 @@ __global__ __launch_bounds__(MSDF_NT) void msd_finish_kernel(MsdFinishArgs a) {
         if (tid == 0) {
             while (ch < 256 && s_cc[ch] == 0) ch++;
             u32 c0 = ch, tot = 0, span = 0;
-            if (ch < 256 && s_cc[ch] > MSDF_TILE) {   // a bucket no chunk can hold: the caller takes the LSD way
-                atomicOr(&a.counters[1], 4u);
+            if (ch < 256 && s_cc[ch] > MSDF_TILE) {
+                // a bucket no chunk can hold (repeats, poly-A).  SORTEDKEYS instance: its members leave as ONE
+                // tied group, in place, for the doubling rounds to order (bit 1: they share only the levels'
+                // symbols) -- what finish_fix_kernel does for over-long buckets of the LSD way.  Else: bit 2,
+                // the caller takes the LSD way.
+                atomicOr(&a.counters[1], SORTEDKEYS ? 2u : 4u);
+                tot = SORTEDKEYS ? s_cc[ch] : 0u;
                 ch++;
-                span = 1;
+                span = 0;   // (marks the whole-bucket form)
             } else {
                 while (ch < 256 && span < MSDF_CH && tot + s_cc[ch] <= MSDF_TILE) {
                     tot += s_cc[ch];
@@ -935,6 +951,32 @@ __global__ __launch_bounds__(MSDF_NT) void msd_finish_kernel(MsdFinishArgs a) {
         ch = s_chunk[4];
         if (c0 >= 256) break;
         if (tot == 0) continue;
+        if (span == 0) {   // over-long bucket: (slot, suffix, group = bucket start) for every member, in place
+            for (u32 base = 0; base < tot; base += MSDF_NT * 4) {
+                const u32 cnt = tot - base < MSDF_NT * 4 ? tot - base : MSDF_NT * 4;
+                // (its entries are dealt over the regions of the tied list: one bucket may hold more than a region)
+                const u32 reg = (blockIdx.x + base / (MSDF_NT * 4)) % FIN_REGIONS;
+                const u32 rbase = reg * a.rcap;
+                __syncthreads();
+                if (tid == 0) s_chunk[3] = atomicAdd(a.rcount + reg * FIN_RSTRIDE, cnt);
+                __syncthreads();
+                const u32 o0 = s_chunk[3];
+                for (u32 i = tid; i < cnt; i += MSDF_NT) {
+                    const u32 p = start + base + i;
+                    const u64 k = a.keys[p];
+                    const u32 v = a.vals[p];
+                    a.sa_out[p] = v;
+                    a.L[p] = (u8)(k & 0xff);
+                    if (SORTEDKEYS) a.kout[p] = k;
+                    if (o0 + i < a.rcap) {
+                        a.out_slot[rbase + o0 + i] = p;
+                        a.out_idx[rbase + o0 + i] = v;
+                        a.out_grp[rbase + o0 + i] = start;
+                    }
+                }
+            }
+            continue;
+        }
         const u32 nbins = span * BINS_PER_CHILD;
         for (u32 i = tid; i <= nbins / 2; i += MSDF_NT) s_off[i] = 0;
         __syncthreads();
