@@ -464,3 +464,36 @@ def test_mtf_slow_and_fast_incoming_list_paths(ctx, monkeypatch):
         idx, fl = ctx.mtf_encode(np.frombuffer(t, np.uint8), None)
         e2, f2 = O.mtf_encode_arr(np.frombuffer(t, np.uint8).astype(np.int16))
         assert idx.tolist() == e2.tolist() and fl.tolist() == f2.tolist()
+
+
+def _wordy(seed, n, vocab=300):
+    """Zipf-ish words over a small vocabulary: nearly every suffix stays tied after round 0 (the
+    sample calls the text hopeless: ranks are written by the first group pass, dense mode)."""
+    rs = np.random.default_rng(seed)
+    words = [bytes(rs.integers(97, 123, int(rs.integers(2, 9))).astype(np.uint8)) + b" " for _ in range(vocab)]
+    p = 1.0 / np.arange(1, vocab + 1) ** 1.1
+    ids = rs.choice(vocab, n // 4, p=p / p.sum())
+    return b"".join(words[i] for i in ids)[:n]
+
+
+@pytest.mark.parametrize("n", [1000, 70000, 1 << 20, (1 << 21) + 12345])
+def test_dense_ranks_by_regions(ctx, monkeypatch, n):
+    """Dense ranks of a large set are stored through (start, rank) pairs partitioned by regions of the
+    rank array (tc_sa.hpp, rank_bin_kernel / rank_scatter_kernel) instead of one random store per member:
+    same suffix array as the direct stores, in the three places that write ranks (first group pass of a
+    hopeless text, the ranks-only pass once dense mode is chosen, every doubling round)."""
+    texts = [_wordy(5, n), O.gen_acgtn(9, n // 2).tobytes() + b"ACGTTGCA" * (n // 16)]
+    for t in texts:
+        exp = O.suffix_array(t).tolist() if n <= (1 << 20) else None
+        monkeypatch.setenv("TC_SA_BIN_MIN_LOG2", "40")       # direct stores
+        ref = ctx.suffix_array(t)
+        if exp is not None:
+            assert ref.tolist() == exp
+        monkeypatch.setenv("TC_SA_BIN_MIN_LOG2", "0")        # by regions, whatever the size
+        assert np.array_equal(ctx.suffix_array(t), ref)
+        monkeypatch.setenv("TC_SA_DENSE", "1")               # full path, dense chosen up front
+        assert np.array_equal(ctx.suffix_array(t), ref)
+        monkeypatch.setenv("TC_SA_FIELDS", "2")
+        assert np.array_equal(ctx.suffix_array(t), ref)
+        monkeypatch.delenv("TC_SA_DENSE")
+        monkeypatch.delenv("TC_SA_FIELDS")

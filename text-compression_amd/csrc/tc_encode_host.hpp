@@ -259,6 +259,25 @@ static void sa_run(tc_ctx *ctx, SaBuffers &b, const u8 *d_text, u64 n, u32 *d_sa
         TC_HIP(ctx, hipStreamSynchronize(s));
         return ctx->h_scalars[1];
     };
+    // dense ranks of a large set go by regions (tc_sa.hpp, "dense ranks by regions"): group_kernel leaves
+    // (start, rank) pairs in `pairs`, these two kernels store them.  `part`: N free u64 slots.
+    const int rbits0 = ceil_log2_u64(N);
+    const int rshift = rbits0 > 8 ? rbits0 - 8 : 0;
+    const u64 bin_min = 1ull << env_int("TC_SA_BIN_MIN_LOG2", 25);   // (below ~2^25 members the direct stores are as fast)
+    auto apply_pairs = [&](const u64 *pairs, u32 count, u64 *part) {
+        u32 *cursor = b.hist;   // (free between the radix passes of two rounds)
+        rank_cursor_kernel<<<1, 256, 0, s>>>(cursor, rshift);
+        TC_LAUNCH_CHECK(ctx);
+        rank_bin_kernel<<<tc_cdiv(count, RBIN_TILE), RBIN_NT, 0, s>>>(pairs, count, rshift, cursor, part);
+        TC_LAUNCH_CHECK(ctx);
+        rank_scatter_kernel<<<tc_cdiv(N, RSCAT_NT * RSCAT_ITEMS), RSCAT_NT, 0, s>>>(part, N, rshift, cursor, b.isa);
+        TC_LAUNCH_CHECK(ctx);
+    };
+    // (the second active set is free whenever the first one is being built: its slot + idx arrays are
+    // adjacent in the arena and together hold N u64)
+    u64 *part_act1 = reinterpret_cast<u64 *>(b.act[1][0]);
+    const bool part_act1_ok = (size_t)((char *)b.act[1][2] - (char *)b.act[1][0]) >= N * sizeof(u64) &&
+                              ((uintptr_t)b.act[1][0] & 7) == 0;
     auto build_keys_and_sort = [&](const RadixPlan &plan, RadixBuffers &rb, bool sa_in_alt_at_end) {
         KeyBuildParams kp;
         kp.B = cfg.B; kp.w = cfg.w; kp.s = cfg.s; kp.P = cfg.P;
@@ -493,8 +512,16 @@ static void sa_run(tc_ctx *ctx, SaBuffers &b, const u8 *d_text, u64 n, u32 *d_sa
                 mf.rcount = fa.rcount; mf.rcap = fa.rcap; mf.counters = counters;
                 mf.kout = kbuf[MSD_LEVELS & 1];   // (the key buffer the last level did not write)
                 kbuf_sorted = mf.kout;
-                if (msd_big) msd_finish_kernel<MSDF_BIG_NT, MSDF_BIG_ITEMS, 1, 5, true><<<np / 256, MSDF_BIG_NT, 0, s>>>(mf);
-                else msd_finish_kernel<256, 8, 4, 1, false><<<np / 256, 256, 0, s>>>(mf);
+                // (the last level's segment table is dead by now: the list of over-long buckets goes there)
+                mf.whole_list = b.msd_seg[MSD_LEVELS - 1];
+                mf.whole_cap = 1u << 20;
+                if (msd_big) {
+                    msd_finish_kernel<MSDF_BIG_NT, MSDF_BIG_ITEMS, 1, 5, true><<<np / 256, MSDF_BIG_NT, 0, s>>>(mf);
+                    TC_LAUNCH_CHECK(ctx);
+                    msd_whole_kernel<<<1024, MSDW_NT, 0, s>>>(mf);
+                } else {
+                    msd_finish_kernel<256, 8, 4, 1, false><<<np / 256, 256, 0, s>>>(mf);
+                }
                 TC_LAUNCH_CHECK(ctx);
                 npass_stat = MSD_LEVELS;
                 st.msd_path = 1;
@@ -621,7 +648,10 @@ static void sa_run(tc_ctx *ctx, SaBuffers &b, const u8 *d_text, u64 n, u32 *d_sa
         g0.keys = skeys; g0.count = (u32)N; g0.vals = sa;
         g0.out_slot = b.act[0][0]; g0.out_idx = b.act[0][1]; g0.out_grp = b.act[0][2]; g0.out_tpos = b.act[0][3];
         if (hopeless) { g0.isa = b.isa; isa_ready = true; }  // many ties expected: ranks in the same pass
+        const bool g0_pairs = hopeless && N >= bin_min && part_act1_ok;
+        if (g0_pairs) g0.pairs = rb.keys_alt;
         run_group(true, g0, sa);
+        if (g0_pairs) apply_pairs(rb.keys_alt, (u32)N, part_act1);
         m = fetch_m();
         st.rounds = 1;
         st.m[0] = N; st.key_bytes[0] = 8; st.passes[0] = (u32)plan.npass; st.h[0] = 0;
@@ -652,7 +682,12 @@ static void sa_run(tc_ctx *ctx, SaBuffers &b, const u8 *d_text, u64 n, u32 *d_sa
             GroupArgs gi = {};
             gi.keys = skeys; gi.count = (u32)N; gi.vals = sa;
             gi.isa = b.isa; gi.isa_only = 1;
+            // (scratch: whichever round-0 key buffer does not hold the sorted keys; the second active set)
+            u64 *kfree = skeys == b.k0 ? b.k1 : b.k0;
+            const bool gi_pairs = N >= bin_min && part_act1_ok && (skeys == b.k0 || skeys == b.k1);
+            if (gi_pairs) gi.pairs = kfree;
             run_group(true, gi, sa);
+            if (gi_pairs) apply_pairs(kfree, (u32)N, part_act1);
         }
         rl.isa = b.isa;
     } else {
@@ -704,6 +739,18 @@ static void sa_run(tc_ctx *ctx, SaBuffers &b, const u8 *d_text, u64 n, u32 *d_sa
         if (st.rounds >= TC_MAX_ROUNDS) TC_FAIL(ctx, TC_ERR_INTERNAL, "suffix sort did not converge");
         u32 mm = (u32)m;
         u32 hh = h > N ? (u32)N : (u32)h;
+        if (trace_on) {   // members per group-size class (k0 is free at this point in both modes' first use)
+            u64 *gh = reinterpret_cast<u64 *>(b.hist);
+            tc_memset_async(ctx, gh, 0, 32 * sizeof(u64));
+            group_size_hist_kernel<<<tc_cdiv(mm, 256), 256, 0, s>>>(b.act[cur][0], b.act[cur][2], mm, gh);
+            u64 hh32[32];
+            tc_d2h(ctx, hh32, gh, sizeof hh32);
+            (void)hipStreamSynchronize(s);
+            fprintf(stderr, "textcomp:   members by group size 2^c:");
+            for (int c = 0; c < 32; c++) if (hh32[c]) fprintf(stderr, " %d:%.1f%%", c, 100.0 * (double)hh32[c] / (double)mm);
+            fprintf(stderr, "\n");
+            trace_t0 = std::chrono::steady_clock::now();
+        }
         // dense: the round-0 key buffers are dead; sparse: they hold the sorted keys
         u64 *k2 = dense ? b.k0 : b.sk[0], *k2alt = dense ? b.k1 : b.sk[1];
         u32 *kv = dense ? b.v0 : b.sv[0], *kvalt = dense ? b.v2 : b.sv[1];
@@ -738,7 +785,12 @@ static void sa_run(tc_ctx *ctx, SaBuffers &b, const u8 *d_text, u64 n, u32 *d_sa
         gr.isa = dense ? b.isa : nullptr; gr.t_rank = dense ? nullptr : b.t_rank;
         gr.out_slot = b.act[cur ^ 1][0]; gr.out_idx = b.act[cur ^ 1][1];
         gr.out_grp = b.act[cur ^ 1][2]; gr.out_tpos = b.act[cur ^ 1][3];
+        // dense, large round: ranks by regions (pairs into the scratch key buffer; the sorted keys are dead
+        // once the groups are made, so the partitioned pairs go there)
+        const bool gr_pairs = dense && mm >= bin_min;
+        if (gr_pairs) gr.pairs = r2.keys_alt;
         run_group(false, gr, sa);
+        if (gr_pairs) apply_pairs(r2.keys_alt, mm, r2.keys);
         st.m[st.rounds] = m; st.key_bytes[st.rounds] = 8; st.passes[st.rounds] = (u32)p2.npass;
         st.h[st.rounds] = hh;
         st.rounds++;

@@ -878,9 +878,50 @@ struct MsdFinishArgs {
     u32 *out_slot, *out_idx, *out_grp;   // tied set, FIN_REGIONS regions of rcap entries
     u32 *rcount;
     u32 rcap;
-    u32 *counters;       // [1] bit 2: a bucket above the instance's chunk was met (the caller takes the LSD path)
+    u32 *counters;       // [1] bit 2: a bucket above the instance's chunk was met (the caller takes the LSD path);
+                         // bit 1: (SORTEDKEYS) such buckets were listed for msd_whole_kernel; [2]: how many
     u64 *kout;           // SORTEDKEYS: the keys in final order
+    u32 *whole_list;     // SORTEDKEYS: (start, length) of the over-long buckets
+    u32 whole_cap;
 };
+
+// Over-long buckets of the SORTEDKEYS instance (repeats, poly-A: no chunk holds them): msd_finish_kernel only
+// lists them (start, length); here every member leaves in place as ONE tied group -- (slot, suffix, group =
+// bucket start), dealt over the regions of the tied list -- for the doubling rounds to order, as
+// finish_fix_kernel does for the over-long buckets of the LSD way.  Its own kernel so that the rare case does
+// not set the register budget of the finish kernel (194 instead of 128 VGPRs when it was a branch there).
+// Launched unconditionally with a fixed grid; the list length is read on the device.
+#define MSDW_NT 512
+__global__ __launch_bounds__(MSDW_NT) void msd_whole_kernel(MsdFinishArgs a) {
+    __shared__ u32 s_o;
+    const u32 tid = threadIdx.x;
+    const u32 nlist = a.counters[2] < a.whole_cap ? a.counters[2] : a.whole_cap;
+    for (u32 e = blockIdx.x; e < nlist; e += gridDim.x) {
+        const u32 start = a.whole_list[2 * e], tot = a.whole_list[2 * e + 1];
+        for (u32 base = 0; base < tot; base += MSDW_NT * 4) {
+            const u32 cnt = tot - base < MSDW_NT * 4 ? tot - base : MSDW_NT * 4;
+            const u32 reg = (e + base / (MSDW_NT * 4)) % FIN_REGIONS;   // (one bucket may hold more than a region)
+            const u32 rbase = reg * a.rcap;
+            __syncthreads();
+            if (tid == 0) s_o = atomicAdd(a.rcount + reg * FIN_RSTRIDE, cnt);
+            __syncthreads();
+            const u32 o0 = s_o;
+            for (u32 i = tid; i < cnt; i += MSDW_NT) {
+                const u32 p = start + base + i;
+                const u64 k = a.keys[p];
+                const u32 v = a.vals[p];
+                a.sa_out[p] = v;
+                a.L[p] = (u8)(k & 0xff);
+                a.kout[p] = k;
+                if (o0 + i < a.rcap) {
+                    a.out_slot[rbase + o0 + i] = p;
+                    a.out_idx[rbase + o0 + i] = v;
+                    a.out_grp[rbase + o0 + i] = start;
+                }
+            }
+        }
+    }
+}
 
 // One workgroup per level-3 parent; its buckets (the children) are taken in chunks of consecutive
 // children -- at most MSDF_CH of them, at most MSDF_TILE pairs -- which are contiguous in memory.  A
@@ -933,10 +974,18 @@ __global__ __launch_bounds__(MSDF_NT) void msd_finish_kernel(MsdFinishArgs a) {
                 // tied group, in place, for the doubling rounds to order (bit 1: they share only the levels'
                 // symbols) -- what finish_fix_kernel does for over-long buckets of the LSD way.  Else: bit 2,
                 // the caller takes the LSD way.
-                atomicOr(&a.counters[1], SORTEDKEYS ? 2u : 4u);
-                tot = SORTEDKEYS ? s_cc[ch] : 0u;
+                if (SORTEDKEYS) {
+                    const u32 e = atomicAdd(&a.counters[2], 1u);
+                    if (e < a.whole_cap) {
+                        a.whole_list[2 * e] = s_cs[ch];
+                        a.whole_list[2 * e + 1] = s_cc[ch];
+                    }
+                    atomicOr(&a.counters[1], e < a.whole_cap ? 2u : 4u);
+                } else {
+                    atomicOr(&a.counters[1], 4u);
+                }
                 ch++;
-                span = 0;   // (marks the whole-bucket form)
+                span = 1;   // (tot = 0: nothing to do here)
             } else {
                 while (ch < 256 && span < MSDF_CH && tot + s_cc[ch] <= MSDF_TILE) {
                     tot += s_cc[ch];
@@ -951,32 +1000,6 @@ __global__ __launch_bounds__(MSDF_NT) void msd_finish_kernel(MsdFinishArgs a) {
         ch = s_chunk[4];
         if (c0 >= 256) break;
         if (tot == 0) continue;
-        if (span == 0) {   // over-long bucket: (slot, suffix, group = bucket start) for every member, in place
-            for (u32 base = 0; base < tot; base += MSDF_NT * 4) {
-                const u32 cnt = tot - base < MSDF_NT * 4 ? tot - base : MSDF_NT * 4;
-                // (its entries are dealt over the regions of the tied list: one bucket may hold more than a region)
-                const u32 reg = (blockIdx.x + base / (MSDF_NT * 4)) % FIN_REGIONS;
-                const u32 rbase = reg * a.rcap;
-                __syncthreads();
-                if (tid == 0) s_chunk[3] = atomicAdd(a.rcount + reg * FIN_RSTRIDE, cnt);
-                __syncthreads();
-                const u32 o0 = s_chunk[3];
-                for (u32 i = tid; i < cnt; i += MSDF_NT) {
-                    const u32 p = start + base + i;
-                    const u64 k = a.keys[p];
-                    const u32 v = a.vals[p];
-                    a.sa_out[p] = v;
-                    a.L[p] = (u8)(k & 0xff);
-                    if (SORTEDKEYS) a.kout[p] = k;
-                    if (o0 + i < a.rcap) {
-                        a.out_slot[rbase + o0 + i] = p;
-                        a.out_idx[rbase + o0 + i] = v;
-                        a.out_grp[rbase + o0 + i] = start;
-                    }
-                }
-            }
-            continue;
-        }
         const u32 nbins = span * BINS_PER_CHILD;
         for (u32 i = tid; i <= nbins / 2; i += MSDF_NT) s_off[i] = 0;
         __syncthreads();

@@ -285,6 +285,8 @@ struct GroupArgs {
     const u8 *text;
     u32 *sa;
     u32 *isa;           // dense rank array or null
+    u64 *pairs;         // dense, large sets: (suffix start << 32 | rank) by sorted position instead of
+                        // isa[start] = rank; rank_bin_kernel + rank_scatter_kernel apply them by regions
     u32 *t_rank;        // sparse rank table or null
     u8 *L;
     u32 *out_slot, *out_idx, *out_grp, *out_tpos;  // next active set
@@ -422,11 +424,13 @@ __global__ __launch_bounds__(GRP_NT, 4) void group_kernel(GroupArgs a) {
         if (!in) continue;
         if (INIT) {
             if (a.isa_only) {
-                a.isa[a.vals[j]] = g;
+                if (a.pairs) a.pairs[j] = ((u64)a.vals[j] << 32) | g;
+                else a.isa[a.vals[j]] = g;
             } else {
                 a.L[j] = (u8)(lowb[k >> 2] >> (8 * (k & 3)));
                 const u32 v = a.vals[j];
-                if (a.isa) a.isa[v] = g;   // dense mode expected: ranks in the same pass
+                if (a.pairs) a.pairs[j] = ((u64)v << 32) | g;
+                else if (a.isa) a.isa[v] = g;   // dense mode expected: ranks in the same pass
                 if (act) {
                     a.out_slot[o] = (u32)j;
                     a.out_idx[o] = v;
@@ -442,7 +446,8 @@ __global__ __launch_bounds__(GRP_NT, 4) void group_kernel(GroupArgs a) {
                 a.L[slot] = i ? a.text[i - 1] : (u8)0;
             }
             u32 tp = 0;
-            if (a.isa) a.isa[i] = g;
+            if (a.pairs) a.pairs[j] = ((u64)i << 32) | g;
+            else if (a.isa) a.isa[i] = g;
             else {
                 tp = a.in_tpos[k0];
                 a.t_rank[tp] = g;
@@ -457,6 +462,92 @@ __global__ __launch_bounds__(GRP_NT, 4) void group_kernel(GroupArgs a) {
     }
     __syncthreads();  // LDS prefix slots are reused by the next tile
     }
+}
+
+// ---- dense ranks by regions ----------------------------------------------------------
+// isa[start] = rank over a large set is one random 4-byte store per member: at 2^30 members ~48 ms,
+// every store a 64-byte line of HBM traffic.  Instead group_kernel writes (start << 32 | rank) pairs in
+// stream order; rank_bin_kernel partitions them by the top 8 bits of `start` (unstable -- order inside a
+// region is irrelevant, the starts are distinct); rank_scatter_kernel then stores region after region,
+// the workgroups running together covering a few regions of <= 16 MiB of ranks that stay in MALL until
+// their lines are complete.  Measured (scripts/dbg/local_scatter_probe.py, 2^30): 48 ms -> 17-19 ms for
+// the stores, plus the partition.
+// Region d of the partitioned array starts at slot d << shift and never overflows: the starts are
+// distinct, so at most 2^shift of them fall into one region (no counting pass).
+#define RBIN_NT 1024
+#define RBIN_ITEMS 16
+#define RBIN_TILE (RBIN_NT * RBIN_ITEMS)
+
+__global__ __launch_bounds__(256) void rank_cursor_kernel(u32 *cursor, int shift) {
+    cursor[threadIdx.x] = (u32)threadIdx.x << shift;
+}
+
+__global__ __launch_bounds__(RBIN_NT) void rank_bin_kernel(const u64 *__restrict__ in, u32 m, int shift,
+                                                           u32 *__restrict__ cursor, u64 *__restrict__ out) {
+    __shared__ u64 s_stage[RBIN_TILE];
+    __shared__ u32 s_cnt[256], s_lb[256], s_gb[256];
+    __shared__ u32 s_scan[RBIN_NT / 64 + 1];
+    const u32 tid = threadIdx.x;
+    const u64 base = (u64)blockIdx.x * RBIN_TILE;
+    const u32 valid = (u64)m - base < (u64)RBIN_TILE ? (u32)((u64)m - base) : (u32)RBIN_TILE;
+    if (tid < 256) s_cnt[tid] = 0;
+    __syncthreads();
+    u64 v[RBIN_ITEMS];
+    u32 r[RBIN_ITEMS];
+#pragma unroll
+    for (int k = 0; k < RBIN_ITEMS; k++) {
+        const u32 p = k * RBIN_NT + tid;
+        v[k] = p < valid ? in[base + p] : 0ull;
+    }
+#pragma unroll
+    for (int k = 0; k < RBIN_ITEMS; k++) {
+        const u32 p = k * RBIN_NT + tid;
+        if (p < valid) r[k] = atomicAdd(&s_cnt[(u32)(v[k] >> 32) >> shift], 1u);
+    }
+    __syncthreads();
+    const u32 c = tid < 256 ? s_cnt[tid] : 0u;
+    u32 tot;
+    const u32 lb = block_excl_sum<RBIN_NT>(c, s_scan, &tot);
+    if (tid < 256) {
+        s_lb[tid] = lb;
+        s_gb[tid] = c ? atomicAdd(&cursor[tid], c) : 0u;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < RBIN_ITEMS; k++) {
+        const u32 p = k * RBIN_NT + tid;
+        if (p < valid) s_stage[s_lb[(u32)(v[k] >> 32) >> shift] + r[k]] = v[k];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < RBIN_ITEMS; k++) {
+        const u32 p = k * RBIN_NT + tid;
+        if (p < valid) {
+            const u64 x = s_stage[p];
+            const u32 d = (u32)(x >> 32) >> shift;
+            out[(u64)s_gb[d] + (p - s_lb[d])] = x;
+        }
+    }
+}
+
+// slots [0, nslots) of the partitioned array: slot p belongs to region p >> shift and is filled iff
+// p < cursor[region]
+#define RSCAT_NT 256
+#define RSCAT_ITEMS 8
+__global__ __launch_bounds__(RSCAT_NT) void rank_scatter_kernel(const u64 *__restrict__ part, u64 nslots, int shift,
+                                                                 const u32 *__restrict__ cursor, u32 *__restrict__ isa) {
+    const u64 base = (u64)blockIdx.x * (RSCAT_NT * RSCAT_ITEMS);
+    u64 x[RSCAT_ITEMS];
+    bool ok[RSCAT_ITEMS];
+#pragma unroll
+    for (int k = 0; k < RSCAT_ITEMS; k++) {
+        const u64 p = base + (u64)k * RSCAT_NT + threadIdx.x;
+        ok[k] = p < nslots && (u32)p < cursor[p >> shift];
+        x[k] = ok[k] ? part[p] : 0ull;
+    }
+#pragma unroll
+    for (int k = 0; k < RSCAT_ITEMS; k++)
+        if (ok[k]) isa[(u32)(x[k] >> 32)] = (u32)x[k];
 }
 
 // ---- finish: order the small buckets left by a partial (top-bits) sort -----------
@@ -1131,6 +1222,16 @@ __global__ __launch_bounds__(256) void key2_kernel(const u32 *__restrict__ idx,
 }
 
 // primary = rank of suffix 0 (its SA position once everything is resolved)
+// TC_SA_TRACE: members per group-size class (class c: 2^c <= size < 2^(c+1)) of an active set in SA order
+__global__ __launch_bounds__(256) void group_size_hist_kernel(const u32 *__restrict__ slot, const u32 *__restrict__ grp,
+                                                               u32 m, u64 *__restrict__ hist) {
+    const u64 j = (u64)blockIdx.x * 256 + threadIdx.x;
+    if (j >= m) return;
+    if (j + 1 < m && grp[j + 1] == grp[j]) return;
+    const u32 size = slot[j] - grp[j] + 1u;
+    atomicAdd((unsigned long long *)&hist[31 - __builtin_clz(size)], (unsigned long long)size);
+}
+
 __global__ void primary_kernel(RankLookup r, u64 *scalars) {
     __shared__ u16 s_lut[256];
     for (int i = threadIdx.x; i < 256; i += blockDim.x) s_lut[i] = r.lut[i];
