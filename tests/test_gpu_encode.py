@@ -99,6 +99,10 @@ def test_mtf_general_sigma(ctx, sigma, monkeypatch):
         if with_nothing and N > 1:
             sym[rng.integers(0, N)] = -1
         eidx, efl = O.mtf_encode_arr(sym)
+        monkeypatch.setenv("TC_MTF_TS", "2")                       # timestamps (the default beyond 64 symbols)
+        idx, fl = ctx.mtf_encode_sym(sym)
+        assert np.array_equal(idx, eidx) and fl.tolist() == efl.tolist(), (sigma, N, skew)
+        monkeypatch.setenv("TC_MTF_TS", "0")                       # the list-shifting families
         idx, fl = ctx.mtf_encode_sym(sym)
         assert np.array_equal(idx, eidx) and fl.tolist() == efl.tolist(), (sigma, N, skew)
         if N == 100001 or N == 1100000:
@@ -112,6 +116,10 @@ def test_mtf_general_sigma(ctx, sigma, monkeypatch):
             Lb = np.where(sym < 0, 0, sym).astype(np.uint8)
             idx, fl = ctx.mtf_encode(Lb, prim)
             assert np.array_equal(idx, eidx) and fl.tolist() == efl.tolist()
+            monkeypatch.setenv("TC_MTF_TS", "2")
+            idx, fl = ctx.mtf_encode(Lb, prim)
+            assert np.array_equal(idx, eidx) and fl.tolist() == efl.tolist()
+        monkeypatch.delenv("TC_MTF_TS", raising=False)
         dec = ctx.mtf_decode(eidx, efl)
         assert np.array_equal(dec, sym)
 
@@ -158,6 +166,10 @@ def test_sigma_257_sentinel_split(ctx, t, monkeypatch):
         except textcomp.TcError as e:
             return ("error", e.args[0])
     got_bad = outcome(bad)
+    monkeypatch.setenv("TC_MTF_TS", "0")                 # the list-shifting families: sampled choice,
+    blk2 = ctx.encode(t)
+    assert blk2["final_list"].tolist() == efl.tolist() and np.array_equal(blk2["run_count"], ec)
+    assert np.array_equal(blk2["run_value"], ev)
     monkeypatch.setenv("TC_MTF_RANK_SAMPLE", "0")        # lane chunks whatever the ranks look like
     blk1 = ctx.encode(t)
     assert blk1["final_list"].tolist() == efl.tolist() and np.array_equal(blk1["run_count"], ec)

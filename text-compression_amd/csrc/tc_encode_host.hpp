@@ -857,6 +857,26 @@ static void mtf_general_launch(tc_ctx *ctx, Acc acc, u64 N, const Lut16 &lut, u1
     TC_LAUNCH_CHECK(ctx);
 }
 
+// any sigma > 16: timestamps (tc_mtf.hpp, "general path, timestamps"); the final list lands in `flist`
+template <class Acc, int ROWS>
+static void mtf_ts_launch(tc_ctx *ctx, Acc acc, u64 N, const Lut16 &lut, u32 sigma, u32 *ts, u32 *seg, u16 *flist,
+                          u16 *d_idx) {
+    hipStream_t s = ctx->stream;
+    const u32 chunks = tc_cdiv(N, TS_CH), nseg = tc_cdiv(chunks, TS_SEG);
+    mtf_ts_last_kernel<Acc><<<chunks, 256, 0, s>>>(acc, N, lut, ts);
+    TC_LAUNCH_CHECK(ctx);
+    mtf_ts_scan_kernel<0><<<nseg, TS_STRIDE, 0, s>>>(ts, chunks, seg, nseg, sigma);
+    TC_LAUNCH_CHECK(ctx);
+    mtf_ts_scan_kernel<1><<<1, TS_STRIDE, 0, s>>>(ts, chunks, seg, nseg, sigma);
+    TC_LAUNCH_CHECK(ctx);
+    mtf_ts_scan_kernel<2><<<nseg, TS_STRIDE, 0, s>>>(ts, chunks, seg, nseg, sigma);
+    TC_LAUNCH_CHECK(ctx);
+    mtf_ts_final_kernel<<<1, TS_STRIDE, 0, s>>>(seg + (size_t)nseg * TS_STRIDE, sigma, flist);
+    TC_LAUNCH_CHECK(ctx);
+    mtf_ts_apply_kernel<Acc, ROWS><<<tc_cdiv(chunks, TS_WPB), 64 * TS_WPB, 0, s>>>(acc, N, lut, ts, d_idx, chunks);
+    TC_LAUNCH_CHECK(ctx);
+}
+
 // sigma <= 256: one chunk per lane (tc_mtf.hpp, "general path, lane chunks")
 template <class Acc, int ROWS>
 static void mtf_lane_launch(tc_ctx *ctx, Acc acc, u64 N, const Alphabet &al, u16 *lists, u32 *seen,
@@ -891,8 +911,10 @@ static void mtf_encode_device(tc_ctx *ctx, Arena &A, Acc acc, u64 N, const u32 *
     u32 *d_counts = A.get<u32>(260);
     u64 *t_perm = A.get<u64>(tiles + 1);
     u32 *t_mask = A.get<u32>(tiles + 1 > 512 ? tiles + 1 : 512);
-    u16 *lists = A.get<u16>(((size_t)chunks + 1) * 320);
+    u16 *lists = A.get<u16>(((size_t)chunks + 4) * 320);   // (also: [N / TS_CH + 1][TS_STRIDE] u32 timestamps)
     u32 *seen = A.get<u32>(chunks + 1);
+    u32 *ts_seg = A.get<u32>(((size_t)tc_cdiv(tc_cdiv(N, TS_CH), TS_SEG) + 2) * TS_STRIDE);
+    u16 *ts_flist = A.get<u16>(TS_STRIDE);
     if (dry) return;
     hipStream_t s = ctx->stream;
     u32 local[257];
@@ -941,6 +963,24 @@ static void mtf_encode_device(tc_ctx *ctx, Arena &A, Acc acc, u64 N, const u32 *
         for (int v = 0; v < 257; v++) lut.v[v] = al.code_of_sym[v];
         int rows;
         u32 last;  // slot of the final list
+        // timestamps: the default beyond 64 symbols (1 GiB: uniform bytes 258 -> 37 ms, ASCII 81 -> 26 ms,
+        // Zipf words over all byte values 126 -> ~40 ms; up to 64 symbols the lane chunks are ahead on
+        // BWT-like streams: Zipf text, sigma 28, 12 against 23 ms).  TC_MTF_TS=0: never, 2: whenever sigma > 16.
+        const int ts_mode = env_int("TC_MTF_TS", 1);
+        if (ts_mode != 0 && (al.sigma > 64 || ts_mode == 2) && N + 300 < (1ull << 32)) {
+            rows = (int)((al.sigma + 63) / 64);
+            u32 *ts = reinterpret_cast<u32 *>(lists);
+            if (rows == 1) mtf_ts_launch<Acc, 1>(ctx, acc, N, lut, al.sigma, ts, ts_seg, ts_flist, d_idx);
+            else if (rows == 2) mtf_ts_launch<Acc, 2>(ctx, acc, N, lut, al.sigma, ts, ts_seg, ts_flist, d_idx);
+            else if (rows == 3) mtf_ts_launch<Acc, 3>(ctx, acc, N, lut, al.sigma, ts, ts_seg, ts_flist, d_idx);
+            else if (rows == 4) mtf_ts_launch<Acc, 4>(ctx, acc, N, lut, al.sigma, ts, ts_seg, ts_flist, d_idx);
+            else mtf_ts_launch<Acc, 5>(ctx, acc, N, lut, al.sigma, ts, ts_seg, ts_flist, d_idx);
+            std::vector<u16> fl(al.sigma);
+            tc_d2h(ctx, fl.data(), ts_flist, fl.size() * sizeof(u16));
+            TC_HIP(ctx, hipStreamSynchronize(s));
+            for (u32 i = 0; i < al.sigma; i++) final_list[i] = al.sym_of_code[fl[i]];
+            return;
+        }
         // large alphabets: lane chunks unless the sampled average rank says the symbols are spread
         // uniformly (tc_mtf.hpp, "which general path?")
         auto prefers_wave = [&](const Alphabet &ax) {

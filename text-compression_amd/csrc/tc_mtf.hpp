@@ -648,6 +648,147 @@ __global__ __launch_bounds__(64) void mtf_gen_apply_kernel(Acc acc, u64 N,
     }
 }
 
+// ---- general path, timestamps (the default beyond 64 symbols) -------------------------------
+// The MTF rank of a symbol is the number of distinct symbols met since its previous occurrence.  Give
+// every code a timestamp -- 257 + j for the code at position j, 256 - q for a code not met yet that
+// starts at list position q -- and the rank of code c at position i is the number of codes whose
+// timestamp exceeds c's: a compare per list entry instead of a shift of the list.  A wave keeps the
+// timestamps across its lanes (code q: row q / 64, lane q % 64): per symbol one v_readlane for c's own
+// timestamp, ROWS compares + scalar popcounts, one select for the update -- no cross-lane shuffle and
+// no dependence on the data (the list-shifting wave path spends ~60 wave instructions per symbol, the
+// lane chunks pay the largest rank among 64 lanes: 1 GiB of uniform bytes 258 ms, ASCII text 81 ms).
+// The state a chunk starts from is a prefix MAXIMUM per code over the chunks before it (last occurrence),
+// so the "summary" pass is one LDS atomicMax per run of equal symbols and the scan is 257 independent
+// max-scans -- no list composition.  N + 257 must fit 32 bits.
+//   mtf_ts_last_kernel   per chunk, per code: the largest timestamp in the chunk (0: code absent)
+//   mtf_ts_scan_kernel   phase 0: maxima per segment of TS_SEG chunks; phase 1: exclusive over segments
+//                        (seeded with the identity list), the last row = state after the text;
+//                        phase 2: exclusive inside every segment, in place
+//   mtf_ts_final_kernel  the list after the last symbol: position of code q = number of larger timestamps
+//   mtf_ts_apply_kernel  one wave per chunk, ranks out
+#define TS_CH 8192
+#define TS_STRIDE 320
+#define TS_SEG 256
+#ifndef TS_WPB
+#define TS_WPB 4
+#endif
+
+template <class Acc>
+__global__ __launch_bounds__(256) void mtf_ts_last_kernel(Acc acc, u64 N, Lut16 lut, u32 *__restrict__ ts) {
+    __shared__ u32 s_last[TS_STRIDE];
+    __shared__ u16 s_lut[260];
+    const u32 tid = threadIdx.x;
+    for (u32 i = tid; i < TS_STRIDE; i += 256) s_last[i] = 0;
+    for (u32 i = tid; i < 257; i += 256) s_lut[i] = lut.v[i];
+    __syncthreads();
+    const u64 base = (u64)blockIdx.x * TS_CH;
+    for (u32 o = 0; o < TS_CH; o += 256) {
+        const u64 j = base + o + tid;
+        const u32 code = j < N ? (u32)s_lut[acc(j) + 1] : 0xffffu;
+        // only the last position of a run of equal codes inside the wave goes to LDS
+        const u32 nxt = __shfl_down(code, 1, 64);
+        if (j < N && ((tid & 63) == 63 || nxt != code)) atomicMax(&s_last[code], (u32)j + 257u);
+    }
+    __syncthreads();
+    for (u32 i = tid; i < TS_STRIDE; i += 256) ts[(u64)blockIdx.x * TS_STRIDE + i] = s_last[i];
+}
+
+// seg: [nseg + 1][TS_STRIDE]
+template <int PHASE>
+__global__ __launch_bounds__(TS_STRIDE) void mtf_ts_scan_kernel(u32 *__restrict__ ts, u32 chunks, u32 *__restrict__ seg,
+                                                               u32 nseg, u32 sigma) {
+    const u32 q = threadIdx.x;
+    if (PHASE == 1) {
+        u32 run = q < sigma ? 256u - q : 0u;
+        for (u32 g = 0; g < nseg; g++) {
+            const u32 cur = seg[(u64)g * TS_STRIDE + q];
+            seg[(u64)g * TS_STRIDE + q] = run;
+            run = run > cur ? run : cur;
+        }
+        seg[(u64)nseg * TS_STRIDE + q] = run;
+        return;
+    }
+    const u32 g = blockIdx.x;
+    const u32 lo = g * TS_SEG, hi = lo + TS_SEG < chunks ? lo + TS_SEG : chunks;
+    if (PHASE == 0) {
+        u32 mx = 0;
+        for (u32 c = lo; c < hi; c++) {
+            const u32 v = ts[(u64)c * TS_STRIDE + q];
+            mx = mx > v ? mx : v;
+        }
+        seg[(u64)g * TS_STRIDE + q] = mx;
+    } else {
+        u32 run = seg[(u64)g * TS_STRIDE + q];
+#pragma unroll 4
+        for (u32 c = lo; c < hi; c++) {
+            const u32 cur = ts[(u64)c * TS_STRIDE + q];
+            ts[(u64)c * TS_STRIDE + q] = run;
+            run = run > cur ? run : cur;
+        }
+    }
+}
+
+__global__ __launch_bounds__(TS_STRIDE) void mtf_ts_final_kernel(const u32 *__restrict__ state, u32 sigma,
+                                                                u16 *__restrict__ list) {
+    __shared__ u32 s_ts[TS_STRIDE];
+    const u32 q = threadIdx.x;
+    s_ts[q] = state[q];
+    __syncthreads();
+    if (q >= sigma) return;
+    const u32 t = s_ts[q];
+    u32 pos = 0;
+    for (u32 i = 0; i < sigma; i++) pos += s_ts[i] > t ? 1u : 0u;
+    list[pos] = (u16)q;
+}
+
+// The table lives in LDS: c's own timestamp is a broadcast read at a wave-uniform address, the rows are
+// re-read every step (ROWS wide reads), lane 0 stores the update and the rank; the 64 ranks of a batch are
+// read back one per lane.  With the table in registers the row of c has to be selected by uniform branches
+// or three scalar instructions per row, and keeping the rows current costs a compare + select per row:
+// 1 GiB of uniform bytes (sigma 257) 65 ms and 54 ms that way, 37 ms this way (same results from stores by
+// every lane instead of lane 0, and from 8 waves per workgroup instead of 4).
+template <class Acc, int ROWS>
+__global__ __launch_bounds__(64 * TS_WPB) void mtf_ts_apply_kernel(Acc acc, u64 N, Lut16 lut, const u32 *__restrict__ ts_in,
+                                                                  u16 *__restrict__ idx, u32 chunks) {
+    // TS_WPB waves per workgroup, a chunk each (nothing shared: only so that enough waves fit a CU)
+    __shared__ u32 s_ts_all[TS_WPB][TS_STRIDE];
+    __shared__ u32 s_out_all[TS_WPB][64];
+    const u32 lane = lane_id(), wv = threadIdx.x >> 6;
+    const u32 chunk = blockIdx.x * TS_WPB + wv;
+    if (chunk >= chunks) return;
+    u32 *s_ts = s_ts_all[wv], *s_out = s_out_all[wv];
+    const u64 base = (u64)chunk * TS_CH;
+#pragma unroll
+    for (int r = 0; r < ROWS; r++) s_ts[r * 64 + lane] = ts_in[(u64)chunk * TS_STRIDE + r * 64 + lane];
+    wave_fence();
+    for (u32 o = 0; o < TS_CH; o += 64) {
+        if (base + o >= N) break;
+        const u64 j = base + o + lane;
+        const u32 code = j < N ? (u32)lut.v[acc(j) + 1] : 0u;
+        const u32 cnt = base + o + 64 <= N ? 64u : (u32)(N - (base + o));
+        const u32 stamp0 = (u32)(base + o) + 257u;
+        auto step = [&](u32 t) {
+            const u32 c = (u32)__builtin_amdgcn_readlane((int)code, (int)t);
+            const u32 tc = s_ts[c];
+            u32 rank = 0;
+#pragma unroll
+            for (int r = 0; r < ROWS; r++) rank += (u32)__popcll(__ballot(s_ts[r * 64 + lane] > tc));
+            if (lane == 0) {
+                s_ts[c] = stamp0 + t;
+                s_out[t] = rank;
+            }
+            wave_fence();   // (lane 0's store is read by the other lanes in the next step)
+        };
+        if (cnt == 64) {
+#pragma unroll 8
+            for (u32 t = 0; t < 64; t++) step(t);
+        } else {
+            for (u32 t = 0; t < cnt; t++) step(t);
+        }
+        if (j < N) idx[j] = (u16)s_out[lane];
+    }
+}
+
 // ---- general path, lane chunks (sigma <= 256: byte codes) -------------------------------
 // One chunk of GM_CH symbols per LANE (64 independent sequential chains per wave instead of
 // one): the lane's list is a byte array in LDS, four codes per dword; a step scans dwords from
