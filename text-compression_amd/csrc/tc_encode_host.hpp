@@ -873,7 +873,7 @@ static void mtf_ts_launch(tc_ctx *ctx, Acc acc, u64 N, const Lut16 &lut, u32 sig
     TC_LAUNCH_CHECK(ctx);
     mtf_ts_final_kernel<<<1, TS_STRIDE, 0, s>>>(seg + (size_t)nseg * TS_STRIDE, sigma, flist);
     TC_LAUNCH_CHECK(ctx);
-    mtf_ts_apply_kernel<Acc, ROWS><<<tc_cdiv(chunks, TS_WPB), 64 * TS_WPB, 0, s>>>(acc, N, lut, ts, d_idx, chunks);
+    mtf_ts_apply_kernel<Acc, ROWS><<<tc_cdiv(chunks, TS_WPB * TS_ILP), 64 * TS_WPB, 0, s>>>(acc, N, lut, ts, d_idx, chunks);
     TC_LAUNCH_CHECK(ctx);
 }
 

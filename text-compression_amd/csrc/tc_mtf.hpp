@@ -747,45 +747,83 @@ __global__ __launch_bounds__(TS_STRIDE) void mtf_ts_final_kernel(const u32 *__re
 // or three scalar instructions per row, and keeping the rows current costs a compare + select per row:
 // 1 GiB of uniform bytes (sigma 257) 65 ms and 54 ms that way, 37 ms this way (same results from stores by
 // every lane instead of lane 0, and from 8 waves per workgroup instead of 4).
+// A wave works on TS_ILP chunks at once (independent tables, steps interleaved): a step is a chain of LDS
+// round trips (store -> broadcast read -> row reads -> compares -> popcounts -> store), and one chain per wave
+// leaves the CU waiting on latency even with every wave slot taken.
+#ifndef TS_ILP
+#define TS_ILP 2
+#endif
 template <class Acc, int ROWS>
 __global__ __launch_bounds__(64 * TS_WPB) void mtf_ts_apply_kernel(Acc acc, u64 N, Lut16 lut, const u32 *__restrict__ ts_in,
                                                                   u16 *__restrict__ idx, u32 chunks) {
-    // TS_WPB waves per workgroup, a chunk each (nothing shared: only so that enough waves fit a CU)
-    __shared__ u32 s_ts_all[TS_WPB][TS_STRIDE];
-    __shared__ u32 s_out_all[TS_WPB][64];
+    // TS_WPB waves per workgroup (nothing shared between them: only so that enough waves fit a CU)
+    __shared__ u32 s_ts_all[TS_WPB][TS_ILP][TS_STRIDE];
+    __shared__ u32 s_out_all[TS_WPB][TS_ILP][64];
     const u32 lane = lane_id(), wv = threadIdx.x >> 6;
-    const u32 chunk = blockIdx.x * TS_WPB + wv;
-    if (chunk >= chunks) return;
-    u32 *s_ts = s_ts_all[wv], *s_out = s_out_all[wv];
-    const u64 base = (u64)chunk * TS_CH;
+    const u32 first = (blockIdx.x * TS_WPB + wv) * TS_ILP;
+    if (first >= chunks) return;
+    const u32 nk = chunks - first < (u32)TS_ILP ? chunks - first : (u32)TS_ILP;
+    for (u32 k = 0; k < nk; k++)
 #pragma unroll
-    for (int r = 0; r < ROWS; r++) s_ts[r * 64 + lane] = ts_in[(u64)chunk * TS_STRIDE + r * 64 + lane];
+        for (int r = 0; r < ROWS; r++)
+            s_ts_all[wv][k][r * 64 + lane] = ts_in[(u64)(first + k) * TS_STRIDE + r * 64 + lane];
     wave_fence();
-    for (u32 o = 0; o < TS_CH; o += 64) {
-        if (base + o >= N) break;
-        const u64 j = base + o + lane;
-        const u32 code = j < N ? (u32)lut.v[acc(j) + 1] : 0u;
-        const u32 cnt = base + o + 64 <= N ? 64u : (u32)(N - (base + o));
-        const u32 stamp0 = (u32)(base + o) + 257u;
-        auto step = [&](u32 t) {
-            const u32 c = (u32)__builtin_amdgcn_readlane((int)code, (int)t);
-            const u32 tc = s_ts[c];
-            u32 rank = 0;
+    if (TS_ILP > 1 && (u64)(first + TS_ILP) * TS_CH <= N) {   // TS_ILP whole chunks: interleaved
+        for (u32 o = 0; o < TS_CH; o += 64) {
+            u32 code[TS_ILP];
 #pragma unroll
-            for (int r = 0; r < ROWS; r++) rank += (u32)__popcll(__ballot(s_ts[r * 64 + lane] > tc));
-            if (lane == 0) {
-                s_ts[c] = stamp0 + t;
-                s_out[t] = rank;
+            for (int k = 0; k < TS_ILP; k++) code[k] = (u32)lut.v[acc((u64)(first + k) * TS_CH + o + lane) + 1];
+#pragma unroll 4
+            for (u32 t = 0; t < 64; t++) {
+                u32 c[TS_ILP], rank[TS_ILP];
+#pragma unroll
+                for (int k = 0; k < TS_ILP; k++) {
+                    c[k] = (u32)__builtin_amdgcn_readlane((int)code[k], (int)t);
+                    const u32 tc = s_ts_all[wv][k][c[k]];
+                    rank[k] = 0;
+#pragma unroll
+                    for (int r = 0; r < ROWS; r++)
+                        rank[k] += (u32)__popcll(__ballot(s_ts_all[wv][k][r * 64 + lane] > tc));
+                }
+                if (lane == 0) {
+#pragma unroll
+                    for (int k = 0; k < TS_ILP; k++) {
+                        s_ts_all[wv][k][c[k]] = (u32)((first + k) * TS_CH + o + t) + 257u;
+                        s_out_all[wv][k][t] = rank[k];
+                    }
+                }
+                wave_fence();   // (lane 0's stores are read by the other lanes in the next step)
             }
-            wave_fence();   // (lane 0's store is read by the other lanes in the next step)
-        };
-        if (cnt == 64) {
-#pragma unroll 8
-            for (u32 t = 0; t < 64; t++) step(t);
-        } else {
-            for (u32 t = 0; t < cnt; t++) step(t);
+#pragma unroll
+            for (int k = 0; k < TS_ILP; k++) idx[(u64)(first + k) * TS_CH + o + lane] = (u16)s_out_all[wv][k][lane];
+            wave_fence();
         }
-        if (j < N) idx[j] = (u16)s_out[lane];
+        return;
+    }
+    for (u32 k = 0; k < nk; k++) {   // the text's last chunks: one after the other
+        u32 *s_ts = s_ts_all[wv][k], *s_out = s_out_all[wv][k];
+        const u64 base = (u64)(first + k) * TS_CH;
+        for (u32 o = 0; o < TS_CH; o += 64) {
+            if (base + o >= N) break;
+            const u64 j = base + o + lane;
+            const u32 code = j < N ? (u32)lut.v[acc(j) + 1] : 0u;
+            const u32 cnt = base + o + 64 <= N ? 64u : (u32)(N - (base + o));
+            const u32 stamp0 = (u32)(base + o) + 257u;
+            for (u32 t = 0; t < cnt; t++) {
+                const u32 c = (u32)__builtin_amdgcn_readlane((int)code, (int)t);
+                const u32 tc = s_ts[c];
+                u32 rank = 0;
+#pragma unroll
+                for (int r = 0; r < ROWS; r++) rank += (u32)__popcll(__ballot(s_ts[r * 64 + lane] > tc));
+                if (lane == 0) {
+                    s_ts[c] = stamp0 + t;
+                    s_out[t] = rank;
+                }
+                wave_fence();
+            }
+            if (j < N) idx[j] = (u16)s_out[lane];
+            wave_fence();
+        }
     }
 }
 
