@@ -25,6 +25,10 @@ int tc_dbg_sort_bench(tc_ctx *ctx, uint64_t n, int key_bits, int iters, int chec
  * segments per tile, each behind the same segment of the previous tile; xrun > 0: blocks on the
  * same XCD take tiles in runs of xrun (the pass's XCD-aware order); mean ms per pass. */
 int tc_dbg_scatter_bench(tc_ctx *ctx, uint64_t n, uint32_t bins, uint32_t xrun, int iters, double *ms_per_pass);
+/* Where the hardware puts the workgroups of a grid launched on this context's stream: `grid` workgroups of 1024
+ * threads with `lds_bytes` of LDS each (147456: one per CU) spin for `spin_cycles`; out6[6 * grid] (host)
+ * receives per workgroup: XCC id, HW_ID register, start (2 words, 100 MHz wall clock), duration, scratch. */
+int tc_dbg_dispatch_probe(tc_ctx *ctx, uint32_t grid, uint32_t lds_bytes, uint32_t spin_cycles, uint32_t *out6);
 #ifdef __cplusplus
 }
 #endif

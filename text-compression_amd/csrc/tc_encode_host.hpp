@@ -207,6 +207,9 @@ static void sa_run(tc_ctx *ctx, SaBuffers &b, const u8 *d_text, u64 n, u32 *d_sa
     hipStream_t s = ctx->stream;
     tc_stats &st = ctx->stats;
 
+    if (env_int("TC_SA_TRACE", 0) == 2)
+        fprintf(stderr, "textcomp: buffers text %p k0 %p k1 %p v0 %p v1 %p sa %p L %p\n", (const void *)d_text, (void *)b.k0,
+                (void *)b.k1, (void *)b.v0, (void *)b.v1, (void *)d_sa, (void *)d_L);
     // 1. alphabet
     tc_memset_async(ctx, b.counts, 0, 256 * sizeof(u32));
     {

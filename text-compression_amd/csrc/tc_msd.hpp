@@ -195,6 +195,17 @@ struct MsdTextDigit {
     u16 lut[256];
 };
 
+// Workgroups are dealt round-robin over the 8 XCDs (blockIdx % 8); each XCD has its own L2 and its own
+// second-level TLB.  The static work split hands workgroup b the b-th slice of the array, so with b = blockIdx
+// every XCD touches every part of the 26 GB a level moves; with this mapping XCD x works on the x-th eighth
+// (levels 2 and 3 write where they read: an eighth of the pages per TLB).
+#ifndef MSD_XCD_MAP
+#define MSD_XCD_MAP 1
+#endif
+__device__ __forceinline__ u32 msd_logical_wg(u32 b, u32 G) {
+    return (MSD_XCD_MAP && (G & 7u) == 0) ? (b & 7u) * (G >> 3) + (b >> 3) : b;
+}
+
 // ---- per-segment digit counts ------------------------------------------------------------------
 // keys: digit = (key >> shift) & 255.  TEXT (level 1): digit = field 0 of suffix i = its first s
 // symbols in base B, straight from the text (two overlapping word loads per 4 suffixes where the
@@ -218,7 +229,7 @@ __global__ __launch_bounds__(MSD_NT) void msd_count_kernel(MsdLevel L, const u64
     __shared__ u16 s_lut[TEXT ? 256 : 1];
     __shared__ u32 s_seg[4];   // q, lo, hi, next tile
     __shared__ u32 s_joint[JOINT ? 32768 : 1];
-    const u32 tid = threadIdx.x, b = blockIdx.x, G = gridDim.x;
+    const u32 tid = threadIdx.x, G = gridDim.x, b = msd_logical_wg(blockIdx.x, G);
     if (tid < 256) s_cnt[tid] = 0;
     if (TEXT && tid < 256) s_lut[tid] = td.lut[tid];
     __shared__ u8 s_row[JOINT ? 256 : 1];
@@ -413,7 +424,7 @@ __global__ __launch_bounds__(MSD_NT) void msd_partition_kernel(MsdLevel L, const
     static_assert(((size_t)MSD_TILE * 12 + 256 * MSD_GROUP * 12 + 8192) * MSD_BPC <= 163840, "LDS budget");
     __shared__ MsdTileInfo s_info[4];
 
-    const u32 tid = threadIdx.x, b = blockIdx.x, G = gridDim.x;
+    const u32 tid = threadIdx.x, G = gridDim.x, b = msd_logical_wg(blockIdx.x, G);
     if (KEYGEN && tid < 256) s_klut[tid] = kg.lut[tid];
     if (tid < 256) { s_r[tid] = 0; s_ph[tid] = 0; s_cur[tid] = 0; }
     for (u32 i = tid; i < 256 * MSD_SUB; i += MSD_NT) s_cnt[i] = 0;

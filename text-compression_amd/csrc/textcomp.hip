@@ -1682,6 +1682,44 @@ int tc_dbg_scatter_bench(tc_ctx *ctx, uint64_t n, uint32_t bins, uint32_t xrun, 
     TC_API_END(ctx)
 }
 
+// Where the hardware puts the workgroups of a one-per-CU grid launched on this context's stream:
+// (XCC id, HW_ID, start and end of each workgroup in device clock ticks).
+__global__ __launch_bounds__(1024) void dbg_dispatch_kernel(u32 *out, u32 spin) {
+    extern __shared__ u32 s_big[];
+    u32 hwid = 0, xcc = 0;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+    const u64 t0 = __builtin_readcyclecounter();
+    const u64 w0 = wall_clock64();
+    s_big[threadIdx.x] = threadIdx.x;
+    __syncthreads();
+    u32 acc = 0;
+    while (__builtin_readcyclecounter() - t0 < spin) acc += s_big[(threadIdx.x + acc) & 1023];
+    const u64 w1 = wall_clock64();
+    if (threadIdx.x == 0) {
+        out[blockIdx.x * 6 + 0] = xcc;
+        out[blockIdx.x * 6 + 1] = hwid;
+        out[blockIdx.x * 6 + 2] = (u32)w0;
+        out[blockIdx.x * 6 + 3] = (u32)(w0 >> 32);
+        out[blockIdx.x * 6 + 4] = (u32)(w1 - w0);
+        out[blockIdx.x * 6 + 5] = acc;
+    }
+}
+
+int tc_dbg_dispatch_probe(tc_ctx *ctx, uint32_t grid, uint32_t lds_bytes, uint32_t spin_cycles, uint32_t *out6) {
+    TC_API_BEGIN(ctx)
+    if (!out6 || grid < 1 || grid > 65536 || lds_bytes < 4096 || lds_bytes > 160 * 1024) TC_FAIL(ctx, TC_ERR_ARG, "bad argument");
+    tc_ws_reserve(ctx, (size_t)grid * 6 * sizeof(u32) + 512);
+    u32 *d = reinterpret_cast<u32 *>(ctx->ws);
+    TC_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(dbg_dispatch_kernel),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
+    dbg_dispatch_kernel<<<grid, 1024, lds_bytes, ctx->stream>>>(d, spin_cycles);
+    TC_LAUNCH_CHECK(ctx);
+    tc_d2h(ctx, out6, d, (size_t)grid * 6 * sizeof(u32));
+    TC_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    TC_API_END(ctx)
+}
+
 int tc_dbg_sort_bench(tc_ctx *ctx, uint64_t n, int key_bits, int iters, int check, double *ms_per_pass) {
     TC_API_BEGIN(ctx)
     if (!ms_per_pass || n < 2 || n > TC_MAX_N || key_bits < 1 || key_bits > 56 || iters < 1)
