@@ -195,12 +195,12 @@ struct MsdTextDigit {
     u16 lut[256];
 };
 
-// Workgroups are dealt round-robin over the 8 XCDs (blockIdx % 8); each XCD has its own L2 and its own
-// second-level TLB.  The static work split hands workgroup b the b-th slice of the array, so with b = blockIdx
-// every XCD touches every part of the 26 GB a level moves; with this mapping XCD x works on the x-th eighth
-// (levels 2 and 3 write where they read: an eighth of the pages per TLB).
+// Workgroups are dealt round-robin over the 8 XCDs (blockIdx % 8; tc_dbg_dispatch_probe shows it), and the
+// static work split hands workgroup b the b-th slice of the array, so every XCD touches every part of the
+// 26 GB a level moves.  MSD_XCD_MAP = 1 gives XCD x the x-th eighth instead (levels 2 and 3 write where they
+// read).  Measured at 1 GiB: no difference in either of the two step-time modes -- left off.
 #ifndef MSD_XCD_MAP
-#define MSD_XCD_MAP 1
+#define MSD_XCD_MAP 0
 #endif
 __device__ __forceinline__ u32 msd_logical_wg(u32 b, u32 G) {
     return (MSD_XCD_MAP && (G & 7u) == 0) ? (b & 7u) * (G >> 3) + (b >> 3) : b;
