@@ -194,6 +194,24 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    # set-up, before any warm-up or timed step: the context tries a few placements of its workspace with this
+    # record and keeps the fastest (tc_ctx_place_workspace; the partition levels of a long record run at one of
+    # two speeds depending on where the workspace lands -- DESIGN.md section 8).  TC_BENCH_PLACE=0: skip.
+    placement = None
+    if os.environ.get("TC_BENCH_PLACE", "1") != "0" and n >= (1 << 28):
+        tries = int(os.environ.get("TC_BENCH_PLACE_TRIES", "5"))
+        pms = (C.c_double * 8)()
+        pch = C.c_int(-1)
+        blk.nruns = cap
+        blk.run_count = d_cnt.data_ptr()
+        blk.run_value = d_val.data_ptr()
+        tp0 = time.perf_counter()
+        rc = lib.tc_ctx_place_workspace(ctx.handle, C.c_void_p(d_text.data_ptr()), n, C.byref(blk), tries, pms, C.byref(pch))
+        if rc != 0:
+            raise RuntimeError("tc_ctx_place_workspace rc=%d: %s" % (rc, lib.tc_last_error(ctx.handle).decode()))
+        placement = {"encode_ms_per_placement": [round(x, 2) for x in pms if x > 0], "chosen": pch.value,
+                     "seconds": round(time.perf_counter() - tp0, 2)}
+
     for _ in range(a.warmup):
         step()
     fence()
@@ -276,6 +294,7 @@ def main():
                        "record_bytes": n, "records": world, "parallelism": "record-per-gpu x%d" % world},
             "roofline": roof,
             "gather": gathered,
+            "workspace_placement": placement,
             "stages_ms": {"suffix_sort+bwt": round(st.ms_sa, 3), "mtf": round(st.ms_mtf, 3), "rle": round(st.ms_rle, 3),
                           "rounds": int(st.rounds), "m": [int(st.m[i]) for i in range(st.rounds)],
                           "passes": [int(st.passes[i]) for i in range(st.rounds)], "runs": int(st.runs),

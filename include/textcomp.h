@@ -111,6 +111,16 @@ int tc_get_stats(const tc_ctx *ctx, tc_stats *out);
 void *tc_ctx_stream(const tc_ctx *ctx);
 /* on != 0: bracket every round-0 radix pass with HIP events (tc_stats.ms_radix). */
 int tc_ctx_set_profile(tc_ctx *ctx, int on);
+/* Workspace placement.  Where the context's workspace lands in device memory decides which of two speeds the
+ * partition levels of a long record run at (1 GiB ACGTN on MI355X: 28.9 or 31.0 ms per encode, fixed for the
+ * life of the workspace).  This call encodes the caller's representative record
+ * (arguments as tc_encode_dev; `out` is overwritten) on up to `tries` differently placed workspaces -- a
+ * rejected block stays allocated until the call ends, so that the next one lands elsewhere; blocks are only
+ * added while device memory has room for them -- and keeps the fastest.  ms (host, [tries], optional)
+ * receives the encode time per placement (0 = not tried), *chosen its index.  Not part of the reference's
+ * surface: a set-up step for long-lived contexts, before any timed work. */
+int tc_ctx_place_workspace(tc_ctx *ctx, const uint8_t *d_text, uint64_t n, tc_block *out, int tries, double *ms,
+                           int *chosen);
 
 /* ---- Data.BWT ------------------------------------------------------------ */
 /* bytestringToBWT (BWT.hs:68-70) = toBWT (:55-64) = createSuffixArray

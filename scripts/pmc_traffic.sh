@@ -4,6 +4,7 @@
 # scripts/pmc_calib.sh on 4/8/16-byte-per-lane streams), WRITE_SIZE is exact.  Units: KB.
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 N=${1:-1073741824}
+export TC_BENCH_PLACE=0   # (one placement: the counters are per launch, the mode does not change the bytes)
 for c in FETCH_SIZE WRITE_SIZE; do
   rm -rf gpurun_out/pmc_$c
   rocprofv3 --pmc $c --kernel-trace --output-format csv -d gpurun_out/pmc_$c -- python bench.py --n $N --steps 1 --warmup 1 --no-cpu-baseline > gpurun_out/pmc_$c.log 2>&1

@@ -3,6 +3,7 @@
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 TAG=${1:-x}; shift
 rm -rf gpurun_out/prof_$TAG
+export TC_BENCH_PLACE=${TC_BENCH_PLACE:-0}   # (the placement search would mix the encodes of rejected placements into the averages)
 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_$TAG -- python bench.py --steps 3 --warmup 1 --no-cpu-baseline "$@" > gpurun_out/prof_${TAG}_bench.log 2>&1
 python - <<PY
 import csv,glob

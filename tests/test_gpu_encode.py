@@ -509,3 +509,32 @@ def test_dense_ranks_by_regions(ctx, monkeypatch, n):
         assert np.array_equal(ctx.suffix_array(t), ref)
         monkeypatch.delenv("TC_SA_DENSE")
         monkeypatch.delenv("TC_SA_FIELDS")
+
+
+def test_place_workspace_keeps_results(ctx):
+    """tc_ctx_place_workspace re-allocates the workspace (several blocks alive at once, the fastest kept):
+    the block it leaves in `out` and every later call give the oracle's results."""
+    import ctypes as C
+    import torch
+    from textcomp import Block
+    t = O.gen_acgtn(41, 300000)
+    eL, eprim, sym = _expect_bwt(t)
+    eidx, efl = O.mtf_encode_arr(sym)
+    ec, ev = O.rle_encode_u32_arr(eidx)
+    d_text = torch.from_numpy(t.copy()).cuda()
+    cap = len(t) + 16
+    d_cnt = torch.empty(cap, dtype=torch.int32, device="cuda")
+    d_val = torch.empty(cap, dtype=torch.int16, device="cuda")
+    blk = Block()
+    blk.nruns = cap
+    blk.run_count = d_cnt.data_ptr()
+    blk.run_value = d_val.data_ptr()
+    torch.cuda.synchronize()
+    ms, chosen = ctx.place_workspace(d_text.data_ptr(), len(t), blk, tries=3)
+    assert 1 <= len(ms) <= 3 and 0 <= chosen < len(ms)
+    assert int(blk.primary) == eprim and int(blk.nruns) == len(ec)
+    assert np.array_equal(d_cnt[:len(ec)].cpu().numpy().astype(np.uint32), ec)
+    assert np.array_equal(d_val[:len(ec)].cpu().numpy().astype(np.uint16), ev)
+    b2 = ctx.encode(t)                                   # the context goes on working on the kept block
+    assert b2["primary"] == eprim and np.array_equal(b2["run_count"], ec)
+    assert ctx.suffix_array(t.tobytes()).tolist() == O.suffix_array(t.tobytes()).tolist()

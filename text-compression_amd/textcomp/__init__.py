@@ -69,6 +69,14 @@ class Context:
     def lib(self):
         return self._lib
 
+    def place_workspace(self, d_text_ptr, n, blk, tries=5):
+        """tc_ctx_place_workspace: encode the record at device address d_text_ptr on up to `tries` workspace
+        placements, keep the fastest; returns (ms per placement tried, chosen index)."""
+        ms = (C.c_double * 8)()
+        ch = C.c_int(-1)
+        self._check(self._lib.tc_ctx_place_workspace(self._h, C.c_void_p(d_text_ptr), n, C.byref(blk), tries, ms, C.byref(ch)))
+        return [x for x in ms if x > 0], ch.value
+
     def stats(self):
         s = Stats()
         self._check(self._lib.tc_get_stats(self._h, C.byref(s)))

@@ -57,6 +57,7 @@ SYMBOLS = [
     ("tc_get_stats", _INT, [_P, C.POINTER(Stats)]),
     ("tc_ctx_stream", _P, [_P]),
     ("tc_ctx_set_profile", _INT, [_P, _INT]),
+    ("tc_ctx_place_workspace", _INT, [_P, _P, _U64, _P, _INT, _P, _P]),
     ("tc_bwt_encode", _INT, [_P, _P, _U64, _P, _PU64]),
     ("tc_bwt_encode_dev", _INT, [_P, _P, _U64, _P, _PU64]),
     ("tc_suffix_array", _INT, [_P, _P, _U64, _P]),
