@@ -104,3 +104,53 @@ def test_full_size_roundtrip(n):
     if n == (1 << 30):      # bit-exact against the oracle's encode of this record
         _assert_digest(lib, ctx, DIGESTS["n%d" % n], blk, d_cnt, d_val, d_text)
     ctx.close()
+
+
+def _encode_digest(lib, ctx, d_text, n, d_cnt, d_val, cap):
+    from textcomp import Block
+    blk = Block()
+    blk.nruns, blk.run_count, blk.run_value = cap, d_cnt.data_ptr(), d_val.data_ptr()
+    rc = lib.tc_encode_dev(ctx.handle, C.c_void_p(d_text.data_ptr()), n, C.byref(blk))
+    assert rc == 0, lib.tc_last_error(ctx.handle)
+    k = int(blk.nruns)
+    if k & 1:
+        d_val[k] = 0
+    return (int(blk.primary), int(blk.sigma), k, [int(blk.final_list[i]) for i in range(int(blk.sigma))],
+            _checksum(lib, ctx, d_cnt, 4 * k), _checksum(lib, ctx, d_val, 2 * (k + (k & 1)))), blk
+
+
+@pytest.mark.parametrize("kind", ["bytes256", "ascii96", "wordy"])
+def test_round2_paths_agree_at_scale(kind, monkeypatch):
+    """2^28-byte records away from the benchmark's class: the paths added in round 2 (MTF by timestamps beyond
+    64 symbols; dense ranks stored by regions) produce the same block, digest for digest, as the paths they
+    replace (TC_MTF_TS=0, TC_SA_BIN_MIN_LOG2=40), and the block decodes to the input."""
+    import torch
+    import textcomp
+    n = 1 << 28
+    g = torch.Generator(device="cuda")
+    g.manual_seed(12)
+    if kind == "bytes256":
+        d_text = torch.randint(0, 256, (n,), generator=g, device="cuda", dtype=torch.int32).to(torch.uint8)
+    elif kind == "ascii96":
+        d_text = (torch.randint(0, 96, (n,), generator=g, device="cuda", dtype=torch.int32) + 32).to(torch.uint8)
+    else:   # words over a small vocabulary: nearly every suffix stays tied after round 0 (dense mode, large rounds)
+        vocab = torch.randint(97, 123, (4096, 8), generator=g, device="cuda", dtype=torch.int32).to(torch.uint8)
+        vocab[:, 7] = 32
+        ids = (torch.rand(n // 8, generator=g, device="cuda") ** 3 * 4096).long().clamp_(0, 4095)
+        d_text = vocab[ids].reshape(-1).contiguous()
+    torch.cuda.synchronize()
+    ctx = textcomp.Context(0)
+    lib = ctx.lib
+    cap = n + 2
+    d_cnt = torch.empty(cap, dtype=torch.int32, device="cuda")
+    d_val = torch.empty(cap, dtype=torch.int16, device="cuda")
+    new, blk = _encode_digest(lib, ctx, d_text, n, d_cnt, d_val, cap)
+    d_back = torch.empty(n, dtype=torch.uint8, device="cuda")
+    assert lib.tc_decode_dev(ctx.handle, C.byref(blk), C.c_void_p(d_back.data_ptr())) == 0, lib.tc_last_error(ctx.handle)
+    torch.cuda.synchronize()
+    assert torch.equal(d_back, d_text)
+    monkeypatch.setenv("TC_MTF_TS", "0")
+    monkeypatch.setenv("TC_SA_BIN_MIN_LOG2", "40")
+    old, _ = _encode_digest(lib, ctx, d_text, n, d_cnt, d_val, cap)
+    assert new == old
+    ctx.close()

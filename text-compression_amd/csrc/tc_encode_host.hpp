@@ -271,7 +271,7 @@ static void sa_run(tc_ctx *ctx, SaBuffers &b, const u8 *d_text, u64 n, u32 *d_sa
         u32 *cursor = b.hist;   // (free between the radix passes of two rounds)
         rank_cursor_kernel<<<1, 256, 0, s>>>(cursor, rshift);
         TC_LAUNCH_CHECK(ctx);
-        rank_bin_kernel<<<tc_cdiv(count, RBIN_TILE), RBIN_NT, 0, s>>>(pairs, count, rshift, cursor, part);
+        rank_bin_kernel<<<tc_cdiv(count, RBIN_TILE), RBIN_NT, 0, s>>>(pairs, count, rshift, cursor, part, N);
         TC_LAUNCH_CHECK(ctx);
         rank_scatter_kernel<<<tc_cdiv(N, RSCAT_NT * RSCAT_ITEMS), RSCAT_NT, 0, s>>>(part, N, rshift, cursor, b.isa);
         TC_LAUNCH_CHECK(ctx);

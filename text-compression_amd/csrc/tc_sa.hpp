@@ -483,7 +483,7 @@ __global__ __launch_bounds__(256) void rank_cursor_kernel(u32 *cursor, int shift
 }
 
 __global__ __launch_bounds__(RBIN_NT) void rank_bin_kernel(const u64 *__restrict__ in, u32 m, int shift,
-                                                           u32 *__restrict__ cursor, u64 *__restrict__ out) {
+                                                           u32 *__restrict__ cursor, u64 *__restrict__ out, u64 nslots) {
     __shared__ u64 s_stage[RBIN_TILE];
     __shared__ u32 s_cnt[256], s_lb[256], s_gb[256];
     __shared__ u32 s_scan[RBIN_NT / 64 + 1];
@@ -525,7 +525,8 @@ __global__ __launch_bounds__(RBIN_NT) void rank_bin_kernel(const u64 *__restrict
         if (p < valid) {
             const u64 x = s_stage[p];
             const u32 d = (u32)(x >> 32) >> shift;
-            out[(u64)s_gb[d] + (p - s_lb[d])] = x;
+            const u64 g = (u64)s_gb[d] + (p - s_lb[d]);
+            if (g < nslots) out[g] = x;   // (always, while the starts are distinct; a guard against a caller's mistake)
         }
     }
 }

@@ -415,6 +415,7 @@ int tc_ctx_place_workspace(tc_ctx *ctx, const uint8_t *d_text, uint64_t n, tc_bl
     try {
         t.push_back(timed());          // placement 0: the workspace the context has (sized by this very encode)
         best_ws = ctx->ws;
+        const size_t cap0 = ctx->ws_cap;
         for (int k = 1; k < tries; k++) {
             double worst = 0;
             for (double v : t) worst = v > worst ? v : worst;
@@ -430,6 +431,12 @@ int tc_ctx_place_workspace(tc_ctx *ctx, const uint8_t *d_text, uint64_t n, tc_bl
             }
             ctx->ws = cand;            // (the best block so far stays allocated: the candidate lands elsewhere)
             t.push_back(timed());
+            if (ctx->ws_cap != cap0) {   // the workspace grew under the candidate (cannot happen for one record): keep it
+                (void)hipFree(best_ws);
+                best_ws = ctx->ws;
+                best = k;
+                break;
+            }
             char *loser = cand;
             if (t[k] < t[best]) {
                 best = k;
