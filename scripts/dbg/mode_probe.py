@@ -6,7 +6,8 @@ fixed for the life of a context.  What decides it?
     blockIdx % 8 in both modes.
 Round-2 findings: not the stream (four streams of one context measure alike), not its priority, not the
 placement of the workgroups, not the distance between the ping-pong buffers (padding them changes nothing
-systematic), and a plain copy between the same buffers runs at 5.0 TB/s in both modes: it is where the
+systematic), not the 2^25-byte spacing of the workgroups' slices (240, 248, 250 workgroups instead of 256:
+scripts/dbg/grid_probe.sh), and a plain copy between the same buffers runs at 5.0 TB/s in both modes: it is where the
 workspace lands in physical memory, it shows only in the kernels that read 13 GB and write 13 GB at once,
 and nothing this library controls selects it."""
 import ctypes as C, os, sys, time
