@@ -611,52 +611,75 @@ __global__ __launch_bounds__(MSD_NT) void msd_partition_kernel(MsdLevel L, const
         }
         const bool fastkg = KEYGEN && kg.s <= 3 && MSD_ITEMS == 8 && !kg_edge(ti);
         if (fastkg) {
-            // interior tile, fields of <= 3 symbols: thread t builds the keys of the 8 CONSECUTIVE suffixes
-            // 8 t .. 8 t + 7 (which thread handles which pair is free: the tile is permuted anyway) from the
-            // 8 + 7 s - 1 symbols they span -- one LUT read per symbol, everything else in registers
+            // interior tile, fields of <= 3 symbols.  Two steps.  (A) every thread turns ITS 8 positions into field
+            // values g(p) = the s symbols from p on (a byte each: B^s <= 256) and leaves them in LDS -- 10 LUT
+            // reads and 16 multiply-adds per thread; (B) thread t assembles the keys of the 8 CONSECUTIVE suffixes
+            // 8 t .. 8 t + 7 (which thread handles which pair is free: the tile is permuted anyway) from the 32
+            // field bytes behind its first position: field f of suffix k is g(k + s f), so a key is seven byte
+            // selections -- three v_perm_b32 per 32-bit half, constant selectors.  (The first version built all
+            // 26 field values of a thread's window in registers, every thread for itself: 28 LUT reads, ~250
+            // VALU per thread; level 1: 5.44 -> 5.12 ms.  Issuing the level's small prefetch after the keys instead of before
+            // them -- right behind B0 the memory pipeline is still full of the previous tile's stores -- moves the wait,
+            // it does not remove it: the level is bound by its 13 GB of scattered stores, 43 % of the fill rate.)
             if (tid < kg_units) *reinterpret_cast<uint4 *>(k_r + tid * 16) = make_uint4(raw.x, raw.y, raw.z, raw.w);
             __syncthreads();
-            const u64 *rp = reinterpret_cast<const u64 *>(k_r + KG_PRE + 8 * tid - 8);
-            const u64 w[5] = {rp[0], rp[1], rp[2], rp[3], rp[4]};
+            u8 *k_g8 = reinterpret_cast<u8 *>(k_c);   // field bytes of positions 0 .. MSD_TILE + 23 (the u16 images are unused here)
             const u32 B = kg.B;
-            auto code = [&](int j) { return (u32)s_klut[(u32)(w[1 + (j >> 3)] >> (8 * (j & 7))) & 255u]; };
+            auto gen_group = [&](u32 grp) {   // positions 8 grp .. 8 grp + 7
+                const u32 *rp = reinterpret_cast<const u32 *>(k_r + KG_PRE + 8 * grp);
+                const u32 x0 = rp[0], x1 = rp[1], x2 = rp[2];
+                u32 c[10];
 #pragma unroll
-            for (int k = 0; k < 8; k++) {
-                const u32 prev = k == 0 ? (u32)(w[0] >> 56) : (u32)(w[1] >> (8 * (k - 1))) & 255u;
-                key[k] = (u64)prev;
-            }
-            // field value g(j) = the s symbols from j on; it is field f of suffix k = j - s f
-            if (kg.s == 3) {
-                u32 c0 = code(0), c1 = code(1);
-#pragma unroll
-                for (int j = 0; j < 26; j++) {
-                    const u32 c2 = code(j + 2);
-                    const u64 g = (u64)((c0 * B + c1) * B + c2);
-#pragma unroll
-                    for (int f = 0; f < 7; f++)
-                        if (j - 3 * f >= 0 && j - 3 * f < 8) key[j - 3 * f] |= g << (56 - 8 * f);
-                    c0 = c1;
-                    c1 = c2;
+                for (int j = 0; j < 4; j++) {
+                    c[j] = (u32)s_klut[(x0 >> (8 * j)) & 255u];
+                    c[4 + j] = (u32)s_klut[(x1 >> (8 * j)) & 255u];
                 }
-            } else if (kg.s == 2) {
-                u32 c0 = code(0);
+                c[8] = (u32)s_klut[x2 & 255u];
+                c[9] = (u32)s_klut[(x2 >> 8) & 255u];
+                u32 lo = 0, hi = 0;
 #pragma unroll
-                for (int j = 0; j < 20; j++) {
-                    const u32 c1 = code(j + 1);
-                    const u64 g = (u64)(c0 * B + c1);
-#pragma unroll
-                    for (int f = 0; f < 7; f++)
-                        if (j - 2 * f >= 0 && j - 2 * f < 8) key[j - 2 * f] |= g << (56 - 8 * f);
-                    c0 = c1;
+                for (int j = 0; j < 8; j++) {
+                    const u32 g = kg.s == 3 ? (c[j] * B + c[j + 1]) * B + c[j + 2] : kg.s == 2 ? c[j] * B + c[j + 1] : c[j];
+                    if (j < 4) lo |= g << (8 * j);
+                    else hi |= g << (8 * (j - 4));
                 }
-            } else {
+                *reinterpret_cast<uint2 *>(k_g8 + 8 * grp) = make_uint2(lo, hi);
+            };
+            gen_group(tid);
+            if (tid < 3) gen_group(MSD_NT + tid);   // the 6 s <= 18 positions behind the tile that its last suffixes reach
+            __syncthreads();
+            {
+                const u32 *gp = reinterpret_cast<const u32 *>(k_g8 + 8 * tid);
+                u32 D[8];
 #pragma unroll
-                for (int j = 0; j < 14; j++) {
-                    const u64 g = (u64)code(j);
+                for (int i = 0; i < 8; i++) D[i] = gp[i];
+                // the byte before each suffix: text bytes p - 1 .. p + 6
+                const u32 *rq = reinterpret_cast<const u32 *>(k_r + KG_PRE + 8 * tid - 4);
+                const u32 r0 = rq[0], r1 = rq[1], r2 = rq[2];
+                const u32 PR[2] = {__builtin_amdgcn_alignbyte(r1, r0, 3), __builtin_amdgcn_alignbyte(r2, r1, 3)};
+                // byte j of the field bytes / byte k of PR into the wanted byte lane
+                auto pick2 = [&](u32 X, int bx, u32 Y, int by, bool upper) -> u32 {
+                    // upper: X.byte[bx] -> result byte 3, Y.byte[by] -> result byte 2; else -> bytes 1, 0
+                    const u32 sel = upper ? ((u32)(4 + bx) << 24) | ((u32)by << 16) : ((u32)(4 + bx) << 8) | (u32)by;
+                    return __builtin_amdgcn_perm(X, Y, sel);
+                };
+                auto build = [&](auto S) {
+                    constexpr int SS = decltype(S)::value;
 #pragma unroll
-                    for (int f = 0; f < 7; f++)
-                        if (j - f >= 0 && j - f < 8) key[j - f] |= g << (56 - 8 * f);
-                }
+                    for (int k = 0; k < 8; k++) {
+                        const int j0 = k, j1 = k + SS, j2 = k + 2 * SS, j3 = k + 3 * SS, j4 = k + 4 * SS, j5 = k + 5 * SS, j6 = k + 6 * SS;
+                        const u32 hA = pick2(D[j0 >> 2], j0 & 3, D[j1 >> 2], j1 & 3, true);
+                        const u32 hB = pick2(D[j2 >> 2], j2 & 3, D[j3 >> 2], j3 & 3, false);
+                        const u32 lA = pick2(D[j4 >> 2], j4 & 3, D[j5 >> 2], j5 & 3, true);
+                        const u32 lB = pick2(D[j6 >> 2], j6 & 3, PR[k >> 2], k & 3, false);
+                        const u32 hi = __builtin_amdgcn_perm(hA, hB, 0x07060100u);
+                        const u32 lo = __builtin_amdgcn_perm(lA, lB, 0x07060100u);
+                        key[k] = ((u64)hi << 32) | (u64)lo;
+                    }
+                };
+                if (kg.s == 3) build(std::integral_constant<int, 3>{});
+                else if (kg.s == 2) build(std::integral_constant<int, 2>{});
+                else build(std::integral_constant<int, 1>{});
             }
             __syncthreads();   // image dead: the staging area may be written
         } else if (KEYGEN) {
