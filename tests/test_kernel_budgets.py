@@ -1,0 +1,46 @@
+"""CPU-only: register / scratch budgets of the kernels the benchmark path stands on, read from hipcc's
+resource-usage remarks (a cross-compile, no GPU).  A branch added to msd_finish_kernel once raised it from
+80 to 123 VGPRs (6 -> 4 waves per SIMD, +3 ms on the 1 GiB step) and went unnoticed for a few commits: this
+pins the budgets the measured numbers were taken with."""
+import os
+import re
+import subprocess
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+PKG = os.path.join(ROOT, "text-compression_amd")
+
+# mangled-name fragment -> (max VGPRs, max scratch bytes per lane, min waves per SIMD)
+BUDGETS = {
+    "msd_finish_kernelILi256ELi8ELi4ELi1ELb0EE": (96, 0, 5),
+    "msd_finish_kernelILi512ELi12ELi1ELi5ELb1EE": (128, 0, 4),
+    "msd_partition_kernelILb0EE": (128, 0, 4),
+    "msd_partition_kernelILb1EE": (128, 16, 4),
+    "msd_count_kernelILb0ELb1EE": (64, 0, 4),
+    "13finish_kernel10FinishArgs": (96, 0, 5),
+    "rle_encode_idx_kernelIhE": (128, 0, 4),
+    "mtf_nib_apply_kernelI6BwtAccLb1EhE": (64, 0, 4),
+    "mtf_ts_apply_kernelI6BwtAccLi5EE": (64, 0, 8),
+    "radix_pass_kernelILb0ELb0ELi1ELb0ELb0EE": (160, 0, 3),
+}
+
+
+def test_kernel_register_budgets():
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    out = subprocess.run([hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-pthread",
+                          "-I" + os.path.join(ROOT, "include"), "-I" + os.path.join(PKG, "csrc"),
+                          "-Rpass-analysis=kernel-resource-usage", "-o", "/tmp/libtextcomp_budget.so",
+                          os.path.join(PKG, "csrc", "textcomp.hip")], capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    seen = {}
+    for blk in out.stderr.split("Function Name: ")[1:]:
+        name = blk.split()[0]
+        v = int(re.search(r"VGPRs: (\d+)", blk).group(1))
+        s = int(re.search(r"ScratchSize \[bytes/lane\]: (\d+)", blk).group(1))
+        o = int(re.search(r"Occupancy \[waves/SIMD\]: (\d+)", blk).group(1))
+        for frag in BUDGETS:
+            if frag in name:
+                seen[frag] = (v, s, o)
+    for frag, (mv, ms, mo) in BUDGETS.items():
+        assert frag in seen, "kernel not found: " + frag
+        v, s, o = seen[frag]
+        assert v <= mv and s <= ms and o >= mo, (frag, "VGPRs %d (<= %d), scratch %d (<= %d), waves/SIMD %d (>= %d)" % (v, mv, s, ms, o, mo))
