@@ -44,8 +44,15 @@ def checksum64(a):
 
 
 def digest(seed, n, log=print):
+    d = digest_text(O.gen_acgtn(seed, n), log)
+    d["seed"] = seed
+    return d
+
+
+def digest_text(text, log=print):
+    """digest of the ORACLE's encode of `text` (a numpy uint8 array)"""
     t0 = time.time()
-    text = O.gen_acgtn(seed, n)
+    n = len(text)
     N = n + 1
     L = np.empty(N, dtype=np.int16)
     assert O.lib().orc_bwt_encode(O._p(text), n, O._p(L)) == N
@@ -70,7 +77,7 @@ def digest(seed, n, log=print):
     v16 = np.zeros(k + (k & 1), dtype=np.uint16)
     v16[:k] = vals[:k]
     del vals
-    d = {"seed": seed, "n": n, "primary": primary, "sigma": int(sigma), "final_list": [int(v) for v in fl[:sigma]],
+    d = {"n": n, "primary": primary, "sigma": int(sigma), "final_list": [int(v) for v in fl[:sigma]],
          "nruns": k, "last_column_checksum64": "%016x" % l_sum,
          "run_count_checksum64": "%016x" % checksum64(c32), "run_value_checksum64": "%016x" % checksum64(v16),
          "max_run": int(c32.max())}

@@ -93,3 +93,17 @@ def test_haskell_ffi_imports_match_header():
                "bytestringToBWTToFMIndexB"):
         assert re.search(r"^%s ::" % fn, gpu, flags=re.M), fn
     assert "NOINLINE theCtx" in gpu      # one process-global context
+
+
+def test_integration_md_excerpt_is_ffi_hs():
+    """INTEGRATION.md shows the Haskell bindings a maintainer would add: the excerpt is FFI.hs itself, and every
+    other Haskell snippet of the document uses only names FFI.hs imports."""
+    md = open(os.path.join(ROOT, "INTEGRATION.md")).read()
+    ffi = open(os.path.join(ROOT, "text-compression_amd", "hs", "Data", "TextCompression", "FFI.hs")).read()
+    m = re.search(r"<!-- FFI.hs begin -->\n```haskell\n(.*?)\n```\n<!-- FFI.hs end -->", md, flags=re.S)
+    assert m, "INTEGRATION.md lost its FFI.hs excerpt markers"
+    assert m.group(1).strip() == ffi.strip(), "INTEGRATION.md's excerpt and hs/.../FFI.hs differ: regenerate the excerpt"
+    imported = set(re.findall(r"\bc_tc_[a-z0-9_]+", ffi))
+    for name in set(re.findall(r"\bc_[a-z0-9_]+", md)):
+        assert name in imported, "INTEGRATION.md mentions %s, which FFI.hs does not import" % name
+    assert "module Data.TextCompression.FFI" in md and "Data.TextComp.FFI" not in md

@@ -11,6 +11,9 @@
 // missing / failing RCCL is the status code TC_ERR_NCCL, not a load error.
 #pragma once
 #include <dlfcn.h>
+#include <stdlib.h>
+
+#include <mutex>
 
 #include "tc_common.hpp"
 
@@ -32,37 +35,42 @@ struct RcclId {
 };
 enum { kNcclUint8 = 1, kNcclUint64 = 5 };   // ncclDataType_t
 
+// TC_RCCL_LIB (tests, unusual installs): the one library name to bind instead of the list below.
 static RcclApi *rccl_api(std::string *why) {
     static RcclApi api;
-    static bool tried = false;
     static std::string err;
-    if (!tried) {
-        tried = true;
-        const char *names[] = {"librccl.so", "librccl.so.1", "/opt/rocm/lib/librccl.so.1"};
+    static std::once_flag once;      // tc_comm_* may be entered from several contexts / threads at once
+    std::call_once(once, [] {
+        const char *only = getenv("TC_RCCL_LIB");
+        const char *dflt[] = {"librccl.so", "librccl.so.1", "/opt/rocm/lib/librccl.so.1"};
+        std::vector<const char *> names;
+        if (only && *only) names.push_back(only);
+        else names.assign(dflt, dflt + 3);
         for (const char *n : names)
             if (!api.lib) api.lib = dlopen(n, RTLD_NOW | RTLD_NOLOAD);   // a copy already in the process
         for (const char *n : names)
             if (!api.lib) api.lib = dlopen(n, RTLD_NOW | RTLD_LOCAL);
         if (!api.lib) {
-            err = std::string("librccl not found: ") + (dlerror() ? dlerror() : "?");
-        } else {
-            auto sym = [&](const char *s) {
-                void *p = dlsym(api.lib, s);
-                if (!p && err.empty()) err = std::string("librccl lacks ") + s;
-                return p;
-            };
-            api.GetUniqueId = reinterpret_cast<decltype(api.GetUniqueId)>(sym("ncclGetUniqueId"));
-            api.CommInitRank = reinterpret_cast<decltype(api.CommInitRank)>(sym("ncclCommInitRank"));
-            api.CommDestroy = reinterpret_cast<decltype(api.CommDestroy)>(sym("ncclCommDestroy"));
-            api.AllGather = reinterpret_cast<decltype(api.AllGather)>(sym("ncclAllGather"));
-            api.Broadcast = reinterpret_cast<decltype(api.Broadcast)>(sym("ncclBroadcast"));
-            api.Send = reinterpret_cast<decltype(api.Send)>(sym("ncclSend"));
-            api.Recv = reinterpret_cast<decltype(api.Recv)>(sym("ncclRecv"));
-            api.GroupStart = reinterpret_cast<decltype(api.GroupStart)>(sym("ncclGroupStart"));
-            api.GroupEnd = reinterpret_cast<decltype(api.GroupEnd)>(sym("ncclGroupEnd"));
-            api.GetErrorString = reinterpret_cast<decltype(api.GetErrorString)>(sym("ncclGetErrorString"));
+            const char *e = dlerror();    // (one call: dlerror() clears the message it returns)
+            err = std::string("librccl not found: ") + (e ? e : "?");
+            return;
         }
-    }
+        auto sym = [&](const char *s) {
+            void *p = dlsym(api.lib, s);
+            if (!p && err.empty()) err = std::string("librccl lacks ") + s;
+            return p;
+        };
+        api.GetUniqueId = reinterpret_cast<decltype(api.GetUniqueId)>(sym("ncclGetUniqueId"));
+        api.CommInitRank = reinterpret_cast<decltype(api.CommInitRank)>(sym("ncclCommInitRank"));
+        api.CommDestroy = reinterpret_cast<decltype(api.CommDestroy)>(sym("ncclCommDestroy"));
+        api.AllGather = reinterpret_cast<decltype(api.AllGather)>(sym("ncclAllGather"));
+        api.Broadcast = reinterpret_cast<decltype(api.Broadcast)>(sym("ncclBroadcast"));
+        api.Send = reinterpret_cast<decltype(api.Send)>(sym("ncclSend"));
+        api.Recv = reinterpret_cast<decltype(api.Recv)>(sym("ncclRecv"));
+        api.GroupStart = reinterpret_cast<decltype(api.GroupStart)>(sym("ncclGroupStart"));
+        api.GroupEnd = reinterpret_cast<decltype(api.GroupEnd)>(sym("ncclGroupEnd"));
+        api.GetErrorString = reinterpret_cast<decltype(api.GetErrorString)>(sym("ncclGetErrorString"));
+    });
     if (!err.empty()) {
         if (why) *why = err;
         return nullptr;

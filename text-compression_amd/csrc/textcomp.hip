@@ -408,6 +408,7 @@ int tc_ctx_place_workspace(tc_ctx *ctx, const uint8_t *d_text, uint64_t n, tc_bl
     };
     int best = 0;
     char *best_ws = nullptr;
+    size_t best_cap = 0;
     auto release = [&]() {
         for (char *sp : spacers) (void)hipFree(sp);
         spacers.clear();
@@ -416,6 +417,7 @@ int tc_ctx_place_workspace(tc_ctx *ctx, const uint8_t *d_text, uint64_t n, tc_bl
         t.push_back(timed());          // placement 0: the workspace the context has (sized by this very encode)
         best_ws = ctx->ws;
         const size_t cap0 = ctx->ws_cap;
+        best_cap = cap0;
         for (int k = 1; k < tries; k++) {
             double worst = 0;
             for (double v : t) worst = v > worst ? v : worst;
@@ -434,6 +436,7 @@ int tc_ctx_place_workspace(tc_ctx *ctx, const uint8_t *d_text, uint64_t n, tc_bl
             if (ctx->ws_cap != cap0) {   // the workspace grew under the candidate (cannot happen for one record): keep it
                 (void)hipFree(best_ws);
                 best_ws = ctx->ws;
+                best_cap = ctx->ws_cap;
                 best = k;
                 break;
             }
@@ -451,10 +454,11 @@ int tc_ctx_place_workspace(tc_ctx *ctx, const uint8_t *d_text, uint64_t n, tc_bl
             else (void)hipGetLastError();
         }
     } catch (const TcFail &) {
-        if (best_ws && ctx->ws != best_ws) {
-            (void)hipFree(ctx->ws);
+        if (best_ws && ctx->ws != best_ws) {     // reinstate the best block WITH its capacity (a reserve inside
+            if (ctx->ws) (void)hipFree(ctx->ws); // timed() may have grown or, after an OOM, dropped the candidate)
             ctx->ws = best_ws;
         }
+        if (best_ws) ctx->ws_cap = best_cap;
         release();
         throw;
     }
@@ -1444,6 +1448,20 @@ int tc_fm_import_dev(tc_ctx *ctx, const uint8_t *d_in, uint64_t bytes, tc_fm **o
     if (memcmp(h.magic, kFmMagic, 8) != 0 || h.bytes > bytes || h.N != (h.n ? h.n + 1 : 0) || h.n > TC_MAX_N ||
         h.sigma_bytes > 256 || (h.n && h.lines != h.N / FM_LINE_BITS + 1))
         TC_FAIL(ctx, TC_ERR_MALFORMED, "not an exported FM-index");
+    {   // the scalars fm_count / fm_locate index with: primary row, symbol counts, code table
+        u64 total = 0;
+        u32 present = 0;
+        bool codes_ok = true;
+        for (int b = 0; b < 256; b++) {
+            total += h.counts[b];
+            if (h.counts[b]) {
+                codes_ok = codes_ok && present < h.sigma_bytes && h.sym_of_code[present] == (i16)b;
+                present++;
+            }
+        }
+        if (h.n && (h.primary == 0 || h.primary >= h.N || total != h.n || present != h.sigma_bytes || !codes_ok))
+            TC_FAIL(ctx, TC_ERR_MALFORMED, "exported FM-index: header is inconsistent");
+    }
     tc_fm *fm = new tc_fm();
     fm->device = ctx->device;
     fm->n = h.n; fm->N = h.N; fm->primary = h.primary; fm->lines = h.lines; fm->sigma_bytes = h.sigma_bytes;
@@ -1680,12 +1698,17 @@ int tc_comm_gather(tc_comm *c, int root, const uint8_t *d_container, uint64_t by
     }
     if (over) TC_FAIL(ctx, TC_ERR_CAPACITY, "a container exceeds the gather slot of %llu bytes", (unsigned long long)slot_bytes);
     TC_NCCL(c, c->api->GroupStart());
-    if (c->rank == root) {
-        for (int r = 0; r < c->world; r++)
-            if (r != root && sizes[r])
-                TC_NCCL(c, c->api->Recv(d_recv + (size_t)r * slot_bytes, (size_t)sizes[r], kNcclUint8, r, c->comm, s));
-    } else if (bytes) {
-        TC_NCCL(c, c->api->Send(d_container, (size_t)bytes, kNcclUint8, root, c->comm, s));
+    try {
+        if (c->rank == root) {
+            for (int r = 0; r < c->world; r++)
+                if (r != root && sizes[r])
+                    TC_NCCL(c, c->api->Recv(d_recv + (size_t)r * slot_bytes, (size_t)sizes[r], kNcclUint8, r, c->comm, s));
+        } else if (bytes) {
+            TC_NCCL(c, c->api->Send(d_container, (size_t)bytes, kNcclUint8, root, c->comm, s));
+        }
+    } catch (const TcFail &) {
+        (void)c->api->GroupEnd();    // never leave the thread's group open: later collectives would queue into it
+        throw;
     }
     TC_NCCL(c, c->api->GroupEnd());
     if (c->rank == root && bytes)

@@ -17,7 +17,7 @@ module Data.TextCompression.GPU
   , bytestringFMIndexLocateS, bytestringFMIndexLocateP
   ) where
 
-import Control.Concurrent.MVar (MVar, newMVar, modifyMVar)
+import Control.Concurrent.MVar (MVar, newMVar, modifyMVar_, withMVar)
 import Control.Monad (when)
 import qualified Data.ByteString as BS
 import qualified Data.ByteString.Char8 as BSC8
@@ -44,14 +44,20 @@ theCtx = unsafePerformIO (newMVar nullPtr)
 {-# NOINLINE theCtx #-}
 
 -- | Run one library call on the global context, holding the MVar for its duration.
+-- Two steps, so that an exception in `act` (e.g. `check` raising on the very first call) cannot lose a
+-- context that was just created: `modifyMVar_` stores the new pointer BEFORE `act` runs, and `act`
+-- itself runs under `withMVar` (which restores the stored pointer on any exception).
+-- Discipline for callers: the MVar is not re-entrant -- never force, inside `act`, a value whose
+-- evaluation calls `withCtx` again (every binding below that depends on another library call is
+-- forced with `seq`/bang BEFORE `withCtx` is entered, see bytestringToBWTToFMIndexB).
 withCtx :: (Ptr TcCtx -> IO a) -> IO a
-withCtx act = modifyMVar theCtx $ \c0 -> do
-  c <- if c0 /= nullPtr then pure c0 else alloca $ \pp -> do
-         rc <- c_tc_ctx_create 0 pp
-         when (rc /= 0) (ioError (userError "textcomp: no usable HIP device"))
-         peek pp
-  r <- act c
-  pure (c, r)
+withCtx act = do
+  modifyMVar_ theCtx $ \c0 ->
+    if c0 /= nullPtr then pure c0 else alloca $ \pp -> do
+      rc <- c_tc_ctx_create 0 pp
+      when (rc /= 0) (ioError (userError "textcomp: no usable HIP device"))
+      peek pp
+  withMVar theCtx act
 
 -- TC_ERR_MALFORMED (-3) stands for the `error` the reference raises itself
 -- (fromJust / DS.index / read); everything else is an infrastructure failure.
