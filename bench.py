@@ -7,10 +7,13 @@ With N > 1 and no WORLD_SIZE in the environment the command launches itself: the
 touches the GPU) starts N fresh ranks through torch.distributed.run on 127.0.0.1, forwards rank 0's
 JSON line and returns the children's exit code.  Under torchrun (WORLD_SIZE set) it is a rank.
 
-A "step" = one fused BWT -> MTF -> RLE encode (tc_encode_dev) of this rank's record,
-input and output resident in HBM; with N > 1 each rank owns one independent record
-(seed 0xC500 + rank) and the step ends with the gather of the
-encoded blocks on rank 0 over RCCL.  Rank 0 prints ONE JSON line.
+A "step" = one fused BWT -> MTF -> RLE encode of this rank's record, input and output resident in
+HBM.  N = 1: tc_encode_dev (the runs as arrays: BASELINE configs[2]).  N > 1: each rank owns one
+independent record (seed 0xC500 + rank) and encodes it straight into its container
+(tc_encode_container_dev: the RLE stage writes the wire format, nothing is packed afterwards), and the step
+ends with the gather of the containers on rank 0 over RCCL, overlapped with the next record's encode.
+Rank 0 prints ONE JSON line.  After the timed region, at N = 1, the line also gets `container` (the N > 1
+step without its exchange, timed on this one GPU) and `fm_count` (BASELINE configs[3]).
 
 PyTorch here is plumbing only: device buffers, torch.distributed (nccl = RCCL),
 barriers.  The compute is libtextcomp.so through its C ABI.
@@ -35,6 +38,7 @@ def parse():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--n", "--record-bytes", dest="n", type=int, default=GIB, help="record size in bytes (default 1 GiB = BASELINE configs[2])")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-fm", action="store_true", help="skip the FM-index count leg (BASELINE configs[3])")
     ap.add_argument("--cpu-sample", type=int, default=64 << 20, help="bytes of the workload timed on the CPU port")
     return ap.parse_args()
 
@@ -92,7 +96,7 @@ def self_launch(a):
            "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__),
            # (rebuilt from the parsed values: torchrun's own parser chokes on abbreviations such as --n)
            "--gpus", str(a.gpus), "--steps", str(a.steps), "--warmup", str(a.warmup), "--record-bytes", str(a.n),
-           "--cpu-sample", str(a.cpu_sample)] + (["--no-cpu-baseline"] if a.no_cpu_baseline else [])
+           "--cpu-sample", str(a.cpu_sample)] + (["--no-cpu-baseline"] if a.no_cpu_baseline else []) + (["--no-fm"] if a.no_fm else [])
     p = subprocess.run(cmd, env=env)
     sys.exit(p.returncode)
 
@@ -111,6 +115,133 @@ def cpu_baseline(n_sample, seed):
             "reference_haskell": haskell_probe(),
             "sample": "first %d MiB of the rank-0 record, BWT+MTF+RLE encode by oracle/tc_oracle.c, %.1f s"
                       % (n_sample >> 20, dt)}
+
+
+def container_leg(ctx, lib, torch, d_text, n, steps, ms_plain):
+    """The step of the N > 1 path without its exchange, on this one GPU, after the timed region: the record
+    encoded straight into its container (tc_encode_container_dev) -- what every rank does per step before it
+    posts the gather.  `ratio` compares it with the N = 1 step (tc_encode_dev, run arrays out)."""
+    pcap = n + n // 4 + 4096
+    buf = torch.empty(pcap, dtype=torch.uint8, device=d_text.device)
+    nb = C.c_uint64(pcap)
+
+    def one():
+        nb.value = pcap
+        rc = lib.tc_encode_container_dev(ctx.handle, C.c_void_p(d_text.data_ptr()), n, C.c_void_p(buf.data_ptr()), C.byref(nb))
+        if rc != 0:
+            raise RuntimeError("tc_encode_container_dev rc=%d: %s" % (rc, lib.tc_last_error(ctx.handle).decode()))
+    one()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        one()
+    torch.cuda.synchronize()
+    ms = (time.perf_counter() - t0) / steps * 1e3
+    st = ctx.stats()
+    return {"ms_per_step_with_container": round(ms, 3), "ratio_to_ms_per_step": round(ms / ms_plain, 4),
+            "container_bytes": int(nb.value), "bytes_per_input_byte": round(nb.value / n, 4),
+            "stages_ms": {"suffix_sort+bwt": round(st.ms_sa, 3), "mtf": round(st.ms_mtf, 3), "rle+wire_format+seal": round(st.ms_rle, 3)},
+            "what": "tc_encode_container_dev: BWT -> MTF -> RLE written as the container's nibble stream by the RLE stage, "
+                    "sealed on the device; bit-identical to tc_encode_dev + tc_block_to_container_dev (tests/test_gpu_container_fused.py)"}
+
+
+def fm_count_leg(ctx, lib, torch, no_cpu):
+    """BASELINE configs[3], after the timed encode region: 10^7 x 100-byte ACGTN patterns (99 % substrings of the
+    text, every 100th iid: SURVEY.md 8d) counted against the index of a 2^28-byte text, patterns and index resident
+    in HBM.  The batch is one tc_fm_count_dev call; best and mean of 5 calls after a warm-up.  `steps_executed` is
+    measured (a miss stops when its range empties), A_cnt = steps x 2 x 64 B + pattern bytes.  The
+    same batch against a 2^29-byte text shows the rate once the index no longer fits the 256 MB Infinity Cache."""
+    import numpy as np
+    from textcomp.synth import c4_patterns_dev
+    npat, m = 10_000_000, 100
+    lib.tc_fm_count_dev.argtypes = [C.c_void_p] * 4 + [C.c_uint64, C.c_void_p]
+    res = {}
+    for lg in (28, 29):
+        n = 1 << lg
+        d_text = torch.empty(n, dtype=torch.uint8, device="cuda")
+        assert lib.tc_generate_dev(ctx.handle, 0, 0xC4, n, C.c_void_p(d_text.data_ptr())) == 0
+        torch.cuda.synchronize()
+        text = d_text.cpu().numpy()
+        t0 = time.perf_counter()
+        fm = ctx.fm_build(text)
+        t_build = time.perf_counter() - t0
+        pats, d_offs = c4_patterns_dev(ctx, d_text, npat, m)
+        d_out = torch.zeros(npat, dtype=torch.int64, device="cuda")
+        torch.cuda.synchronize()
+        ts = []
+        for it in range(6):
+            t0 = time.perf_counter()
+            rc = lib.tc_fm_count_dev(ctx.handle, fm._h, C.c_void_p(pats.data_ptr()), C.c_void_p(d_offs.data_ptr()), npat, C.c_void_p(d_out.data_ptr()))
+            dt = time.perf_counter() - t0
+            assert rc == 0, lib.tc_last_error(ctx.handle)
+            if it:
+                ts.append(dt)
+        out = d_out.cpu().numpy()
+        is_miss = (np.arange(npat) % 100) == 99
+        ok = bool((out[~is_miss] >= 1).all() and (out[is_miss] == 0).all())
+        if lg == 29:
+            res["outside_mall"] = {"text_bytes": n, "ms": round(min(ts) * 1e3, 3), "ms_mean": round(sum(ts) / len(ts) * 1e3, 3),
+                                   "Mpatterns_per_s": round(npat / min(ts) / 1e6, 1), "hits_and_misses_as_generated": ok}
+            fm.close()
+            break
+        # executed steps of the miss patterns: the shortest suffix with count 0 is the step that empties the range
+        sub = np.arange(99, npat, 100)[:2000]
+        mp = pats[torch.from_numpy(sub).cuda()]
+        alive = np.ones(len(sub), bool)
+        last = np.zeros(len(sub), np.int64)
+        for ln in range(1, 48):
+            sfx = mp[:, m - ln:].contiguous()
+            so = (torch.arange(len(sub) + 1, device="cuda", dtype=torch.int64) * ln).contiguous()
+            o = torch.zeros(len(sub), dtype=torch.int64, device="cuda")
+            torch.cuda.synchronize()
+            assert lib.tc_fm_count_dev(ctx.handle, fm._h, C.c_void_p(sfx.data_ptr()), C.c_void_p(so.data_ptr()), len(sub), C.c_void_p(o.data_ptr())) == 0
+            z = o.cpu().numpy() == 0
+            last[alive & z] = ln
+            alive &= ~z
+            if not alive.any():
+                break
+        steps = float(int((~is_miss).sum()) * m + last.mean() * int(is_miss.sum()))
+        A = steps * 128 + npat * m
+        best = min(ts)
+        res.update({"ms": round(best * 1e3, 3), "ms_mean": round(sum(ts) / len(ts) * 1e3, 3), "calls_timed": len(ts),
+                    "Mpatterns_per_s": round(npat / best / 1e6, 1), "patterns": npat, "pattern_bytes": m, "text_bytes": n,
+                    "index_build_ms_host_text_in": round(t_build * 1e3, 1),
+                    "steps_executed": int(steps), "miss_patterns_stop_after_steps": round(float(last.mean()), 2),
+                    "A_cnt": int(A), "A_cnt_GBps": round(A / best / 1e9, 1),
+                    "bound": "MALL, dependent 64-B lines (one lane = one pattern = 100 sequential steps); A_cnt / t is not an HBM figure",
+                    "hits_and_misses_as_generated": ok})
+        pj = os.path.join(ROOT, "profiles", "traffic_latest.json")
+        try:
+            tj = json.load(open(pj))
+            res["fetch_bytes"] = tj.get("fm_count_kernel_fetch_bytes_per_launch")
+            res["fetch_bytes_source"] = "recorded: profiles/traffic_latest.json (%s), not measured in this run" % tj.get("fm_commit", tj.get("commit", "?"))
+        except Exception:
+            res["fetch_bytes"] = None
+        fm.close()
+        del d_text, pats, d_offs, d_out
+    if not no_cpu:
+        # the CPU port on the same workload SHAPE over a 2^24-byte text (the oracle's index of 2^28 bytes is minutes)
+        sys.path.insert(0, os.path.join(ROOT, "tests"))
+        import oracle as O
+        from textcomp.synth import c4_offsets
+        n2, np2 = 1 << 24, 200_000
+        t = O.gen_acgtn(0xC4, n2)
+        t0 = time.perf_counter()
+        ofm = O.FMIndex(t)
+        tb = time.perf_counter() - t0
+        offs = c4_offsets(n2, np2, m)
+        flat = t[(offs[:, None] + np.arange(m)[None, :]).reshape(-1)].reshape(np2, m).copy()
+        flat[99::100] = O.gen_acgtn(0xC4F1, (np2 // 100) * m).reshape(-1, m)
+        po = (np.arange(np2 + 1, dtype=np.int64) * m)
+        cores = min(os.cpu_count() or 1, 64)
+        t0 = time.perf_counter()
+        want = ofm.count_batch(flat.reshape(-1), po, threads=cores)
+        tc = time.perf_counter() - t0
+        res["cpu_baseline"] = {"value": round(np2 / tc / 1e6, 4), "unit": "Mpatterns/s", "cores": cores, "kind": "port",
+                               "sample": "%d patterns of the same generator against the oracle's index of a 2^24-byte text "
+                                         "(index build %.1f s on 1 core, count %.2f s on %d threads); found %d"
+                                         % (np2, tb, tc, cores, int((want > 0).sum()))}
+    return res
 
 
 def main():
@@ -172,20 +303,21 @@ def main():
     blk = Block()
 
     def step():
-        blk.nruns = cap
-        blk.run_count = d_cnt.data_ptr()
-        blk.run_value = d_val.data_ptr()
-        rc = lib.tc_encode_dev(ctx.handle, C.c_void_p(d_text.data_ptr()), n, C.byref(blk))
-        if rc != 0:
-            raise RuntimeError("tc_encode_dev rc=%d: %s" % (rc, lib.tc_last_error(ctx.handle).decode()))
-        if gatherer is not None:
-            buf = packed[gatherer.acquire()]   # the send of the record that last used this buffer has completed
-            nb = C.c_uint64(pcap)       # the block as one self-describing container (header + packed runs)
-            rc = lib.tc_block_to_container_dev(ctx.handle, C.byref(blk), C.c_void_p(buf.data_ptr()), C.byref(nb))
+        if gatherer is None:
+            blk.nruns = cap
+            blk.run_count = d_cnt.data_ptr()
+            blk.run_value = d_val.data_ptr()
+            rc = lib.tc_encode_dev(ctx.handle, C.c_void_p(d_text.data_ptr()), n, C.byref(blk))
             if rc != 0:
-                raise RuntimeError("tc_block_to_container_dev rc=%d: %s" % (rc, lib.tc_last_error(ctx.handle).decode()))
-            payload = buf[:nb.value].cpu() if rehearsal else buf
-            gatherer.submit([nb.value, int(blk.nruns), 0, int(blk.primary), int(blk.sigma), n], payload)
+                raise RuntimeError("tc_encode_dev rc=%d: %s" % (rc, lib.tc_last_error(ctx.handle).decode()))
+            return
+        buf = packed[gatherer.acquire()]   # the send of the record that last used this buffer has completed
+        nb = C.c_uint64(pcap)       # the record as one self-describing container (header + nibble stream)
+        rc = lib.tc_encode_container_dev(ctx.handle, C.c_void_p(d_text.data_ptr()), n, C.c_void_p(buf.data_ptr()), C.byref(nb))
+        if rc != 0:
+            raise RuntimeError("tc_encode_container_dev rc=%d: %s" % (rc, lib.tc_last_error(ctx.handle).decode()))
+        payload = buf[:nb.value].cpu() if rehearsal else buf
+        gatherer.submit([nb.value, 0, 0, 0, 0, n], payload)
 
     def fence():
         if gatherer is not None:
@@ -245,8 +377,6 @@ def main():
             rc = lib.tc_container_to_block_dev(ctx.handle, C.c_void_p(pd.data_ptr()), int(h[0]), C.byref(vb))
             assert rc == 0, "gathered container of rank %d: rc=%d %s" % (r, rc, lib.tc_last_error(ctx.handle).decode())
             assert int(vb.n) == n, "header of rank %d" % r
-            if len(h) > 3:      # (the native gather carries sizes only: the rest is inside the container)
-                assert int(vb.nruns) == int(h[1]) and int(vb.primary) == int(h[3]), "header of rank %d" % r
             assert lib.tc_decode_dev(ctx.handle, C.byref(vb), C.c_void_p(d_back.data_ptr())) == 0
             assert lib.tc_generate_dev(ctx.handle, 0, 0xC500 + r, n, C.c_void_p(d_chk.data_ptr())) == 0
             torch.cuda.synchronize()
@@ -300,6 +430,11 @@ def main():
                           "passes": [int(st.passes[i]) for i in range(st.rounds)], "runs": int(st.runs),
                           "ticket_fallbacks": int(st.ticket_fallbacks)},
         }
+        if world == 1 and os.environ.get("TC_BENCH_CONTAINER", "1") != "0":
+            out["container"] = container_leg(ctx, lib, torch, d_text, n, a.steps, out["ms_per_step"])
+        if world == 1 and not a.no_fm and n == GIB:
+            del d_cnt, d_val
+            out["fm_count"] = fm_count_leg(ctx, lib, torch, a.no_cpu_baseline)
         if not a.no_cpu_baseline and world == 1:   # the CPU port is timed at N = 1 only
             out["cpu_baseline"] = cpu_baseline(min(a.cpu_sample, n), seed)
         print(json.dumps(out), flush=True)

@@ -191,7 +191,7 @@ int tc_decode_dev(tc_ctx *ctx, const tc_block *blk, uint8_t *d_text);
  *   sigma <= 6  (an ACGTN record: 5 letters + sentinel) -- nibble stream: code 0..11 starts a run
  *       (value = code % 6, count = 1 + code / 6); a following 12 / 13 raises a count of 2 to 3 / 4;
  *       a following 14 means "count = next uint32 of the escape list" (counts 0 and >= 5, in run
- *       order); 15 is padding (the packer pads each 16384-run tile to a 16-byte boundary).  The
+ *       order); 15 is padding (the stream is dense; its end is padded to a 16-byte boundary).  The
  *       escape list (4 bytes each) follows the nibble body.  `packed` must be 16-byte aligned.
  *   sigma <= 16 -- byte k (k < nruns) = value | (min(count, 15) << 4)
  *   sigma > 16  -- two bytes per run: value low byte, then count (escape 127) | ninth value bit << 7
@@ -220,6 +220,13 @@ int tc_block_unpack_dev(tc_ctx *ctx, const uint8_t *d_packed, uint64_t packed_by
 #define TC_CONTAINER_HEADER 640
 uint64_t tc_container_bound(uint64_t nruns, uint32_t sigma);
 int tc_block_to_container_dev(tc_ctx *ctx, const tc_block *blk /* device runs */, uint8_t *d_out, uint64_t *bytes);
+/* Text -> container in one call, everything on the device: the bytes of tc_encode_dev followed by
+ * tc_block_to_container_dev, without the run arrays in between -- for sigma <= 6 (an ACGTN record) the RLE
+ * stage writes the container's nibble stream itself and the container is sealed (escape list, checksum,
+ * header) by device kernels.  This is what one step of the multi-GPU path produces and ships
+ * (tc_comm_gather).  d_text, d_out: device pointers; d_out 16-byte aligned; *bytes as above
+ * (tc_container_bound(n + 2, TC_MAX_SIGMA) is always enough; an ACGTN record needs ~0.45 n). */
+int tc_encode_container_dev(tc_ctx *ctx, const uint8_t *d_text, uint64_t n, uint8_t *d_out, uint64_t *bytes);
 /* blk->run_count / run_value: device arrays of capacity blk->nruns (TC_ERR_CAPACITY: blk->nruns = needed). */
 int tc_container_to_block_dev(tc_ctx *ctx, const uint8_t *d_in, uint64_t bytes, tc_block *blk);
 /* Host side: text -> container and back in one call each; only the compact form crosses PCIe.

@@ -11,6 +11,10 @@ sys.path.insert(0, os.path.join(ROOT, "text-compression_amd"))
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 import oracle as O  # noqa: E402
 import textcomp  # noqa: E402
+try:
+    import torch  # device buffers for the *_dev entry points
+except Exception:  # noqa: BLE001
+    torch = None
 
 cases = int(sys.argv[1]) if len(sys.argv) > 1 else 2000
 seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1
@@ -54,6 +58,12 @@ for it in range(cases):
         if it % 4 == 0:
             blob = ctx.encode_container(tb)
             assert ctx.decode_container(blob) == tb, "container"
+            if torch is not None:    # the fused device path (RLE stage writes the wire format) gives the same bytes
+                d_t = torch.from_numpy(np.frombuffer(tb, np.uint8).copy()).cuda()
+                bound = int(ctx.lib.tc_container_bound(n + 2, 257))
+                d_o = torch.full((bound + 16,), 0x5A, dtype=torch.uint8, device="cuda")
+                used = ctx.encode_container_dev(d_t.data_ptr(), n, d_o.data_ptr(), bound)
+                assert d_o[:used].cpu().numpy().tobytes() == blob, "fused container"
             bs = int(rng.integers(1, n + 2))
             st = ctx.encode_stream(tb, bs)
             assert ctx.decode_stream(st) == tb, "stream"

@@ -1,0 +1,81 @@
+"""Records AWAY from iid ACGTN at 2^26 .. 2^28 bytes, bit-exact against the ORACLE: the paths a non-ACGTN text takes
+(timestamp MTF, dense ranks by regions, the big finish instance with its whole-bucket kernel, finish_fix tied groups,
+the MSD -> LSD hand-over, sigma = 257) compared digest for digest with the oracle's encode of the same bytes
+(tests/golden/classes_digest.json, written by tests/long/classes_digest.py on the CPU; the records are regenerated
+here by tests/classgen.py: numpy, integer arithmetic only).  src/Data/BWT.hs:68-70 accepts any ByteString."""
+import ctypes as C
+import json
+import os
+
+import numpy as np
+import pytest
+
+import classgen
+
+pytestmark = pytest.mark.gpu
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+DIGESTS = json.load(open(os.path.join(HERE, "golden", "classes_digest.json")))
+KEYS = sorted((k for k in DIGESTS if not k.startswith("_")), key=lambda k: (DIGESTS[k]["n"], k))
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    import textcomp
+    c = textcomp.Context(0)
+    yield c
+    c.close()
+
+
+def _checksum(lib, ctx, tensor, nbytes):
+    out = C.c_uint64()
+    lib.tc_dbg_checksum64_dev.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.POINTER(C.c_uint64)]
+    rc = lib.tc_dbg_checksum64_dev(ctx.handle, C.c_void_p(tensor.data_ptr()), nbytes, C.byref(out))
+    assert rc == 0, lib.tc_last_error(ctx.handle)
+    return "%016x" % out.value
+
+
+@pytest.mark.parametrize("key", KEYS)
+def test_class_digest_equals_oracle(ctx, key):
+    import torch
+    from textcomp import Block
+    d = DIGESTS[key]
+    n = d["n"]
+    lib = ctx.lib
+    text = classgen.make(d["class"], n)
+    d_text = torch.from_numpy(text).cuda()
+    del text
+    cap = n + 2
+    d_cnt = torch.empty(cap, dtype=torch.int32, device="cuda")
+    d_val = torch.empty(cap, dtype=torch.int16, device="cuda")
+    blk = Block()
+    blk.nruns, blk.run_count, blk.run_value = cap, d_cnt.data_ptr(), d_val.data_ptr()
+    rc = lib.tc_encode_dev(ctx.handle, C.c_void_p(d_text.data_ptr()), n, C.byref(blk))
+    assert rc == 0, lib.tc_last_error(ctx.handle)
+    k = int(blk.nruns)
+    assert (int(blk.primary), int(blk.sigma), k) == (d["primary"], d["sigma"], d["nruns"])
+    assert [int(blk.final_list[i]) for i in range(d["sigma"])] == d["final_list"]
+    assert _checksum(lib, ctx, d_cnt, 4 * k) == d["run_count_checksum64"]
+    if k & 1:
+        d_val[k] = 0
+    assert _checksum(lib, ctx, d_val, 2 * (k + (k & 1))) == d["run_value_checksum64"]
+    assert int(d_cnt[:k].max().item()) == d["max_run"]
+    st = ctx.stats()
+    # the BWT stage on its own: the last column, byte 0 in the primary slot
+    N = n + 1
+    d_L = torch.zeros((N + 3) // 4 * 4, dtype=torch.uint8, device="cuda")
+    prim = C.c_uint64()
+    assert lib.tc_bwt_encode_dev(ctx.handle, C.c_void_p(d_text.data_ptr()), n, C.c_void_p(d_L.data_ptr()), C.byref(prim)) == 0
+    assert prim.value == d["primary"]
+    assert _checksum(lib, ctx, d_L, d_L.numel()) == d["last_column_checksum64"]
+    # which way the record took (so that a change of the selectors cannot silently move it off the path it pins)
+    if n >= (1 << 26):
+        if d["class"] == "acgt4":
+            assert st.msd_path == 1
+        if d["class"] in ("zipf_words", "genome_like"):
+            assert st.msd_path == 0 and st.rounds >= 2
+    # and the block decodes
+    d_back = torch.empty(n, dtype=torch.uint8, device="cuda")
+    assert lib.tc_decode_dev(ctx.handle, C.byref(blk), C.c_void_p(d_back.data_ptr())) == 0, lib.tc_last_error(ctx.handle)
+    torch.cuda.synchronize()
+    assert torch.equal(d_back, d_text)

@@ -3,6 +3,7 @@ goes: RCCL is found and bound at run time, a communicator of one rank is built f
 container gather (all-gather of the sizes + root copy) and the broadcast run on it, a container larger
 than the slot is TC_ERR_CAPACITY.  The point-to-point transfers need a second GPU: the driver's run."""
 import ctypes as C
+import os
 
 import numpy as np
 import pytest
@@ -10,6 +11,7 @@ import pytest
 import oracle as O
 
 pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def test_comm_world1_gather_and_broadcast():
@@ -58,3 +60,27 @@ def test_comm_world1_gather_and_broadcast():
     assert torch.equal(x, torch.arange(1000, dtype=torch.uint8, device="cuda"))
     g.close()
     ctx.close()
+
+
+def test_missing_rccl_is_a_status_code_not_a_crash():
+    """a host without RCCL: tc_comm_unique_id / tc_comm_create return TC_ERR_NCCL with a message (the binding is
+    made at run time; TC_RCCL_LIB names the one library to try).  A child process, because the binding is made once."""
+    import subprocess
+    import sys
+    code = r"""
+import ctypes as C, sys
+sys.path.insert(0, %r)
+import textcomp
+ctx = textcomp.Context(0)
+ident = (C.c_uint8 * 128)()
+rc = ctx.lib.tc_comm_unique_id(ctx.handle, ident)
+msg = ctx.lib.tc_last_error(ctx.handle).decode()
+h = C.c_void_p()
+rc2 = ctx.lib.tc_comm_create(ctx.handle, ident, 0, 1, C.byref(h))
+print(rc, rc2, msg)
+assert rc == -7 and rc2 == -7 and "librccl not found" in msg, (rc, rc2, msg)
+""" % os.path.join(ROOT, "text-compression_amd")
+    env = dict(os.environ)
+    env["TC_RCCL_LIB"] = "/nonexistent/librccl-none.so"
+    p = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300)
+    assert p.returncode == 0, p.stdout + p.stderr

@@ -106,51 +106,46 @@ def test_full_size_roundtrip(n):
     ctx.close()
 
 
-def _encode_digest(lib, ctx, d_text, n, d_cnt, d_val, cap):
-    from textcomp import Block
-    blk = Block()
-    blk.nruns, blk.run_count, blk.run_value = cap, d_cnt.data_ptr(), d_val.data_ptr()
-    rc = lib.tc_encode_dev(ctx.handle, C.c_void_p(d_text.data_ptr()), n, C.byref(blk))
-    assert rc == 0, lib.tc_last_error(ctx.handle)
-    k = int(blk.nruns)
-    if k & 1:
-        d_val[k] = 0
-    return (int(blk.primary), int(blk.sigma), k, [int(blk.final_list[i]) for i in range(int(blk.sigma))],
-            _checksum(lib, ctx, d_cnt, 4 * k), _checksum(lib, ctx, d_val, 2 * (k + (k & 1)))), blk
-
-
-@pytest.mark.parametrize("kind", ["bytes256", "ascii96", "wordy"])
-def test_round2_paths_agree_at_scale(kind, monkeypatch):
-    """2^28-byte records away from the benchmark's class: the paths added in round 2 (MTF by timestamps beyond
-    64 symbols; dense ranks stored by regions) produce the same block, digest for digest, as the paths they
-    replace (TC_MTF_TS=0, TC_SA_BIN_MIN_LOG2=40), and the block decodes to the input."""
+def test_fused_container_1gib_equals_two_step():
+    """the 1 GiB benchmark record encoded straight into its container (tc_encode_container_dev: the RLE stage
+    writes the nibble stream, device kernels seal the container) against tc_encode_dev + tc_block_to_container_dev:
+    same size, same bytes -- and the header carries the oracle's digest values for this record.
+    (Other records at 2^26 .. 2^28 against the oracle: tests/test_gpu_classes_digest.py.)"""
+    import struct
     import torch
     import textcomp
-    n = 1 << 28
-    g = torch.Generator(device="cuda")
-    g.manual_seed(12)
-    if kind == "bytes256":
-        d_text = torch.randint(0, 256, (n,), generator=g, device="cuda", dtype=torch.int32).to(torch.uint8)
-    elif kind == "ascii96":
-        d_text = (torch.randint(0, 96, (n,), generator=g, device="cuda", dtype=torch.int32) + 32).to(torch.uint8)
-    else:   # words over a small vocabulary: nearly every suffix stays tied after round 0 (dense mode, large rounds)
-        vocab = torch.randint(97, 123, (4096, 8), generator=g, device="cuda", dtype=torch.int32).to(torch.uint8)
-        vocab[:, 7] = 32
-        ids = (torch.rand(n // 8, generator=g, device="cuda") ** 3 * 4096).long().clamp_(0, 4095)
-        d_text = vocab[ids].reshape(-1).contiguous()
-    torch.cuda.synchronize()
+    from textcomp import Block
+    n = 1 << 30
+    d = DIGESTS["n%d" % n]
     ctx = textcomp.Context(0)
     lib = ctx.lib
+    d_text = torch.empty(n, dtype=torch.uint8, device="cuda")
+    assert lib.tc_generate_dev(ctx.handle, 0, d["seed"], n, C.c_void_p(d_text.data_ptr())) == 0
+    pcap = n + n // 4 + 4096
+    a = torch.empty(pcap, dtype=torch.uint8, device="cuda")
+    used_a = ctx.encode_container_dev(d_text.data_ptr(), n, a.data_ptr(), pcap)
+    hdr = a[:640].cpu().numpy().tobytes()
+    magic, hn, hprim, hruns, hesc, hbody, hsum, hsigma, hfmt = struct.unpack_from("<8s6Q2I", hdr, 0)
+    assert (hn, hprim, hruns, hsigma, hfmt) == (n, d["primary"], d["nruns"], d["sigma"], 0)
+    assert list(struct.unpack_from("<%dh" % hsigma, hdr, 64)) == d["final_list"]
     cap = n + 2
-    d_cnt = torch.empty(cap, dtype=torch.int32, device="cuda")
-    d_val = torch.empty(cap, dtype=torch.int16, device="cuda")
-    new, blk = _encode_digest(lib, ctx, d_text, n, d_cnt, d_val, cap)
-    d_back = torch.empty(n, dtype=torch.uint8, device="cuda")
-    assert lib.tc_decode_dev(ctx.handle, C.byref(blk), C.c_void_p(d_back.data_ptr())) == 0, lib.tc_last_error(ctx.handle)
-    torch.cuda.synchronize()
-    assert torch.equal(d_back, d_text)
-    monkeypatch.setenv("TC_MTF_TS", "0")
-    monkeypatch.setenv("TC_SA_BIN_MIN_LOG2", "40")
-    old, _ = _encode_digest(lib, ctx, d_text, n, d_cnt, d_val, cap)
-    assert new == old
+    d_c = torch.empty(cap, dtype=torch.int32, device="cuda")
+    d_v = torch.empty(cap, dtype=torch.int16, device="cuda")
+    blk = Block()
+    blk.nruns, blk.run_count, blk.run_value = cap, d_c.data_ptr(), d_v.data_ptr()
+    assert lib.tc_encode_dev(ctx.handle, C.c_void_p(d_text.data_ptr()), n, C.byref(blk)) == 0
+    b = torch.empty(pcap, dtype=torch.uint8, device="cuda")
+    used_b = C.c_uint64(pcap)
+    assert lib.tc_block_to_container_dev(ctx.handle, C.byref(blk), C.c_void_p(b.data_ptr()), C.byref(used_b)) == 0
+    assert used_a == used_b.value
+    assert torch.equal(a[:used_a], b[:used_a])
+    # and the container read back: the oracle's run arrays, digest for digest
+    blk2 = Block()
+    blk2.nruns, blk2.run_count, blk2.run_value = cap, d_c.data_ptr(), d_v.data_ptr()
+    assert lib.tc_container_to_block_dev(ctx.handle, C.c_void_p(a.data_ptr()), used_a, C.byref(blk2)) == 0, lib.tc_last_error(ctx.handle)
+    k = int(blk2.nruns)
+    assert _checksum(lib, ctx, d_c, 4 * k) == d["run_count_checksum64"]
+    if k & 1:
+        d_v[k] = 0
+    assert _checksum(lib, ctx, d_v, 2 * (k + (k & 1))) == d["run_value_checksum64"]
     ctx.close()

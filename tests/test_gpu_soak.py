@@ -1,0 +1,36 @@
+"""Bounded, seeded slices of the long randomized runs (tests/long/fuzz_*.py: differential against the CPU oracle)
+under `-m gpu`, so that the driver observes them: default paths and the path selectors that force the MSD round 0,
+the timestamp MTF and the dense ranks by regions at small sizes.  Each slice is a child
+process (its own context; the selectors are read from the environment at run time) and a few seconds."""
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+LONG = os.path.join(ROOT, "tests", "long")
+
+SLICES = [
+    ("fuzz_long.py", ["150", "101", "60000"], {}),
+    ("fuzz_long.py", ["80", "102", "200000"], {"TC_SA_MSD": "2", "TC_SA_MSD_MIN_LOG2": "10"}),
+    ("fuzz_long.py", ["60", "103", "200000"], {"TC_SA_MSD": "2", "TC_SA_MSD_MIN_LOG2": "10", "TC_SA_MSD_BIG": "1"}),
+    ("fuzz_long.py", ["80", "104", "120000"], {"TC_MTF_TS": "2", "TC_SA_BIN_MIN_LOG2": "0"}),
+    ("fuzz_long.py", ["60", "105", "120000"], {"TC_SA_BIN_MIN_LOG2": "0", "TC_SA_DENSE": "1"}),
+    ("fuzz_raw.py", ["150", "106"], {}),
+    ("fuzz_raw.py", ["100", "107"], {"TC_MTF_TS": "2"}),
+    ("fuzz_fm.py", ["60", "108"], {}),
+]
+
+
+@pytest.mark.parametrize("script,args,env", SLICES, ids=["%s-%s-%s" % (s[0][:-3], s[1][1], "+".join(sorted(s[2])) or "default") for s in SLICES])
+def test_soak_slice(script, args, env):
+    e = dict(os.environ)
+    e.update(env)
+    os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+    p = subprocess.run([sys.executable, os.path.join(LONG, script)] + args, env=e, cwd=ROOT, capture_output=True, text=True, timeout=300)
+    tail = (p.stdout or "")[-1500:] + (p.stderr or "")[-1500:]
+    assert p.returncode == 0, tail
+    assert "0 failures" in p.stdout, tail

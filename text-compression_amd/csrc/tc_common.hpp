@@ -30,6 +30,7 @@ struct tc_ctx {
     u32 *d_err = nullptr;     // device error word (look-back spin overflow etc.)
     u64 *d_scalars = nullptr; // small device scratch for scalar results (64 words)
     u64 *h_scalars = nullptr; // pinned mirror
+    u8 *h_hdr = nullptr;      // pinned staging for a container header (1 KB)
     hipEvent_t ev[8] = {};
     hipEvent_t pev[2 * 16] = {};  // per-pass event pairs (profile mode)
     int profile = 0;

@@ -5,8 +5,13 @@
 //   code 0..11   start of a run: value = code % 6, count = 1 + code / 6
 //   code 12, 13  follows a start with count 2: count becomes 3, 4
 //   code 14      follows a start: count is the next word of the escape list (run order)
-//   code 15      padding (every 16384-run tile of the packer ends on a 16-byte boundary)
+//   code 15      padding (only at the very end: the stream is dense and padded to a 16-byte boundary)
 // so a run costs 4 bits (count 1, 2) or 8 bits; iid ACGTN: 1.04 nibbles per run.
+// The stream is a function of the runs alone, so the two producers below give the same bytes:
+// pack_nib_kernel (from a tc_block's run arrays) and rle_nib_kernel (straight from the MTF index
+// stream: the fused encode -> container path, no run arrays in HBM).  Tiles of either kernel start at
+// arbitrary nibble offsets; a 16-byte unit shared by neighbouring tiles is completed by atomicOr of
+// 32-bit words, which is why the output must be ZERO before the kernel runs.
 // 6 < sigma <= 16: one byte per run (value | min(count,15) << 4); sigma > 16: two bytes per run;
 // both with an escape list of (run index, count) pairs.
 #pragma once
@@ -62,19 +67,59 @@ __device__ __forceinline__ void pk_append(u64 &L, u64 &H, u32 &len, u32 &nesc, u
     len += nl;
 }
 
+// the tile's nibble image (u64 words, aligned to the GLOBAL 16-byte unit grid: nibble q0 of the stream sits at
+// image nibble q0 & 31) goes out: units that lie wholly inside [q0, q0 + tn) by one 16-byte store, the (up to
+// two) units shared with neighbouring tiles by atomicOr of their non-zero 32-bit words.  `pad`: the stream
+// ends with this tile -- the rest of its last unit is filled with code 15.  Every thread of the block calls.
+template <int NT>
+__device__ __forceinline__ void nib_image_out(const u64 *img, u64 q0, u32 tn, bool pad, u8 *out, u64 cap_units) {
+    if (tn == 0) return;
+    const u64 u_first = q0 >> 5, u_last = (q0 + tn - 1) >> 5;
+    const u32 nunits = (u32)(u_last - u_first) + 1u;
+    for (u32 u = threadIdx.x; u < nunits; u += NT) {
+        u64 w0 = img[2 * u], w1 = img[2 * u + 1];
+        const u64 g = u_first + u;
+        if (g >= cap_units) continue;
+        const u64 n0 = g << 5;                       // first nibble of this unit in the stream
+        const bool whole = n0 >= q0 && n0 + 32 <= q0 + tn;
+        if (pad && g == u_last) {
+            const u32 used = (u32)(q0 + tn - n0);    // 1..32 nibbles of this unit are real
+            if (used < 16u) { w0 |= ~0ull << (used * 4u); w1 = ~0ull; }
+            else if (used < 32u) w1 |= ~0ull << ((used - 16u) * 4u);
+        }
+        if (whole || (pad && g == u_last && n0 >= q0)) {
+            reinterpret_cast<ulonglong2 *>(out)[g] = make_ulonglong2(w0, w1);
+        } else {
+            u32 *o32 = reinterpret_cast<u32 *>(out) + 4 * g;
+            if ((u32)w0) atomicOr(o32, (u32)w0);
+            if ((u32)(w0 >> 32)) atomicOr(o32 + 1, (u32)(w0 >> 32));
+            if ((u32)w1) atomicOr(o32 + 2, (u32)w1);
+            if ((u32)(w1 >> 32)) atomicOr(o32 + 3, (u32)(w1 >> 32));
+        }
+    }
+}
+
+// look-back value of both producers: nibbles so far (< 2^32) << 30 | escapes so far (< 2^30: an encoded record
+// has a count >= 5 behind each, so at most N / 5 of them; run arrays handed to tc_block_pack_dev with more
+// escapes than that are refused: device flag 0x2, an error instead of wrong bytes)
+#define NIB_LB_SHIFT 30
+#define NIB_LB(nibs, esc) (((u64)(nibs) << NIB_LB_SHIFT) | (u64)(esc))
+#define NIB_LB_ESC(v) ((v) & ((1ull << NIB_LB_SHIFT) - 1))
+
 __global__ __launch_bounds__(PK_NT) void pack_nib_kernel(PackNibArgs a) {
-    __shared__ u64 nib[PK_WORDS + 2];
+    __shared__ u64 nib[PK_WORDS + 4];
     __shared__ u32 wsum[PK_SUB][PK_NT / 64];
     __shared__ u32 s_tile;
     __shared__ u64 s_excl;
     const int tid = threadIdx.x, lane = lane_id(), w = tid >> 6;
     while (true) {
+        __syncthreads();   // the image and s_tile of the previous tile have been read by everybody
         if (tid == 0) s_tile = atomicAdd(a.ticket, 1u);
+        for (int i = tid; i < PK_WORDS + 4; i += PK_NT) nib[i] = 0;
         __syncthreads();
         const u32 tile = s_tile;
         if (tile >= a.ntiles) break;
         const u64 base = (u64)tile * PK_TILE;
-        for (int i = tid; i < PK_WORDS + 2; i += PK_NT) nib[i] = 0;
 
         u64 L[PK_SUB], H[PK_SUB];
         u32 x[PK_SUB];  // nibbles | escapes << 16
@@ -122,7 +167,7 @@ __global__ __launch_bounds__(PK_NT) void pack_nib_kernel(PackNibArgs a) {
 #pragma unroll
             for (int s = 0; s < PK_SUB; s++) wsum[s][w] = inc[s];
         }
-        __syncthreads();  // also: nib[] zeroed
+        __syncthreads();
         u32 run = 0, excl[PK_SUB];
 #pragma unroll
         for (int s = 0; s < PK_SUB; s++) {
@@ -136,10 +181,17 @@ __global__ __launch_bounds__(PK_NT) void pack_nib_kernel(PackNibArgs a) {
             excl[s] = b + inc[s] - x[s];
         }
         const u32 tile_len = run & 0xffffu, tile_esc = run >> 16;
-        const u32 units = (tile_len + 31u) >> 5;
+        if (w == 0) {
+            const u64 e = lb_exclusive<OpSum>(a.status, tile, NIB_LB(tile_len, tile_esc), a.err);
+            if (lane == 0) s_excl = e;
+        }
+        __syncthreads();
+        const u64 q0 = s_excl >> NIB_LB_SHIFT, excl_esc = NIB_LB_ESC(s_excl);
+        if (tid == 0 && excl_esc + tile_esc >= (1ull << NIB_LB_SHIFT)) atomicOr(a.err, 2u);
+        const u32 a0 = (u32)(q0 & 31u);    // where the tile's first nibble sits in the image
 #pragma unroll
         for (int s = 0; s < PK_SUB; s++) {
-            const u32 off = excl[s] & 0xffffu;
+            const u32 off = a0 + (excl[s] & 0xffffu);
             const u32 wd = off >> 4, sh = (off & 15u) * 4u;
             const u64 l = L[s], h = H[s];
             const u64 w0 = l << sh;
@@ -149,20 +201,8 @@ __global__ __launch_bounds__(PK_NT) void pack_nib_kernel(PackNibArgs a) {
             if (w1) atomicOr((unsigned long long *)&nib[wd + 1], (unsigned long long)w1);
             if (w2) atomicOr((unsigned long long *)&nib[wd + 2], (unsigned long long)w2);
         }
-        if (w == 0) {
-            const u64 e = lb_exclusive<OpSum>(a.status, tile, ((u64)units << 32) | tile_esc, a.err);
-            if (lane == 0) s_excl = e;
-        }
         __syncthreads();
-        const u64 excl_units = s_excl >> 32, excl_esc = s_excl & 0xffffffffull;
-        for (u32 u = tid; u < units; u += PK_NT) {
-            u64 w0 = nib[2 * u], w1 = nib[2 * u + 1];
-            const u32 n0 = 32u * u;  // first nibble of this unit
-            if (tile_len < n0 + 16u) w0 |= ~0ull << ((tile_len - n0) * 4u);
-            if (tile_len < n0 + 32u) w1 = tile_len <= n0 + 16u ? ~0ull : (w1 | (~0ull << ((tile_len - n0 - 16u) * 4u)));
-            const u64 g = excl_units + u;
-            if (g < a.cap_units) reinterpret_cast<ulonglong2 *>(a.out)[g] = make_ulonglong2(w0, w1);
-        }
+        nib_image_out<PK_NT>(nib, q0, tile_len, tile + 1 == a.ntiles, a.out, a.cap_units);
         // escapes are rare: their owners re-read the counts and append them in run order
 #pragma unroll
         for (int s = 0; s < PK_SUB; s++) {
@@ -179,6 +219,238 @@ __global__ __launch_bounds__(PK_NT) void pack_nib_kernel(PackNibArgs a) {
                 }
             }
         }
+    }
+}
+
+// ---- the fused producer: MTF index stream (one byte per symbol, values < 6) -> nibble stream -----------------
+// Replaces, for the container of a small-alphabet record, rle_encode_idx_kernel + pack_nib_kernel: the 6-byte
+// run records (5.2 GB for a 1 GiB ACGTN record) are never written and re-read.  seqToRLE of the index stream
+// (reference RLE/Internal.hs:104-153; no Nothing in this stream, so only run ends exist) in a blocked
+// arrangement: a thread owns 16 consecutive positions per sub-tile (one 16-byte load).
+//   E    bit i: position p0 + i ends a run (its successor differs, or it is the last position): SWAR byte compare
+//   the length of a run is the distance from the previous end, which is the previous set bit of E or -- for
+//   the first run of a chunk -- the last end before the chunk: a max-scan over the tile in position order
+//   (inside a wave: ballot + one bpermute; waves and sub-tiles through LDS; tiles by look-back A).
+//   With X = E << 4 | (the last end before the chunk, if within 4 positions) the length classes are masks:
+//   length >= 2: X & ~(X << 1), >= 3: & ~(X << 2), >= 5: & ~(X << 3) & ~(X << 4) -- so nibbles and escapes per
+//   chunk are popcounts, their prefix over the tile one packed scan, their prefix over the tiles look-back B
+//   (sum), and the nibble strings are built -- position by position, four positions to a 32-bit group -- when
+//   their place in the stream is already known.
+#define RN_NT 512
+#define RN_SUB 4
+#define RN_SUBSZ (RN_NT * 16)             // 8192 positions
+#define RN_TILE (RN_SUB * RN_SUBSZ)       // 32768 positions
+#define RN_NSEG (RN_SUB * (RN_NT / 64))   // (sub-tile, wave) segments of 1024 positions, in position order
+#define RN_IMG_WORDS (RN_TILE / 16 + 4)   // a tile emits at most one nibble per position
+static_assert(RN_NSEG <= 64, "segment scans are done by one wave");
+
+struct RleNibArgs {
+    const u8 *src;   // index stream; 16-byte aligned; readable up to the next 16-byte boundary behind N
+    u64 N;
+    u8 *out;         // 16-byte aligned, ZERO for cap_units * 16 bytes
+    u64 cap_units;
+    u32 *esc;
+    u64 esc_cap;
+    u64 *status_a, *status_b;
+    u32 *ticket;
+    u64 *totals;     // [0] runs (atomicAdd), [1] nibbles, [2] escapes (written by the last tile)
+    u32 *err;
+    u32 ntiles;
+};
+
+// bits 0..3: which of the four bytes of d are non-zero
+__device__ __forceinline__ u32 nz_bytes4(u32 d) {
+    const u32 t = (((d & 0x7f7f7f7fu) + 0x7f7f7f7fu) | d) & 0x80808080u;
+    return ((t >> 7) * 0x01020408u) >> 24;
+}
+// exclusive prefix over the RN_NSEG per-segment values of a tile (a wave computes it for its RN_SUB segments):
+// lane g holds segment g's value
+template <class Op>
+__device__ __forceinline__ u32 seg_incl_scan(u32 v) {
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const u32 t = __shfl_up(v, d, 64);
+        if ((int)lane_id() >= d) v = (u32)Op::apply(v, t);
+    }
+    return v;
+}
+
+__global__ __launch_bounds__(RN_NT, 2) void rle_nib_kernel(RleNibArgs a) {
+    constexpr int NW = RN_NT / 64;
+    __shared__ u64 img[RN_IMG_WORDS];
+    __shared__ u32 s_last[RN_NSEG], s_carry[RN_NSEG], s_sum[RN_NSEG], s_runs[NW];
+    __shared__ u32 s_tile;
+    __shared__ u64 s_pref;
+    const int tid = threadIdx.x, lane = lane_id(), w = tid >> 6;
+    const u64 N = a.N;
+    for (;;) {
+        __syncthreads();   // the image, s_tile and s_pref of the previous tile have been read by everybody
+        if (tid == 0) s_tile = atomicAdd(a.ticket, 1u);
+        for (int i = tid; i < RN_IMG_WORDS; i += RN_NT) img[i] = 0;
+        __syncthreads();
+        const u32 tile = s_tile;
+        if (tile >= a.ntiles) break;
+        const u64 tbase = (u64)tile * RN_TILE;
+        const bool edge = tbase + RN_TILE >= N;   // the stream ends in this tile (block-uniform)
+
+        // ---- 1: load, run ends, last end per chunk ------------------------------------------------------
+        uint4 x[RN_SUB];
+        u32 E[RN_SUB], pv[RN_SUB];
+        u32 hasmask = 0;
+#pragma unroll
+        for (int s = 0; s < RN_SUB; s++) {
+            const u64 p0 = tbase + (u64)s * RN_SUBSZ + (u64)tid * 16;
+            uint4 q = make_uint4(0, 0, 0, 0);
+            if (!edge || p0 < N) q = *reinterpret_cast<const uint4 *>(a.src + p0);
+            u32 nx = __shfl_down(q.x, 1, 64);
+            if (lane == 63) nx = (!edge || p0 + 16 < N) ? (u32)a.src[p0 + 16] : 0u;
+            const u32 y0 = __builtin_amdgcn_alignbyte(q.y, q.x, 1), y1 = __builtin_amdgcn_alignbyte(q.z, q.y, 1);
+            const u32 y2 = __builtin_amdgcn_alignbyte(q.w, q.z, 1), y3 = __builtin_amdgcn_alignbyte(nx, q.w, 1);
+            u32 e = nz_bytes4(q.x ^ y0) | (nz_bytes4(q.y ^ y1) << 4) | (nz_bytes4(q.z ^ y2) << 8) | (nz_bytes4(q.w ^ y3) << 12);
+            if (edge) {
+                const u32 valid = p0 >= N ? 0u : (N - p0 >= 16 ? 0xffffu : ((1u << (u32)(N - p0)) - 1u));
+                e &= valid;
+                if (p0 < N && N - p0 <= 16) e |= 1u << (u32)(N - 1 - p0);   // the last position ends its run
+            }
+            x[s] = q;
+            E[s] = e;
+            const u32 last1 = e ? (u32)p0 + 32u - (u32)__builtin_clz(e) : 0u;   // 1 + position of the chunk's last end
+            const u64 m = __ballot(e != 0);
+            const u64 pm = m & lanemask_lt();
+            const int src = pm ? 63 - __builtin_clzll(pm) : 0;
+            pv[s] = __shfl(last1, src, 64);
+            if (pm) hasmask |= 1u << s;
+            const u32 wlast = m ? __shfl(last1, 63 - __builtin_clzll(m), 64) : 0u;
+            if (lane == 0) s_last[s * NW + w] = wlast;
+        }
+        __syncthreads();
+        // ---- 2: last end before every segment (wave 0: scan over the segments + look-back A over the tiles)
+        if (w == 0) {
+            const u32 v = lane < RN_NSEG ? s_last[lane] : 0u;
+            const u32 inc = seg_incl_scan<OpMax>(v);
+            const u32 agg = __shfl(inc, RN_NSEG - 1, 64);
+            u32 ex = __shfl_up(inc, 1, 64);
+            if (lane == 0) ex = 0;
+            const u32 tin = (u32)lb_exclusive<OpMax>(a.status_a, tile, agg, a.err);
+            if (lane < RN_NSEG) s_carry[lane] = ex > tin ? ex : tin;
+        }
+        __syncthreads();
+        // ---- 3: length classes, nibbles and escapes per chunk, prefix inside the tile ---------------------
+        u32 prev1[RN_SUB], cnt[RN_SUB], inc[RN_SUB];   // cnt: nibbles | escapes << 16
+        u32 myruns = 0;
+#pragma unroll
+        for (int s = 0; s < RN_SUB; s++) {
+            const u32 p0 = (u32)(tbase + (u64)s * RN_SUBSZ + (u64)tid * 16);
+            const u32 pe = ((hasmask >> s) & 1u) ? pv[s] : s_carry[s * NW + w];
+            prev1[s] = pe;
+            // the last end before the chunk is position pe - 1 (pe == 0: the virtual end before position 0)
+            const u32 back = p0 + 1u - pe;                       // 1: directly before the chunk, 2, 3, 4 ...
+            const u32 vb = (back - 1u < 4u) ? 1u << (4u - back) : 0u;
+            const u32 X = (E[s] << 4) | vb;
+            const u32 g2 = X & ~(X << 1);
+            const u32 g3 = g2 & ~(X << 2);
+            const u32 g5 = g3 & ~(X << 3) & ~(X << 4);
+            const u32 runs = (u32)__popc(E[s]);
+            myruns += runs;
+            cnt[s] = (runs + (u32)__popc((g3 >> 4) & 0xffffu)) | ((u32)__popc((g5 >> 4) & 0xffffu) << 16);
+            inc[s] = wave_incl_sum(cnt[s]);
+            if (lane == 63) s_sum[s * NW + w] = inc[s];
+        }
+        myruns = wave_sum(myruns);
+        if (lane == 0) s_runs[w] = myruns;
+        __syncthreads();
+        u32 excl[RN_SUB];
+        u32 tile_cnt;
+        {
+            const u32 v = lane < RN_NSEG ? s_sum[lane] : 0u;
+            const u32 sc = seg_incl_scan<OpSum>(v);
+            tile_cnt = __shfl(sc, RN_NSEG - 1, 64);
+#pragma unroll
+            for (int s = 0; s < RN_SUB; s++) {
+                const int g = s * NW + w;
+                const u32 before = g ? __shfl(sc, g - 1, 64) : 0u;
+                excl[s] = before + inc[s] - cnt[s];
+            }
+        }
+        const u32 tn = tile_cnt & 0xffffu, te = tile_cnt >> 16;
+        if (w == 1) {
+            const u64 e = lb_exclusive<OpSum>(a.status_b, tile, NIB_LB(tn, te), a.err);
+            if (lane == 0) {
+                s_pref = e;
+                if (tile + 1 == a.ntiles) {
+                    a.totals[1] = (e >> NIB_LB_SHIFT) + tn;
+                    a.totals[2] = NIB_LB_ESC(e) + te;
+                }
+            }
+        } else if (tid == 0) {
+            u32 r = 0;
+#pragma unroll
+            for (int i = 0; i < NW; i++) r += s_runs[i];
+            if (r) atomicAdd((unsigned long long *)&a.totals[0], (unsigned long long)r);
+        }
+        __syncthreads();
+        const u64 q0 = s_pref >> NIB_LB_SHIFT, e0 = NIB_LB_ESC(s_pref);
+        const u32 a0 = (u32)(q0 & 31u);
+        // ---- 4: the nibble strings, into the tile's image --------------------------------------------------
+#pragma unroll
+        for (int s = 0; s < RN_SUB; s++) {
+            const u32 p0 = (u32)(tbase + (u64)s * RN_SUBSZ + (u64)tid * 16);
+            const u32 xs[4] = {x[s].x, x[s].y, x[s].z, x[s].w};
+            u32 prev = prev1[s];
+            u64 L = 0;
+            u32 H = 0, len = 0;     // the chunk's string: at most 17 nibbles
+#pragma unroll
+            for (int d = 0; d < 4; d++) {
+                u32 g = 0, sh = 0;  // the nibbles of four positions: at most five
+#pragma unroll
+                for (int k = 0; k < 4; k++) {
+                    const int i = 4 * d + k;
+                    const bool end = (E[s] >> i) & 1u;
+                    const u32 pos1 = p0 + (u32)i + 1u;
+                    const u32 c1 = pos1 - prev - 1u;                      // run length - 1
+                    const u32 v = (xs[d] >> (8 * k)) & 0xffu;
+                    const u32 first = v + ((c1 - 1u < 3u) ? 6u : 0u);     // lengths 2, 3, 4: value + 6
+                    const u32 second = (c1 < 4u ? c1 : 4u) + 10u;         // 3 -> 12, 4 -> 13, >= 5 -> 14
+                    const bool two = c1 >= 2u;
+                    const u32 pair = first | (two ? second << 4 : 0u);
+                    if (end) {
+                        g |= pair << sh;
+                        sh += two ? 8u : 4u;
+                        prev = pos1;
+                    }
+                }
+                const u32 bsh = len * 4u;
+                if (len < 16u) {
+                    L |= (u64)g << bsh;
+                    if (bsh > 32u) H |= g >> (64u - bsh);
+                } else {
+                    H |= g << (bsh - 64u);
+                }
+                len += sh >> 2;
+            }
+            const u32 off = a0 + (excl[s] & 0xffffu);
+            const u32 wd = off >> 4, bs = (off & 15u) * 4u;
+            const u64 w0 = L << bs;
+            const u64 w1 = (bs ? L >> (64u - bs) : 0ull) | ((u64)H << bs);
+            if (w0) atomicOr((unsigned long long *)&img[wd], (unsigned long long)w0);
+            if (w1) atomicOr((unsigned long long *)&img[wd + 1], (unsigned long long)w1);
+            if (cnt[s] >> 16) {   // rare: lengths >= 5 go to the escape list, in run order
+                u64 e = e0 + (excl[s] >> 16);
+                u32 pr = prev1[s], em = E[s];
+                while (em) {
+                    const u32 i = (u32)__builtin_ctz(em);
+                    em &= em - 1u;
+                    const u32 c = p0 + i + 1u - pr;
+                    pr = p0 + i + 1u;
+                    if (c >= 5u) {
+                        if (e < a.esc_cap) a.esc[e] = c;
+                        e++;
+                    }
+                }
+            }
+        }
+        __syncthreads();
+        nib_image_out<RN_NT>(img, q0, tn, tile + 1 == a.ntiles, a.out, a.cap_units);
     }
 }
 

@@ -342,6 +342,7 @@ int tc_ctx_create(int device, tc_ctx **out) {
         TC_HIP(ctx, hipMalloc((void **)&ctx->d_err, 256));
         TC_HIP(ctx, hipMalloc((void **)&ctx->d_scalars, 128 * sizeof(u64)));
         TC_HIP(ctx, hipHostMalloc((void **)&ctx->h_scalars, 64 * sizeof(u64), hipHostMallocDefault));
+        TC_HIP(ctx, hipHostMalloc((void **)&ctx->h_hdr, 1024, hipHostMallocDefault));
         TC_HIP(ctx, hipMemsetAsync(ctx->d_err, 0, 256, ctx->stream));
         TC_HIP(ctx, hipMemsetAsync(ctx->d_scalars, 0, 128 * sizeof(u64), ctx->stream));
         for (int i = 0; i < 8; i++) TC_HIP(ctx, hipEventCreate(&ctx->ev[i]));
@@ -368,6 +369,7 @@ void tc_ctx_destroy(tc_ctx *ctx) {
     if (ctx->d_err) (void)hipFree(ctx->d_err);
     if (ctx->d_scalars) (void)hipFree(ctx->d_scalars);
     if (ctx->h_scalars) (void)hipHostFree(ctx->h_scalars);
+    if (ctx->h_hdr) (void)hipHostFree(ctx->h_hdr);
     if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;
 }
@@ -748,8 +750,14 @@ uint64_t tc_block_packed_bound(uint64_t nruns, uint32_t sigma) {
     return (((u64)fmt * nruns + 7) & ~7ull) + 8 * nruns + 8;
 }
 
+// ws_base: bytes at the start of the context's workspace that belong to the caller (the packer's scratch is
+// carved behind them; the caller has reserved block_pack_scratch() bytes there, so the workspace never moves)
+static size_t block_pack_scratch(u64 nruns) {
+    return (((size_t)(nruns / PR_TILE + nruns / PK_TILE + 8) * sizeof(u64) + 255) & ~(size_t)255) +
+           (((size_t)(nruns + 8) * sizeof(u32) + 255) & ~(size_t)255) + 512;
+}
 static void block_pack_device(tc_ctx *ctx, const tc_block *blk, uint8_t *d_packed, uint64_t *packed_bytes,
-                              uint64_t *nesc) {
+                              uint64_t *nesc, size_t ws_base = 0) {
     if (!blk || !packed_bytes || !nesc) TC_FAIL(ctx, TC_ERR_ARG, "bad argument");
     const u64 nruns = blk->nruns;
     const u64 cap = *packed_bytes;
@@ -771,10 +779,14 @@ static void block_pack_device(tc_ctx *ctx, const tc_block *blk, uint8_t *d_packe
         };
         Arena dry(nullptr);
         carve(dry);
-        tc_ws_reserve(ctx, dry.off);
-        Arena A(ctx->ws);
+        tc_ws_reserve(ctx, ws_base + dry.off);
+        Arena A(ctx->ws + ws_base);
         carve(A);
         tc_memset_async(ctx, status, 0, ((size_t)ntiles + 2) * sizeof(u64));
+        {   // tiles meet inside 16-byte units and complete them by atomicOr: the body must start out zero
+            const u64 most = ((2 * nruns + 31) / 32 + 1) * 16;     // at most two nibbles per run
+            tc_memset_async(ctx, d_packed, 0, most < (cap & ~15ull) ? most : (cap & ~15ull));
+        }
         PackNibArgs a;
         a.cnt = blk->run_count; a.val = blk->run_value; a.nruns = nruns;
         a.out = d_packed; a.cap_units = cap / 16;
@@ -788,7 +800,7 @@ static void block_pack_device(tc_ctx *ctx, const tc_block *blk, uint8_t *d_packe
         tc_d2h(ctx, &ctx->h_scalars[14], status + (ntiles - 1), sizeof(u64));
         tc_sync_check(ctx);
         const u64 tot = LB_VALUE(ctx->h_scalars[14]);
-        const u64 body = (tot >> 32) * 16, ne = tot & 0xffffffffull;
+        const u64 body = (((tot >> NIB_LB_SHIFT) + 31) / 32) * 16, ne = NIB_LB_ESC(tot);
         *nesc = ne;
         *packed_bytes = body + 4 * ne;
         if (*packed_bytes > cap || ne > esc_cap)
@@ -813,8 +825,8 @@ static void block_pack_device(tc_ctx *ctx, const tc_block *blk, uint8_t *d_packe
         auto carve = [&](Arena &A) { tcnt = A.get<u64>((size_t)tiles + 2); };
         Arena dry(nullptr);
         carve(dry);
-        tc_ws_reserve(ctx, dry.off);
-        Arena A(ctx->ws);
+        tc_ws_reserve(ctx, ws_base + dry.off);
+        Arena A(ctx->ws + ws_base);
         carve(A);
     }
     if (body >= 8) tc_memset_async(ctx, d_packed + body - 8, 0, 8);   // the alignment padding is part of the bytes
@@ -951,7 +963,7 @@ uint64_t tc_container_bound(uint64_t nruns, uint32_t sigma) {
     return TC_CONTAINER_HEADER + tc_block_packed_bound(nruns, sigma);
 }
 
-static void container_write_device(tc_ctx *ctx, const tc_block *blk, u8 *d_out, u64 *bytes) {
+static void container_write_device(tc_ctx *ctx, const tc_block *blk, u8 *d_out, u64 *bytes, size_t ws_base = 0) {
     if (!blk || !bytes) TC_FAIL(ctx, TC_ERR_ARG, "bad argument");
     const u64 cap = *bytes;
     *bytes = 0;
@@ -969,7 +981,7 @@ static void container_write_device(tc_ctx *ctx, const tc_block *blk, u8 *d_out, 
     for (u32 i = 0; i < blk->sigma; i++) h.final_list[i] = blk->final_list[i];
     u64 body = cap - TC_CONTAINER_HEADER, nesc = 0;
     try {
-        block_pack_device(ctx, blk, d_out + TC_CONTAINER_HEADER, &body, &nesc);
+        block_pack_device(ctx, blk, d_out + TC_CONTAINER_HEADER, &body, &nesc, ws_base);
     } catch (const TcFail &f) {
         if (f.code == TC_ERR_CAPACITY) *bytes = TC_CONTAINER_HEADER + body;
         throw;
@@ -1013,6 +1025,197 @@ static void container_read_device(tc_ctx *ctx, const u8 *d_in, u64 bytes, tc_blo
     block_unpack_device(ctx, d_in + TC_CONTAINER_HEADER, h.body_bytes, h.nruns, h.sigma, h.nesc, blk);
     blk->n = h.n; blk->primary = h.primary; blk->sigma = h.sigma; blk->nruns = h.nruns;
     for (u32 i = 0; i < h.sigma; i++) blk->final_list[i] = h.final_list[i];
+}
+
+// ---- text -> container on the device, the runs never leaving the chip for a small alphabet -----------------
+// What the multi-GPU step ships is the container, not the run arrays: for sigma <= 6 (an ACGTN record) the RLE
+// stage writes the container's nibble stream itself (rle_nib_kernel, tc_pack.hpp) and three small kernels seal
+// the container on the device -- escape list behind the body, checksum, header fields -- so the call has one
+// host synchronisation of its own (the sizes it returns).  Larger alphabets take the two-step way (run arrays
+// in the workspace, then the byte packers).  The bytes are those of tc_encode_dev + tc_block_to_container_dev.
+__global__ __launch_bounds__(256) void nib_escapes_kernel(const u64 *__restrict__ totals, const u32 *__restrict__ esc,
+                                                          u8 *__restrict__ body, u64 cap_bytes, u64 esc_cap) {
+    const u64 units = (totals[1] + 31) >> 5;
+    u64 nesc = totals[2];
+    if (nesc > esc_cap) nesc = esc_cap;
+    u32 *dst = reinterpret_cast<u32 *>(body + 16 * units);
+    for (u64 i = (u64)blockIdx.x * 256 + threadIdx.x; i < nesc; i += (u64)gridDim.x * 256)
+        if (16 * units + 4 * (i + 1) <= cap_bytes) dst[i] = esc[i];
+}
+// checksum64_kernel over a body whose length is known on the device only
+__global__ __launch_bounds__(256) void checksum64_dyn_kernel(const u32 *__restrict__ w, const u64 *__restrict__ totals,
+                                                             u64 cap_bytes, u64 *out) {
+    u64 nwords = 4 * ((totals[1] + 31) >> 5) + totals[2];
+    if (nwords > cap_bytes / 4) nwords = cap_bytes / 4;
+    u64 acc = 0;
+    for (u64 i = (u64)blockIdx.x * 256 + threadIdx.x; i < nwords; i += (u64)gridDim.x * 256) {
+        u64 z = ((u64)w[i] << 32 | (u32)i) + (i >> 32) * 0x9E3779B97F4A7C15ull;
+        z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+        z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+        acc += z ^ (z >> 31);
+    }
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) acc += __shfl_xor(acc, d, 64);
+    if (lane_id() == 0 && acc) atomicAdd((unsigned long long *)out, (unsigned long long)acc);
+}
+// header fields that only the device knows: nruns @24, nesc @32, body_bytes @40, checksum @48 (ContainerHeader)
+__global__ void container_seal_kernel(u8 *hdr, const u64 *totals, const u64 *sum, u64 *result) {
+    const u64 nruns = totals[0], nesc = totals[2], body = 16 * ((totals[1] + 31) >> 5) + 4 * nesc;
+    u64 *h = reinterpret_cast<u64 *>(hdr);
+    h[3] = nruns; h[4] = nesc; h[5] = body;
+    h[6] = *sum ^ (body * 0x9E3779B97F4A7C15ull);
+    result[0] = nruns; result[1] = nesc; result[2] = body;
+}
+
+static void encode_container_device(tc_ctx *ctx, const u8 *d_text, u64 n, u8 *d_out, u64 *bytes) {
+    const u64 cap = *bytes;
+    *bytes = 0;
+    if (!d_out || ((uintptr_t)d_out & 15)) TC_FAIL(ctx, TC_ERR_ARG, "container buffer must be 16-byte aligned");
+    if (cap < TC_CONTAINER_HEADER) {
+        *bytes = tc_container_bound(n + 2, TC_MAX_SIGMA);
+        TC_FAIL(ctx, TC_ERR_CAPACITY, "container needs at least %d bytes", TC_CONTAINER_HEADER);
+    }
+    if (n == 0) {   // empty in, empty out: a header with no runs
+        tc_block e;
+        memset(&e, 0, sizeof e);
+        *bytes = cap;
+        container_write_device(ctx, &e, d_out, bytes, 0);
+        return;
+    }
+    const u64 N = n + 1;
+    ctx->stats = tc_stats{};
+    ctx->stats.n = n; ctx->stats.N = N;
+    u8 *d_L = nullptr;
+    u16 *d_idx = nullptr;
+    u64 primary = 0;
+    u32 counts[256], counts257[257];
+    u32 sigma = 0;
+    i16 final_list[TC_MAX_SIGMA];
+    hipStream_t s = ctx->stream;
+    const u32 ntiles = tc_cdiv(N, RN_TILE);
+    const u64 esc_cap = N / 5 + 16;
+    bool fused = false;
+    tc_block blk;
+    memset(&blk, 0, sizeof blk);
+    size_t pack_base = 0;
+    u64 *status = nullptr;
+    auto plan = [&](Arena &A, bool dry) {
+        d_L = A.get<u8>(N + 16);
+        d_idx = A.get<u16>(N + 16);
+        size_t mark = A.off;
+        if (!dry) TC_HIP(ctx, hipEventRecord(ctx->ev[0], s));
+        sa_build(ctx, A, d_text, n, nullptr, d_L, &primary, counts, dry);
+        size_t end_sa = A.off;
+        A.off = mark;
+        if (!dry) {
+            TC_HIP(ctx, hipEventRecord(ctx->ev[1], s));
+            counts257[0] = 1;
+            for (int b = 0; b < 256; b++) counts257[1 + b] = counts[b];
+        }
+        BwtAcc acc{d_L, (i64)primary};
+        bool idx8 = false;
+        mtf_encode_device<BwtAcc>(ctx, A, acc, N, dry ? nullptr : counts257, d_idx, final_list, &sigma, dry,
+                                  reinterpret_cast<u8 *>(d_idx), &idx8);
+        if (!dry) TC_HIP(ctx, hipEventRecord(ctx->ev[2], s));
+        // scratch of both ways (the dry run does not know sigma yet)
+        status = A.get<u64>(2 * (size_t)ntiles + 32);
+        u32 *esc = A.get<u32>(esc_cap);
+        u32 *r_cnt = A.get<u32>(N + 2);
+        u16 *r_val = A.get<u16>(N + 2);
+        size_t rle_mark = A.off;
+        if (dry) {
+            U16Acc iacc{d_idx};
+            u64 t = 0;
+            rle_encode_device<U16Acc, u16>(ctx, A, iacc, N, r_cnt, r_val, N + 2, &t, true);
+            pack_base = A.off;
+            (void)A.get<u8>(block_pack_scratch(N + 2));
+            if (A.off < end_sa) A.off = end_sa;
+            return;
+        }
+        fused = idx8 && sigma <= PK_NIB_SIGMA;
+        if (fused) {
+            tc_memset_async(ctx, status, 0, (2 * (size_t)ntiles + 32) * sizeof(u64));
+            u8 *body = d_out + TC_CONTAINER_HEADER;
+            const u64 body_cap = cap - TC_CONTAINER_HEADER;
+            const u64 most = ((N + 31) / 32 + 1) * 16;       // at most one nibble per symbol
+            tc_memset_async(ctx, body, 0, most < (body_cap & ~15ull) ? most : (body_cap & ~15ull));
+            // what the host knows of the header goes first; the seal kernel fills in the rest
+            ContainerHeader h;
+            memset(&h, 0, sizeof h);
+            memcpy(h.magic, kContainerMagic, 8);
+            h.n = n; h.primary = primary; h.sigma = sigma; h.format = (u32)pack_format(sigma);
+            for (u32 i = 0; i < sigma; i++) h.final_list[i] = final_list[i];
+            memset(ctx->h_hdr, 0, TC_CONTAINER_HEADER);
+            memcpy(ctx->h_hdr, &h, sizeof h);
+            tc_h2d(ctx, d_out, ctx->h_hdr, TC_CONTAINER_HEADER);
+            RleNibArgs a;
+            a.src = reinterpret_cast<const u8 *>(d_idx); a.N = N;
+            a.out = body; a.cap_units = body_cap / 16;
+            a.esc = esc; a.esc_cap = esc_cap;
+            a.status_a = status; a.status_b = status + ntiles;
+            a.ticket = reinterpret_cast<u32 *>(status + 2 * (size_t)ntiles);
+            a.totals = status + 2 * (size_t)ntiles + 8;
+            a.err = ctx->d_err; a.ntiles = ntiles;
+            u32 grid = tc_persistent_grid_for(ctx, rle_nib_kernel, RN_NT, 4);
+            if (grid > ntiles) grid = ntiles;
+            rle_nib_kernel<<<grid, RN_NT, 0, s>>>(a);
+            TC_LAUNCH_CHECK(ctx);
+            u64 *sum = a.totals + 4, *result = a.totals + 5;
+            nib_escapes_kernel<<<64, 256, 0, s>>>(a.totals, esc, body, body_cap, esc_cap);
+            TC_LAUNCH_CHECK(ctx);
+            checksum64_dyn_kernel<<<4096, 256, 0, s>>>(reinterpret_cast<const u32 *>(body), a.totals, body_cap, sum);
+            TC_LAUNCH_CHECK(ctx);
+            container_seal_kernel<<<1, 1, 0, s>>>(d_out, a.totals, sum, result);
+            TC_LAUNCH_CHECK(ctx);
+            TC_HIP(ctx, hipEventRecord(ctx->ev[3], s));
+            tc_d2h(ctx, &ctx->h_scalars[20], result, 3 * sizeof(u64));
+        } else {
+            u64 total = 0;
+            A.off = rle_mark;
+            if (idx8) {
+                U8Acc iacc{reinterpret_cast<const u8 *>(d_idx)};
+                rle_encode_device<U8Acc, u16>(ctx, A, iacc, N, r_cnt, r_val, N + 2, &total, false);
+            } else {
+                U16Acc iacc{d_idx};
+                rle_encode_device<U16Acc, u16>(ctx, A, iacc, N, r_cnt, r_val, N + 2, &total, false);
+            }
+            TC_HIP(ctx, hipEventRecord(ctx->ev[3], s));
+            blk.n = n; blk.primary = primary; blk.sigma = sigma; blk.nruns = total;
+            blk.run_count = r_cnt; blk.run_value = r_val;
+            for (u32 i = 0; i < sigma; i++) blk.final_list[i] = final_list[i];
+        }
+        if (A.off < end_sa) A.off = end_sa;
+    };
+    Arena dry(nullptr);
+    plan(dry, true);
+    tc_ws_reserve(ctx, dry.off);
+    Arena A(ctx->ws);
+    plan(A, false);
+    tc_sync_check(ctx);
+    tc_stats &st = ctx->stats;
+    (void)hipEventElapsedTime(&st.ms_sa, ctx->ev[0], ctx->ev[1]);
+    (void)hipEventElapsedTime(&st.ms_mtf, ctx->ev[1], ctx->ev[2]);
+    (void)hipEventElapsedTime(&st.ms_rle, ctx->ev[2], ctx->ev[3]);
+    (void)hipEventElapsedTime(&st.ms_total, ctx->ev[0], ctx->ev[3]);
+    st.ms_bwt = 0;
+    if (fused) {
+        const u64 nruns = ctx->h_scalars[20], nesc = ctx->h_scalars[21], body = ctx->h_scalars[22];
+        st.runs = nruns;
+        *bytes = TC_CONTAINER_HEADER + body;
+        if (*bytes > cap || nesc > esc_cap)
+            TC_FAIL(ctx, TC_ERR_CAPACITY, "container needs %llu bytes", (unsigned long long)*bytes);
+        return;
+    }
+    st.runs = blk.nruns;
+    *bytes = cap;
+    container_write_device(ctx, &blk, d_out, bytes, pack_base);
+}
+
+int tc_encode_container_dev(tc_ctx *ctx, const uint8_t *d_text, uint64_t n, uint8_t *d_out, uint64_t *bytes) {
+    TC_API_BEGIN(ctx)
+    if (!bytes || n > TC_MAX_N || (n && !d_text)) TC_FAIL(ctx, TC_ERR_ARG, "bad argument");
+    encode_container_device(ctx, d_text, n, d_out, bytes);
+    TC_API_END(ctx)
 }
 
 int tc_block_to_container_dev(tc_ctx *ctx, const tc_block *blk, uint8_t *d_out, uint64_t *bytes) {

@@ -49,6 +49,8 @@ foreign import ccall unsafe "tc_container_bound"
   c_tc_container_bound :: Word64 -> Word32 -> Word64
 foreign import ccall safe "tc_encode_container"
   c_tc_encode_container :: Ptr TcCtx -> Ptr Word8 -> Word64 -> Ptr Word8 -> Ptr Word64 -> IO Int32
+foreign import ccall safe "tc_encode_container_dev"
+  c_tc_encode_container_dev :: Ptr TcCtx -> Ptr Word8 -> Word64 -> Ptr Word8 -> Ptr Word64 -> IO Int32
 foreign import ccall safe "tc_container_info"
   c_tc_container_info :: Ptr TcCtx -> Ptr Word8 -> Word64 -> Ptr Word64 -> Ptr Word64 -> IO Int32
 foreign import ccall safe "tc_decode_container"

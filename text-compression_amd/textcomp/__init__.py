@@ -250,6 +250,14 @@ class Context:
         self._check(self._lib.tc_encode_container(self._h, _ptr(t), n, _ptr(out), C.byref(used)))
         return out[:used.value].tobytes()
 
+    def encode_container_dev(self, d_text_ptr, n, d_out_ptr, cap):
+        """device text -> device container (tc_encode_container_dev: for sigma <= 6 the RLE stage writes the
+        container's nibble stream itself).  Returns the bytes used."""
+        used = C.c_uint64(int(cap))
+        self._check(self._lib.tc_encode_container_dev(self._h, C.c_void_p(d_text_ptr), int(n), C.c_void_p(d_out_ptr),
+                                                      C.byref(used)))
+        return int(used.value)
+
     def decode_container(self, blob):
         b = np.frombuffer(bytes(blob), np.uint8)
         n, nruns = C.c_uint64(), C.c_uint64()

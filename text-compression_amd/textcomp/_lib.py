@@ -80,6 +80,7 @@ SYMBOLS = [
     ("tc_block_unpack_dev", _INT, [_P, _P, _U64, _U64, _U32, _U64, C.POINTER(Block)]),
     ("tc_container_bound", _U64, [_U64, _U32]),
     ("tc_block_to_container_dev", _INT, [_P, C.POINTER(Block), _P, _PU64]),
+    ("tc_encode_container_dev", _INT, [_P, _P, _U64, _P, _PU64]),
     ("tc_container_to_block_dev", _INT, [_P, _P, _U64, C.POINTER(Block)]),
     ("tc_encode_container", _INT, [_P, _P, _U64, _P, _PU64]),
     ("tc_container_info", _INT, [_P, _P, _U64, _PU64, _PU64]),
