@@ -27,6 +27,10 @@ struct tc_ctx {
     char *ws = nullptr;  // device workspace arena
     size_t ws_cap = 0;
     size_t ws_off = 0;
+    // workspace built from separately created physical chunks mapped into one reserved address range
+    // (TC_WS_VMM = log2 of the chunk size; 0 = one hipMalloc block): empty unless that way was taken
+    std::vector<hipMemGenericAllocationHandle_t> ws_chunks;
+    size_t ws_chunk_bytes = 0, ws_mapped = 0;
     u32 *d_err = nullptr;     // device error word (look-back spin overflow etc.)
     u64 *d_scalars = nullptr; // small device scratch for scalar results (64 words)
     u64 *h_scalars = nullptr; // pinned mirror

@@ -8,10 +8,25 @@
 // locateFMIndex :448-542 mapped over the pattern list (FMIndex.hs:362-379,
 // 411-432, 475-497: serial or parListChunk sparks; here one lane per pattern in one
 // launch, result order = pattern order).
+//
+// Two symbols per step (round 3).  One backward-search step is one dependent random 64-byte line read, and the
+// batch of BASELINE configs[3] runs at the rate the memory system serves such reads (50 G lines/s from 2^27-byte
+// texts on, whatever the index size: scripts/fm_sweep.py) -- so the lever is the NUMBER of dependent reads.  For
+// texts of at most FM_PAIR_SIGMA byte values a second set of rank bit-vectors is kept, one per PAIR (a, b) of
+// byte values: bit j is set iff row j's suffix is preceded by "ab" (L[j] = b and T[SA[j] - 2] = a).  With
+// C2[ab] = C[a] + Occ(a, C[b]) (the start of the "ab" interval) two pattern symbols are consumed by one lookup:
+//   s' = C2[ab] + Occ2(ab, s - 1) + 1,  e' = C2[ab] + Occ2(ab, e)
+// which is exactly what two steps of countFMIndex (:424-432) compute, because the rows with pair ab inside a
+// range keep their relative order among the "ab"-prefixed suffixes.  The reference's stop rules stay as they
+// are: the range is tested for emptiness before every (single or double) step (:387-389), a byte that is not
+// in the text stops the loop where the reference stops it (:393,:421) -- a pair is only taken when both of its
+// bytes occur -- and an empty range between the two symbols of a pair stays empty, so the result (0 = Nothing)
+// is the same.  Cost: sigma^2 / 7 bytes per text byte (3.6 N for ACGTN).
 #pragma once
 #include "tc_decode_host.hpp"
 
 #define FM_LINE_BITS 448  // 7 words of payload per 64-byte line
+#define FM_PAIR_SIGMA 5   // pair vectors for texts of at most this many byte values (25 vectors)
 
 struct tc_fm {
     int device = 0;
@@ -21,6 +36,8 @@ struct tc_fm {
     u32 *d_sa = nullptr;
     u64 *d_bits = nullptr;  // [sigma_bytes][lines][8]
     u32 *d_tab = nullptr;   // [0..255] code of byte (0xFFFFFFFF absent), [256..511] C[code], [512..767] cnt[code]
+    u64 *d_bits2 = nullptr; // [sigma_bytes^2][lines][8]: one rank bit-vector per pair of byte values (or null)
+    u32 *d_tab2 = nullptr;  // [FM_PAIR_SIGMA^2] C2[a * sigma_bytes + b]
     u64 lines = 0;
     u32 counts[256];
     i16 sym_of_code[256];
@@ -85,6 +102,43 @@ __global__ __launch_bounds__(1024) void fm_scan_kernel(u64 *bits, u64 lines) {
     }
 }
 
+// the pair vectors: row j carries pair (a, b) = (T[SA[j] - 2], L[j]) when SA[j] >= 2 (a row whose suffix starts at
+// text position 0 or 1 has no pair: nothing can be matched two symbols to its left)
+__global__ __launch_bounds__(256) void fm_bits2_kernel(const u8 *__restrict__ L, const u32 *__restrict__ sa,
+                                                       const u8 *__restrict__ text, u64 N,
+                                                       const u32 *__restrict__ tab, u32 sigma, u64 lines,
+                                                       u64 *__restrict__ bits2) {
+    __shared__ u32 s_code[256];
+    s_code[threadIdx.x] = tab[threadIdx.x];
+    __syncthreads();
+    const u64 line = (u64)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (line >= lines) return;
+    const u32 l = threadIdx.x & 63;
+    u32 sw[7];
+#pragma unroll
+    for (int w = 0; w < 7; w++) {
+        const u64 j = line * FM_LINE_BITS + (u64)w * 64 + l;
+        u32 pc = 0xFFFFFFFFu;
+        if (j < N) {
+            const u32 p = sa[j];
+            if (p >= 2) pc = s_code[text[p - 2]] * sigma + s_code[L[j]];
+        }
+        sw[w] = pc;
+    }
+    for (u32 c = 0; c < sigma * sigma; c++) {
+        u64 mine = 0;
+        u32 pc = 0;
+#pragma unroll
+        for (int w = 0; w < 7; w++) {
+            const u64 m = __ballot(sw[w] == c);
+            pc += (u32)__popcll(m);
+            if ((int)l == w + 1) mine = m;
+        }
+        if (l == 0) mine = pc;
+        if (l < 8) bits2[((u64)c * lines + line) * 8 + l] = mine;
+    }
+}
+
 // Occ(c, k): occurrences of code c in L[0 .. k)
 __device__ __forceinline__ u64 fm_occ(const u64 *__restrict__ bits, u64 lines, u32 c, u64 k) {
     u64 line = k / FM_LINE_BITS;
@@ -139,16 +193,29 @@ __device__ __forceinline__ void fm_occ2(const u64 *__restrict__ bits, u64 lines,
     }
 }
 
+// C2[a * sigma + b] = C[a] + Occ(a, C[b]): the 0-based start of the interval of suffixes that begin with "ab"
+__global__ void fm_c2_kernel(const u64 *__restrict__ bits, u64 lines, const u32 *__restrict__ tab, u32 sigma,
+                             u32 *__restrict__ tab2) {
+    const u32 t = threadIdx.x;
+    if (t >= sigma * sigma) return;
+    const u32 a = t / sigma, b = t % sigma;
+    tab2[t] = tab[256 + a] + (u32)fm_occ(bits, lines, a, (u64)tab[256 + b]);
+}
+
 // countFMIndex (FMIndex/Internal.hs:347-438), one pattern per lane.
 // ranges (optional): [2p] = s, [2p+1] = e (1-based inclusive) for non-empty results.
-__global__ __launch_bounds__(256) void fm_count_kernel(const u64 *__restrict__ bits, u64 lines,
-                                                       const u32 *__restrict__ tab,
+template <bool PAIRS>
+__global__ __launch_bounds__(256) void fm_count_kernel(const u64 *__restrict__ bits, const u64 *__restrict__ bits2,
+                                                       u64 lines, const u32 *__restrict__ tab,
+                                                       const u32 *__restrict__ tab2, u32 sigma,
                                                        const u8 *__restrict__ pats,
                                                        const u64 *__restrict__ offs, u64 npat,
                                                        i64 *__restrict__ out,
                                                        u64 *__restrict__ ranges) {
     __shared__ u32 s_tab[768];
+    __shared__ u32 s_tab2[FM_PAIR_SIGMA * FM_PAIR_SIGMA];
     for (int i = threadIdx.x; i < 768; i += 256) s_tab[i] = tab[i];
+    if (PAIRS && threadIdx.x < FM_PAIR_SIGMA * FM_PAIR_SIGMA) s_tab2[threadIdx.x] = tab2[threadIdx.x];
     __syncthreads();
     u64 p = (u64)blockIdx.x * 256 + threadIdx.x;
     if (p >= npat) return;
@@ -160,29 +227,48 @@ __global__ __launch_bounds__(256) void fm_count_kernel(const u64 *__restrict__ b
     // that holds a valid byte lies in that byte's page, so reading it whole is always safe.
     uintptr_t wbase = ~(uintptr_t)0;
     u64 word = 0;
-    for (u64 q = end; q > beg; q--) {  // right to left (:375)
-        if (s > e) {                    // :387-389
-            flag = true;
-            break;
-        }
-        const uintptr_t ad = (uintptr_t)(pats + (q - 1));
+    auto byte_at = [&](u64 q) -> u32 {   // pats[q]
+        const uintptr_t ad = (uintptr_t)(pats + q);
         if ((ad & ~(uintptr_t)7) != wbase) {
             wbase = ad & ~(uintptr_t)7;
             word = *reinterpret_cast<const u64 *>(wbase);
         }
-        u32 c = s_tab[(u32)(word >> (8 * (ad & 7))) & 255u];
+        return (u32)(word >> (8 * (ad & 7))) & 255u;
+    };
+    u64 q = end;
+    while (q > beg) {                   // right to left (:375)
+        if (s > e) {                    // :387-389
+            flag = true;
+            break;
+        }
+        const u32 c = s_tab[byte_at(q - 1)];
         if (c == 0xFFFFFFFFu) break;    // findIndexL = Nothing: the loop just stops (:393,:421)
-        i64 C = (i64)s_tab[256 + c];
+        const i64 C = (i64)s_tab[256 + c];
         if (first) {                    // :391-418
             s = C + 1;
             e = C + (i64)s_tab[512 + c];
             first = false;
-        } else {                        // :424-432
-            u64 o1, o2;   // (s <= e here: s - 1 < e)
-            fm_occ2(bits, lines, c, (u64)(s - 1), (u64)e, &o1, &o2);
-            s = C + (i64)o1 + 1;
-            e = C + (i64)o2;
+            q--;
+            continue;
         }
+        if (PAIRS && q - 1 > beg) {     // two symbols by one lookup, when the one to the left occurs in the text too
+            const u32 a = s_tab[byte_at(q - 2)];
+            if (a != 0xFFFFFFFFu) {
+                const u32 pr = a * sigma + c;
+                u64 o1, o2;
+                fm_occ2(bits2, lines, pr, (u64)(s - 1), (u64)e, &o1, &o2);
+                const i64 C2 = (i64)s_tab2[pr];
+                s = C2 + (i64)o1 + 1;
+                e = C2 + (i64)o2;
+                q -= 2;
+                continue;
+            }
+        }
+        u64 o1, o2;                     // :424-432 (s <= e here: s - 1 < e)
+        fm_occ2(bits, lines, c, (u64)(s - 1), (u64)e, &o1, &o2);
+        s = C + (i64)o1 + 1;
+        e = C + (i64)o2;
+        q--;
     }
     i64 cnt = (first || (e - s + 1) == 0 || flag) ? 0 : (e - s + 1);  // :366-371
     out[p] = cnt;
@@ -224,12 +310,32 @@ __global__ __launch_bounds__(256) void fm_locate_fill_kernel(const u64 *__restri
 
 #endif  // __HIPCC__
 
+// code of byte / C[code] / count[code] from the byte histogram; returns the number of present byte values
+static u32 fm_make_tab(const u32 *counts, u32 *tab, i16 *sym_of_code) {
+    u32 sig = 0, acc = 1;
+    for (int b = 0; b < 256; b++) {
+        tab[b] = 0xFFFFFFFFu;
+        if (counts[b]) {
+            tab[b] = sig;
+            tab[256 + sig] = acc;
+            tab[512 + sig] = counts[b];
+            if (sym_of_code) sym_of_code[sig] = (i16)b;
+            acc += counts[b];
+            sig++;
+        }
+    }
+    for (u32 c = sig; c < 256; c++) tab[256 + c] = tab[512 + c] = 0;
+    return sig;
+}
+
 static void fm_release(tc_fm *fm) {
     if (!fm) return;
     (void)hipSetDevice(fm->device);
     if (fm->d_L) (void)hipFree(fm->d_L);
     if (fm->d_sa) (void)hipFree(fm->d_sa);
     if (fm->d_bits) (void)hipFree(fm->d_bits);
+    if (fm->d_bits2) (void)hipFree(fm->d_bits2);
+    if (fm->d_tab2) (void)hipFree(fm->d_tab2);
     if (fm->d_tab) (void)hipFree(fm->d_tab);
     delete fm;
 }
@@ -260,19 +366,7 @@ static tc_fm *fm_build_device(tc_ctx *ctx, const u8 *text_host, u64 n) {
         plan(A, false);
         // C[c] = #symbols of text.'$' smaller than c ('$' = Nothing counts once)
         u32 tab[768];
-        u32 sig = 0, acc = 1;
-        for (int b = 0; b < 256; b++) {
-            tab[b] = 0xFFFFFFFFu;
-            if (fm->counts[b]) {
-                tab[b] = sig;
-                tab[256 + sig] = acc;
-                tab[512 + sig] = fm->counts[b];
-                fm->sym_of_code[sig] = (i16)b;
-                acc += fm->counts[b];
-                sig++;
-            }
-        }
-        for (u32 c = sig; c < 256; c++) tab[256 + c] = tab[512 + c] = 0;
+        const u32 sig = fm_make_tab(fm->counts, tab, fm->sym_of_code);
         fm->sigma_bytes = sig;
         fm->lines = N / FM_LINE_BITS + 1;
         TC_HIP(ctx, hipMalloc((void **)&fm->d_bits, (size_t)sig * fm->lines * 64));
@@ -283,6 +377,18 @@ static tc_fm *fm_build_device(tc_ctx *ctx, const u8 *text_host, u64 n) {
         TC_LAUNCH_CHECK(ctx);
         fm_scan_kernel<<<sig, 1024, 0, s>>>(fm->d_bits, fm->lines);
         TC_LAUNCH_CHECK(ctx);
+        if (sig <= FM_PAIR_SIGMA && n >= 2 && env_int("TC_FM_PAIRS", 1) != 0) {
+            TC_HIP(ctx, hipMalloc((void **)&fm->d_tab2, FM_PAIR_SIGMA * FM_PAIR_SIGMA * sizeof(u32)));
+            TC_HIP(ctx, hipMalloc((void **)&fm->d_bits2, (size_t)sig * sig * fm->lines * 64));
+            TC_HIP(ctx, hipMemsetAsync(fm->d_tab2, 0, FM_PAIR_SIGMA * FM_PAIR_SIGMA * sizeof(u32), s));
+            fm_bits2_kernel<<<tc_cdiv(fm->lines, 4), 256, 0, s>>>(fm->d_L, fm->d_sa, d_text, N, fm->d_tab, sig,
+                                                                 fm->lines, fm->d_bits2);
+            TC_LAUNCH_CHECK(ctx);
+            fm_scan_kernel<<<sig * sig, 1024, 0, s>>>(fm->d_bits2, fm->lines);
+            TC_LAUNCH_CHECK(ctx);
+            fm_c2_kernel<<<1, 64, 0, s>>>(fm->d_bits, fm->lines, fm->d_tab, sig, fm->d_tab2);
+            TC_LAUNCH_CHECK(ctx);
+        }
         tc_sync_check(ctx);
     } catch (...) {
         fm_release(fm);
@@ -294,8 +400,13 @@ static tc_fm *fm_build_device(tc_ctx *ctx, const u8 *text_host, u64 n) {
 // ranges (device, 2*npat u64) may be null
 static void fm_count_device(tc_ctx *ctx, const tc_fm *fm, const u8 *d_pats, const u64 *d_offs,
                             u64 npat, i64 *d_out, u64 *d_ranges) {
-    fm_count_kernel<<<tc_cdiv(npat, 256), 256, 0, ctx->stream>>>(fm->d_bits, fm->lines, fm->d_tab,
-                                                                 d_pats, d_offs, npat, d_out,
-                                                                 d_ranges);
+    if (fm->d_bits2)
+        fm_count_kernel<true><<<tc_cdiv(npat, 256), 256, 0, ctx->stream>>>(fm->d_bits, fm->d_bits2, fm->lines, fm->d_tab,
+                                                                           fm->d_tab2, fm->sigma_bytes, d_pats, d_offs,
+                                                                           npat, d_out, d_ranges);
+    else
+        fm_count_kernel<false><<<tc_cdiv(npat, 256), 256, 0, ctx->stream>>>(fm->d_bits, nullptr, fm->lines, fm->d_tab,
+                                                                            nullptr, fm->sigma_bytes, d_pats, d_offs,
+                                                                            npat, d_out, d_ranges);
     TC_LAUNCH_CHECK(ctx);
 }

@@ -12,25 +12,111 @@
 #include "textcomp_debug.h"
 
 // ================================================================== context
+// The workspace.  Long records want it as physical chunks created one by one and mapped into one reserved,
+// chunk-aligned address range (HIP virtual memory management) rather than as one hipMalloc block: with the
+// single block the partition levels of a 1 GiB record run in their slow mode three times out of four (memory-
+// side back-pressure: TCC_EA0_{WR,RD}REQ_DRAM_CREDIT_STALL 3.5x / 6x higher, address translation alike;
+// profiles/r03_mode_pmc.txt), with chunks of 2^24 .. 2^34 bytes 30 fresh contexts of 32 landed in the fast one
+// (profiles/r03_ws_recipes.txt).  TC_WS_VMM = log2 of the chunk size (default 28; 0: always
+// hipMalloc); workspaces under 1 GiB are plain hipMalloc blocks.
+struct TcWs {
+    char *p = nullptr;
+    size_t cap = 0, mapped = 0;
+    std::vector<hipMemGenericAllocationHandle_t> chunks;
+};
+static TcWs ws_detach(tc_ctx *ctx) {
+    TcWs w;
+    w.p = ctx->ws; w.cap = ctx->ws_cap; w.mapped = ctx->ws_mapped;
+    w.chunks.swap(ctx->ws_chunks);
+    ctx->ws = nullptr; ctx->ws_cap = 0; ctx->ws_mapped = 0;
+    return w;
+}
+static void ws_attach(tc_ctx *ctx, TcWs &w) {
+    ctx->ws = w.p; ctx->ws_cap = w.cap; ctx->ws_mapped = w.mapped;
+    ctx->ws_chunks.swap(w.chunks);
+    w = TcWs();
+}
+static void ws_free(TcWs &w) {
+    if (!w.p) return;
+    if (!w.chunks.empty()) {
+        (void)hipMemUnmap(w.p, w.mapped);
+        for (auto h : w.chunks) (void)hipMemRelease(h);
+        (void)hipMemAddressFree(w.p, w.mapped);
+    } else {
+        (void)hipFree(w.p);
+    }
+    w = TcWs();
+}
+static bool ws_alloc_vmm(tc_ctx *ctx, size_t want, int chunk_log2, TcWs &w) {
+    hipMemAllocationProp prop = {};
+    prop.type = hipMemAllocationTypePinned;
+    prop.location.type = hipMemLocationTypeDevice;
+    prop.location.id = ctx->device;
+    size_t gran = 0;
+    if (hipMemGetAllocationGranularity(&gran, &prop, hipMemAllocationGranularityRecommended) != hipSuccess || !gran) {
+        (void)hipGetLastError();
+        return false;
+    }
+    size_t chunk = (size_t)1 << chunk_log2;
+    chunk = (chunk + gran - 1) / gran * gran;
+    const size_t total = (want + chunk - 1) / chunk * chunk;
+    void *va = nullptr;
+    if (hipMemAddressReserve(&va, total, chunk, nullptr, 0) != hipSuccess) {
+        (void)hipGetLastError();
+        return false;
+    }
+    size_t done = 0;
+    bool ok = true;
+    for (; done < total; done += chunk) {
+        hipMemGenericAllocationHandle_t h;
+        if (hipMemCreate(&h, chunk, &prop, 0) != hipSuccess) { ok = false; break; }
+        if (hipMemMap((char *)va + done, chunk, 0, h, 0) != hipSuccess) { (void)hipMemRelease(h); ok = false; break; }
+        w.chunks.push_back(h);
+    }
+    if (ok) {
+        hipMemAccessDesc acc = {};
+        acc.location = prop.location;
+        acc.flags = hipMemAccessFlagsProtReadWrite;
+        ok = hipMemSetAccess(va, total, &acc, 1) == hipSuccess;
+    }
+    if (!ok) {
+        (void)hipGetLastError();
+        if (done) (void)hipMemUnmap(va, done);
+        for (auto h : w.chunks) (void)hipMemRelease(h);
+        w.chunks.clear();
+        (void)hipMemAddressFree(va, total);
+        return false;
+    }
+    w.p = (char *)va; w.cap = total; w.mapped = total;
+    return true;
+}
+// a workspace of `want` bytes (exactly `want` when exact: a second placement of an existing size)
+static bool ws_alloc(tc_ctx *ctx, size_t want, TcWs &w) {
+    const int vmm = env_int("TC_WS_VMM", 28);
+    if (vmm >= 21 && vmm <= 36 && want >= ((size_t)1 << 30) && ws_alloc_vmm(ctx, want, vmm, w)) return true;
+    if (hipMalloc((void **)&w.p, want) != hipSuccess) {
+        (void)hipGetLastError();
+        w.p = nullptr;
+        return false;
+    }
+    w.cap = want;
+    return true;
+}
+static void tc_ws_release(tc_ctx *ctx) {
+    TcWs w = ws_detach(ctx);
+    ws_free(w);
+}
+
 void tc_ws_reserve(tc_ctx *ctx, size_t bytes) {
     if (bytes <= ctx->ws_cap) return;
     if (ctx->ws) {
         TC_HIP(ctx, hipStreamSynchronize(ctx->stream));
-        TC_HIP(ctx, hipFree(ctx->ws));
-        ctx->ws = nullptr;
-        ctx->ws_cap = 0;
+        tc_ws_release(ctx);
     }
-    size_t want = bytes + (bytes >> 4) + (1u << 20);
-    hipError_t e = hipMalloc((void **)&ctx->ws, want);
-    if (e != hipSuccess) {
-        want = bytes;
-        e = hipMalloc((void **)&ctx->ws, want);
-    }
-    if (e != hipSuccess) {
-        (void)hipGetLastError();
-        TC_FAIL(ctx, TC_ERR_OOM, "workspace of %zu bytes: %s", bytes, hipGetErrorString(e));
-    }
-    ctx->ws_cap = want;
+    TcWs w;
+    if (!ws_alloc(ctx, bytes + (bytes >> 4) + (1u << 20), w) && !ws_alloc(ctx, bytes, w))
+        TC_FAIL(ctx, TC_ERR_OOM, "workspace of %zu bytes: out of device memory", bytes);
+    ws_attach(ctx, w);
 }
 
 u32 tc_persistent_grid(tc_ctx *ctx, int blocks_per_cu) {
@@ -365,7 +451,7 @@ void tc_ctx_destroy(tc_ctx *ctx) {
         if (ctx->ev[i]) (void)hipEventDestroy(ctx->ev[i]);
     for (int i = 0; i < 32; i++)
         if (ctx->pev[i]) (void)hipEventDestroy(ctx->pev[i]);
-    if (ctx->ws) (void)hipFree(ctx->ws);
+    tc_ws_release(ctx);
     if (ctx->d_err) (void)hipFree(ctx->d_err);
     if (ctx->d_scalars) (void)hipFree(ctx->d_scalars);
     if (ctx->h_scalars) (void)hipHostFree(ctx->h_scalars);
@@ -409,17 +495,14 @@ int tc_ctx_place_workspace(tc_ctx *ctx, const uint8_t *d_text, uint64_t n, tc_bl
         return best;
     };
     int best = 0;
-    char *best_ws = nullptr;
-    size_t best_cap = 0;
+    TcWs best_ws;                       // the best placement so far while a candidate is attached to the context
     auto release = [&]() {
         for (char *sp : spacers) (void)hipFree(sp);
         spacers.clear();
     };
     try {
         t.push_back(timed());          // placement 0: the workspace the context has (sized by this very encode)
-        best_ws = ctx->ws;
         const size_t cap0 = ctx->ws_cap;
-        best_cap = cap0;
         for (int k = 1; k < tries; k++) {
             double worst = 0;
             for (double v : t) worst = v > worst ? v : worst;
@@ -427,40 +510,36 @@ int tc_ctx_place_workspace(tc_ctx *ctx, const uint8_t *d_text, uint64_t n, tc_bl
             if (t[best] < 0.96 * worst && env_int("TC_PLACE_ALL", 0) == 0) break;   // (TC_PLACE_ALL=1: experiments)
             size_t free_b = 0, total_b = 0;
             TC_HIP(ctx, hipMemGetInfo(&free_b, &total_b));
-            if (free_b < ctx->ws_cap + ((size_t)8 << 30)) break;     // no room for a second block
-            char *cand = nullptr;
-            if (hipMalloc((void **)&cand, ctx->ws_cap) != hipSuccess) {
-                (void)hipGetLastError();
-                break;
-            }
-            ctx->ws = cand;            // (the best block so far stays allocated: the candidate lands elsewhere)
+            if (free_b < cap0 + ((size_t)8 << 30)) break;     // no room for a second workspace
+            TcWs cand;
+            if (!ws_alloc(ctx, cap0, cand)) break;
+            best_ws = ws_detach(ctx);  // (the best one so far stays allocated: the candidate lands elsewhere)
+            ws_attach(ctx, cand);
             t.push_back(timed());
-            if (ctx->ws_cap != cap0) {   // the workspace grew under the candidate (cannot happen for one record): keep it
-                (void)hipFree(best_ws);
-                best_ws = ctx->ws;
-                best_cap = ctx->ws_cap;
+            if (ctx->ws_cap < cap0 || ctx->ws_cap > cap0 + ((size_t)1 << 30)) {   // re-reserved under the candidate: keep it
+                ws_free(best_ws);
                 best = k;
                 break;
             }
-            char *loser = cand;
             if (t[k] < t[best]) {
                 best = k;
-                loser = best_ws;
-                best_ws = cand;
+                ws_free(best_ws);
+            } else {
+                TcWs loser = ws_detach(ctx);
+                ws_attach(ctx, best_ws);
+                const bool plain = loser.chunks.empty();
+                ws_free(loser);
+                // a spacer in the hole a rejected block leaves: the next candidate does not fit there and goes somewhere new
+                char *sp = nullptr;
+                if (plain && hipMalloc((void **)&sp, (size_t)1 << 30) == hipSuccess) spacers.push_back(sp);
+                else (void)hipGetLastError();
             }
-            ctx->ws = best_ws;
-            (void)hipFree(loser);
-            // a spacer in the hole the loser leaves: the next candidate does not fit there and goes somewhere new
-            char *sp = nullptr;
-            if (hipMalloc((void **)&sp, (size_t)1 << 30) == hipSuccess) spacers.push_back(sp);
-            else (void)hipGetLastError();
         }
     } catch (const TcFail &) {
-        if (best_ws && ctx->ws != best_ws) {     // reinstate the best block WITH its capacity (a reserve inside
-            if (ctx->ws) (void)hipFree(ctx->ws); // timed() may have grown or, after an OOM, dropped the candidate)
-            ctx->ws = best_ws;
+        if (best_ws.p) {               // reinstate the best workspace, with its capacity, whatever the candidate became
+            tc_ws_release(ctx);
+            ws_attach(ctx, best_ws);
         }
-        if (best_ws) ctx->ws_cap = best_cap;
         release();
         throw;
     }
@@ -1589,19 +1668,20 @@ void tc_fm_free(tc_fm *fm) { fm_release(fm); }
 
 // ---- the index as one device byte string (replication over the GPUs of a node) ----------------
 struct FmWire {
-    char magic[8];   // "TCFMI01\0"
+    char magic[8];   // "TCFMI02\0"
     u64 n, N, primary, lines, bytes;
     u32 sigma_bytes, with_locate;
+    u32 with_pairs, reserved;   // 1: the pair vectors (sigma_bytes^2 of them) follow the per-byte vectors
     u32 counts[256];
     i16 sym_of_code[256];
-    u32 tab[768];
 };
-static const char kFmMagic[8] = {'T', 'C', 'F', 'M', 'I', '0', '1', 0};
+static const char kFmMagic[8] = {'T', 'C', 'F', 'M', 'I', '0', '2', 0};
 static inline u64 fm_wire_align(u64 v) { return (v + 255) & ~(u64)255; }
 static u64 fm_wire_bytes(const tc_fm *fm, int with_locate) {
     u64 b = fm_wire_align(sizeof(FmWire));
     if (fm->n == 0) return b;
     b += fm_wire_align((u64)fm->sigma_bytes * fm->lines * 64);
+    if (fm->d_bits2) b += fm_wire_align((u64)fm->sigma_bytes * fm->sigma_bytes * fm->lines * 64);
     if (with_locate) b += fm_wire_align(fm->N + 16) + fm_wire_align(fm->N * sizeof(u32));
     return b;
 }
@@ -1619,17 +1699,20 @@ int tc_fm_export_dev(tc_ctx *ctx, const tc_fm *fm, int with_locate, uint8_t *d_o
     memcpy(h.magic, kFmMagic, 8);
     h.n = fm->n; h.N = fm->N; h.primary = fm->primary; h.lines = fm->lines; h.bytes = need;
     h.sigma_bytes = fm->sigma_bytes; h.with_locate = (fm->n && with_locate) ? 1u : 0u;
+    h.with_pairs = fm->d_bits2 ? 1u : 0u;
     memcpy(h.counts, fm->counts, sizeof h.counts);
     memcpy(h.sym_of_code, fm->sym_of_code, sizeof h.sym_of_code);
     hipStream_t s = ctx->stream;
-    if (fm->n) TC_HIP(ctx, hipMemcpyAsync(h.tab, fm->d_tab, sizeof h.tab, hipMemcpyDeviceToHost, s));
-    TC_HIP(ctx, hipStreamSynchronize(s));
     TC_HIP(ctx, hipMemcpyAsync(d_out, &h, sizeof h, hipMemcpyHostToDevice, s));
     u64 o = fm_wire_align(sizeof(FmWire));
     if (fm->n) {
         const u64 bb = (u64)fm->sigma_bytes * fm->lines * 64;
         TC_HIP(ctx, hipMemcpyAsync(d_out + o, fm->d_bits, bb, hipMemcpyDeviceToDevice, s));
         o += fm_wire_align(bb);
+        if (fm->d_bits2) {
+            TC_HIP(ctx, hipMemcpyAsync(d_out + o, fm->d_bits2, bb * fm->sigma_bytes, hipMemcpyDeviceToDevice, s));
+            o += fm_wire_align(bb * fm->sigma_bytes);
+        }
         if (with_locate) {
             TC_HIP(ctx, hipMemcpyAsync(d_out + o, fm->d_L, fm->N, hipMemcpyDeviceToDevice, s));
             o += fm_wire_align(fm->N + 16);
@@ -1665,6 +1748,8 @@ int tc_fm_import_dev(tc_ctx *ctx, const uint8_t *d_in, uint64_t bytes, tc_fm **o
         if (h.n && (h.primary == 0 || h.primary >= h.N || total != h.n || present != h.sigma_bytes || !codes_ok))
             TC_FAIL(ctx, TC_ERR_MALFORMED, "exported FM-index: header is inconsistent");
     }
+    if (h.with_pairs > 1 || (h.with_pairs && (h.sigma_bytes > FM_PAIR_SIGMA || h.n < 2)))
+        TC_FAIL(ctx, TC_ERR_MALFORMED, "exported FM-index: header is inconsistent");
     tc_fm *fm = new tc_fm();
     fm->device = ctx->device;
     fm->n = h.n; fm->N = h.N; fm->primary = h.primary; fm->lines = h.lines; fm->sigma_bytes = h.sigma_bytes;
@@ -1672,15 +1757,29 @@ int tc_fm_import_dev(tc_ctx *ctx, const uint8_t *d_in, uint64_t bytes, tc_fm **o
     memcpy(fm->sym_of_code, h.sym_of_code, sizeof h.sym_of_code);
     try {
         if (fm->n) {
-            tc_fm probe = *fm;
-            if (fm_wire_bytes(&probe, (int)h.with_locate) != h.bytes) TC_FAIL(ctx, TC_ERR_MALFORMED, "exported FM-index: size mismatch");
             const u64 bb = (u64)fm->sigma_bytes * fm->lines * 64;
+            u64 need = fm_wire_align(sizeof(FmWire)) + fm_wire_align(bb);
+            if (h.with_pairs) need += fm_wire_align(bb * fm->sigma_bytes);
+            if (h.with_locate) need += fm_wire_align(fm->N + 16) + fm_wire_align(fm->N * sizeof(u32));
+            if (need != h.bytes) TC_FAIL(ctx, TC_ERR_MALFORMED, "exported FM-index: size mismatch");
+            u32 tab[768];
+            (void)fm_make_tab(fm->counts, tab, nullptr);
             TC_HIP(ctx, hipMalloc((void **)&fm->d_tab, 768 * sizeof(u32)));
             TC_HIP(ctx, hipMalloc((void **)&fm->d_bits, bb));
-            TC_HIP(ctx, hipMemcpyAsync(fm->d_tab, h.tab, sizeof h.tab, hipMemcpyHostToDevice, s));
+            TC_HIP(ctx, hipMemcpyAsync(fm->d_tab, tab, sizeof tab, hipMemcpyHostToDevice, s));
+            TC_HIP(ctx, hipStreamSynchronize(s));   // tab is a stack buffer
             u64 o = fm_wire_align(sizeof(FmWire));
             TC_HIP(ctx, hipMemcpyAsync(fm->d_bits, d_in + o, bb, hipMemcpyDeviceToDevice, s));
             o += fm_wire_align(bb);
+            if (h.with_pairs) {
+                TC_HIP(ctx, hipMalloc((void **)&fm->d_tab2, FM_PAIR_SIGMA * FM_PAIR_SIGMA * sizeof(u32)));
+                TC_HIP(ctx, hipMalloc((void **)&fm->d_bits2, bb * fm->sigma_bytes));
+                TC_HIP(ctx, hipMemsetAsync(fm->d_tab2, 0, FM_PAIR_SIGMA * FM_PAIR_SIGMA * sizeof(u32), s));
+                TC_HIP(ctx, hipMemcpyAsync(fm->d_bits2, d_in + o, bb * fm->sigma_bytes, hipMemcpyDeviceToDevice, s));
+                o += fm_wire_align(bb * fm->sigma_bytes);
+                fm_c2_kernel<<<1, 64, 0, s>>>(fm->d_bits, fm->lines, fm->d_tab, fm->sigma_bytes, fm->d_tab2);
+                TC_LAUNCH_CHECK(ctx);
+            }
             if (h.with_locate) {
                 TC_HIP(ctx, hipMalloc((void **)&fm->d_L, fm->N + 16));
                 TC_HIP(ctx, hipMalloc((void **)&fm->d_sa, fm->N * sizeof(u32)));
