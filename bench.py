@@ -294,10 +294,26 @@ def main():
     if world > 1:
         from textcomp.gather import BlockGather, NativeGather
         pcap = n + n // 4 + 4096          # packed bytes per record (iid ACGTN: ~0.8 n), with slack
-        # TC_BENCH_GATHER=native: the exchange through the library's own RCCL communicator (tc_comm_*, the C
-        # ABI a Haskell or C caller would use) instead of torch.distributed's point-to-point batch
-        native = os.environ.get("TC_BENCH_GATHER") == "native" and not rehearsal
-        gatherer = NativeGather(ctx, pcap, dev, depth=2) if native else BlockGather(pcap, xdev, depth=2)
+        # the exchange goes through the library's own RCCL communicator (tc_comm_*, the C ABI a Haskell or C caller
+        # would use): one group of point-to-point transfers into rank 0, posted behind the encode
+        # and on its own CU-restricted stream, so that RCCL's workgroups cannot hold back the partition levels of the
+        # next record's encode (tc_comm_create; TC_COMM_CUS).  TC_BENCH_GATHER=torch: torch.distributed's batch.
+        native = os.environ.get("TC_BENCH_GATHER", "native") == "native" and not rehearsal
+        if native:
+            try:
+                gatherer = NativeGather(ctx, pcap, dev, depth=2)
+                ok = 1
+            except Exception as e:   # noqa: BLE001
+                sys.stderr.write("rank %d: native gather unavailable (%s): torch.distributed instead\n" % (rank, e))
+                ok = 0
+            flag = torch.tensor([ok], dtype=torch.int32, device=dev)
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN)     # all ranks take the same path
+            if int(flag.item()) == 0:
+                if gatherer is not None:
+                    gatherer.close()
+                gatherer, native = None, False
+        if gatherer is None:
+            gatherer = BlockGather(pcap, xdev, depth=2)
         gatherer.prime()                  # communicator / peer connection set-up, not part of any step
         packed = [torch.empty(pcap, dtype=torch.uint8, device=dev) for _ in range(2)]
     blk = Block()
@@ -383,7 +399,8 @@ def main():
             assert torch.equal(d_back, d_chk), "record of rank %d does not decode to its text" % r
         gathered = {"ranks_in_communicator": dist.get_world_size(),
                     "backend": "tc_comm (RCCL behind the C ABI)" if isinstance(gatherer, NativeGather) else dist.get_backend(),
-                    "containers_verified": world, "container_bytes": [int(h[0]) for h, _ in last]}
+                    "containers_verified": world, "container_bytes": [int(h[0]) for h, _ in last],
+                    "comm_cus": getattr(gatherer, "comm_cus", 0)}
         del d_chk, d_back
     if rank == 0:
         st = ctx.stats()

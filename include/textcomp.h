@@ -313,6 +313,11 @@ void tc_comm_destroy(tc_comm *comm);
 int tc_comm_gather(tc_comm *comm, int root, const uint8_t *d_container, uint64_t bytes, uint8_t *d_recv,
                    uint64_t slot_bytes, uint64_t *sizes);
 int tc_comm_wait(tc_comm *comm);
+/* The exchange overlaps the next record's encode; to keep RCCL's workgroups from holding back the encode's
+ * partition levels (which want whole CUs), the communicator's stream is restricted to TC_COMM_CUS compute units
+ * (environment; default 8 when world > 1, one per XCD; 0: unrestricted) and the context's partition levels
+ * split their work over the others.  Returns how many CUs this communicator is restricted to (0: none). */
+int tc_comm_reserved_cus(const tc_comm *comm);
 int tc_comm_broadcast(tc_comm *comm, int root, uint8_t *d_buf, uint64_t bytes);
 
 /* ---- synthetic inputs, generated on the device ------------- */

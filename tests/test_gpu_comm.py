@@ -84,3 +84,37 @@ assert rc == -7 and rc2 == -7 and "librccl not found" in msg, (rc, rc2, msg)
     env["TC_RCCL_LIB"] = "/nonexistent/librccl-none.so"
     p = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300)
     assert p.returncode == 0, p.stdout + p.stderr
+
+
+def test_comm_stream_on_reserved_cus(monkeypatch):
+    """TC_COMM_CUS: the communicator's stream is restricted to a few compute units and the context's partition
+    levels split their work over the others (what every rank of the N > 1 step runs with).  One rank here: the
+    restricted stream carries the size all-gather, the root copy and the broadcast; the record encoded with the
+    reduced partition grid (the MSD round 0 forced at this size) gives the container of the plain context."""
+    import torch
+    import textcomp
+    from textcomp.gather import NativeGather
+    n = (1 << 21) + 12345
+    t = O.gen_acgtn(0xC501, n)
+    d_text = torch.from_numpy(t).cuda()
+    pcap = n + n // 4 + 4096
+    monkeypatch.setenv("TC_SA_MSD_MIN_LOG2", "10")
+    with textcomp.Context(0) as plain:
+        ref = torch.zeros(pcap, dtype=torch.uint8, device="cuda")
+        nref = plain.encode_container_dev(d_text.data_ptr(), n, ref.data_ptr(), pcap)
+        assert plain.stats().msd_path == 1
+    monkeypatch.setenv("TC_COMM_CUS", "8")
+    ctx = textcomp.Context(0)
+    g = NativeGather(ctx, pcap, torch.device("cuda", 0), depth=2)
+    assert g.comm_cus == 8
+    buf = torch.zeros(pcap, dtype=torch.uint8, device="cuda")
+    for step in range(2):
+        g.acquire()
+        nb = ctx.encode_container_dev(d_text.data_ptr(), n, buf.data_ptr(), pcap)
+        assert ctx.stats().msd_path == 1
+        g.submit([nb], buf)
+    g.drain()
+    (hdr, got), = g.completed[-1]
+    assert hdr[0] == nref and torch.equal(got, ref[:nref])
+    g.close()
+    ctx.close()

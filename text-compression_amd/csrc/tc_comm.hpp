@@ -87,6 +87,7 @@ struct tc_comm {
     u64 *d_words = nullptr;         // [1 + world] my size, all sizes
     u64 *h_words = nullptr;         // pinned mirror
     bool inflight = false;
+    int cus = 0;                    // compute units the exchange is restricted to (0: any)
 };
 
 #define TC_NCCL(c, expr)                                                                         \

@@ -39,6 +39,7 @@ struct tc_ctx {
     hipEvent_t pev[2 * 16] = {};  // per-pass event pairs (profile mode)
     int profile = 0;
     int num_cus = 0;
+    int reserved_cus = 0;  // CUs left to a tc_comm's stream: the partition levels split their work over the others
     int safe_tickets = 0;  // set after a look-back spin overflow: single ticket counter
     u32 ticket_fallbacks = 0;  // how often that happened (reported in tc_stats)
     int pev_used = 0;

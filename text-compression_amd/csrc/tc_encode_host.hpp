@@ -444,6 +444,8 @@ static void sa_run(tc_ctx *ctx, SaBuffers &b, const u8 *d_text, u64 n, u32 *d_sa
                 td.text = d_text; td.n = (u32)n; td.B = cfg.B; td.s = cfg.s;
                 memcpy(td.lut, cfg.lut, sizeof td.lut);
                 u32 G = b.msd_grid < (u32)ctx->num_cus * MSD_BPC ? b.msd_grid : (u32)ctx->num_cus * MSD_BPC;
+                if (ctx->reserved_cus > 0 && G > (u32)(ctx->num_cus - ctx->reserved_cus) * MSD_BPC)
+                    G = (u32)(ctx->num_cus - ctx->reserved_cus) * MSD_BPC;   // (CUs left to the exchange: tc_comm_create)
                 if (env_int("TC_MSD_GRID", 0) > 0 && (u32)env_int("TC_MSD_GRID", 0) < G) G = (u32)env_int("TC_MSD_GRID", 0);
                 u32 *maxchild = reinterpret_cast<u32 *>(ctx->d_scalars + 15);
                 msd_root_kernel<<<1, 1, 0, s>>>(b.msd_pstart[0], b.msd_pcnt[0], (u32)N, maxchild);

@@ -1952,7 +1952,27 @@ int tc_comm_create(tc_ctx *ctx, const uint8_t *id, int rank, int world, tc_comm 
     tc_comm *c = new tc_comm();
     c->ctx = ctx; c->api = api; c->rank = rank; c->world = world;
     try {
-        TC_HIP(ctx, hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+        // The exchange overlaps the next record's encode, and the partition levels of that encode want whole CUs
+        // (one 1024-thread workgroup with 153 KB of LDS each, a static split of the work over the workgroups): an
+        // RCCL workgroup resident on a CU for the ~10 ms of a transfer would hold one partition workgroup back and
+        // with it the whole level.  So the two are kept apart by construction: the communicator's stream is
+        // restricted to the last TC_COMM_CUS compute units of the CU numbering (default 8 when there is a peer --
+        // the mask bits are dealt round-robin over the XCDs, so that is one CU per XCD; 0: no restriction), and
+        // the partition levels of this context split their work over the other CUs (tc_ctx.reserved_cus).
+        int cus = env_int("TC_COMM_CUS", world > 1 ? 8 : 0);
+        if (cus < 0 || cus > ctx->num_cus / 4) cus = 0;
+        if (cus > 0) {
+            std::vector<uint32_t> mask((size_t)(ctx->num_cus + 31) / 32, 0u);
+            for (int cu = ctx->num_cus - cus; cu < ctx->num_cus; cu++) mask[(size_t)cu / 32] |= 1u << (cu % 32);
+            if (hipExtStreamCreateWithCUMask(&c->stream, (uint32_t)mask.size(), mask.data()) != hipSuccess) {
+                (void)hipGetLastError();
+                c->stream = nullptr;
+                cus = 0;
+            }
+        }
+        if (!c->stream) TC_HIP(ctx, hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+        c->cus = cus;
+        ctx->reserved_cus = cus;
         TC_HIP(ctx, hipMalloc((void **)&c->d_words, (size_t)(1 + world) * sizeof(u64)));
         TC_HIP(ctx, hipHostMalloc((void **)&c->h_words, (size_t)(1 + world) * sizeof(u64), hipHostMallocDefault));
         RcclId u;
@@ -1966,7 +1986,12 @@ int tc_comm_create(tc_ctx *ctx, const uint8_t *id, int rank, int world, tc_comm 
     TC_API_END(ctx)
 }
 
-void tc_comm_destroy(tc_comm *comm) { comm_release(comm); }
+void tc_comm_destroy(tc_comm *comm) {
+    if (comm && comm->ctx) comm->ctx->reserved_cus = 0;
+    comm_release(comm);
+}
+
+int tc_comm_reserved_cus(const tc_comm *comm) { return comm ? comm->cus : 0; }
 
 int tc_comm_wait(tc_comm *c) {
     if (!c) return TC_ERR_ARG;

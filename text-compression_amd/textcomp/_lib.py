@@ -100,6 +100,7 @@ SYMBOLS = [
     ("tc_comm_destroy", None, [_P]),
     ("tc_comm_gather", _INT, [_P, _INT, _P, _U64, _P, _U64, _PU64]),
     ("tc_comm_wait", _INT, [_P]),
+    ("tc_comm_reserved_cus", _INT, [_P]),
     ("tc_comm_broadcast", _INT, [_P, _INT, _P, _U64]),
     ("tc_fm_export_bound", _U64, [_P, _INT]),
     ("tc_fm_export_dev", _INT, [_P, _P, _INT, _P, _PU64]),

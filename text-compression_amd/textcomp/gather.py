@@ -147,15 +147,21 @@ class NativeGather:
         self.rank = dist.get_rank(group) if dist.is_initialized() else 0
         self.device, self.cap, self.depth = device, (int(cap_bytes) + 255) & ~255, depth
         idbuf = (C.c_uint8 * _lib.TC_COMM_ID_BYTES)()
-        if self.rank == 0:
-            ctx._check(self.lib.tc_comm_unique_id(ctx.handle, idbuf))
+        rc0 = self.lib.tc_comm_unique_id(ctx.handle, idbuf) if self.rank == 0 else 0
         if self.world > 1:
-            box = [bytes(idbuf)]
+            # (a failure on rank 0 -- no RCCL to bind -- travels in place of the id: nobody is left waiting)
+            box = [bytes(idbuf) if rc0 == 0 else None]
             dist.broadcast_object_list(box, src=0, group=group)
+            if box[0] is None:
+                raise RuntimeError("tc_comm_unique_id failed on rank 0: %s" % self.lib.tc_last_error(ctx.handle).decode()
+                                   if self.rank == 0 else "tc_comm_unique_id failed on rank 0")
             idbuf = (C.c_uint8 * _lib.TC_COMM_ID_BYTES).from_buffer_copy(box[0])
+        else:
+            ctx._check(rc0)
         h = C.c_void_p()
         ctx._check(self.lib.tc_comm_create(ctx.handle, idbuf, self.rank, self.world, C.byref(h)))
         self._h = h
+        self.comm_cus = int(self.lib.tc_comm_reserved_cus(h))
         self._recv = ([torch.empty(self.world * self.cap, dtype=torch.uint8, device=device) for _ in range(depth)]
                       if self.rank == 0 else [None] * depth)
         self._pending = None    # (slot, sizes)
