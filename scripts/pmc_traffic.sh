@@ -37,5 +37,11 @@ for name,pat in (("radix_pass_kernel","radix_pass_kernel<false"),("msd_partition
                 if w > 0.5*big: fe.append(2*f); wr.append(w)
     if wr and sum(wr) / len(wr) > 1e9:   # (full-length launches only: the refinement's small sorts reuse the kernel)
         res[name+"_bytes_per_launch"]=(sum(fe)+sum(wr))/len(wr); res[name+"_launches"]=len(wr)
+# FM count (configs[3] leg of the bench): raw FETCH_SIZE of the largest launch -- 64-byte requests, so NOT doubled
+for k,d in tot.items():
+    if "fm_count_kernel" in k and d["FETCH_SIZE"]:
+        res["fm_count_kernel_fetch_bytes_per_launch"]=max(d["FETCH_SIZE"]); res["fm_commit"]=res["commit"]
+    if "rle_nib_kernel" in k and d["WRITE_SIZE"]:
+        res["rle_nib_kernel_bytes_per_launch"]=2*max(d["FETCH_SIZE"]+[0])+max(d["WRITE_SIZE"])
 json.dump(res, open("gpurun_out/traffic_latest.json","w"), indent=1)
 PY
