@@ -22,7 +22,7 @@
 struct TcWs {
     char *p = nullptr;
     size_t cap = 0, mapped = 0;
-    std::vector<hipMemGenericAllocationHandle_t> chunks;
+    std::vector<hipMemGenericAllocationHandle_t> chunks;   // (mapped / chunks.size() bytes each)
 };
 static TcWs ws_detach(tc_ctx *ctx) {
     TcWs w;
@@ -39,9 +39,14 @@ static void ws_attach(tc_ctx *ctx, TcWs &w) {
 static void ws_free(TcWs &w) {
     if (!w.p) return;
     if (!w.chunks.empty()) {
-        (void)hipMemUnmap(w.p, w.mapped);
-        for (auto h : w.chunks) (void)hipMemRelease(h);
-        (void)hipMemAddressFree(w.p, w.mapped);
+        // every mapping is undone on its own (hipMemUnmap takes exactly one mapped range), then its memory
+        // released; the address range goes last
+        const size_t chunk = w.mapped / w.chunks.size();
+        for (size_t i = 0; i < w.chunks.size(); i++) {
+            if (hipMemUnmap(w.p + i * chunk, chunk) != hipSuccess) (void)hipGetLastError();
+            if (hipMemRelease(w.chunks[i]) != hipSuccess) (void)hipGetLastError();
+        }
+        if (hipMemAddressFree(w.p, w.mapped) != hipSuccess) (void)hipGetLastError();
     } else {
         (void)hipFree(w.p);
     }
@@ -81,10 +86,13 @@ static bool ws_alloc_vmm(tc_ctx *ctx, size_t want, int chunk_log2, TcWs &w) {
     }
     if (!ok) {
         (void)hipGetLastError();
-        if (done) (void)hipMemUnmap(va, done);
-        for (auto h : w.chunks) (void)hipMemRelease(h);
+        for (size_t i = 0; i < w.chunks.size(); i++) {
+            (void)hipMemUnmap((char *)va + i * chunk, chunk);
+            (void)hipMemRelease(w.chunks[i]);
+        }
         w.chunks.clear();
         (void)hipMemAddressFree(va, total);
+        (void)hipGetLastError();
         return false;
     }
     w.p = (char *)va; w.cap = total; w.mapped = total;
@@ -503,6 +511,13 @@ int tc_ctx_place_workspace(tc_ctx *ctx, const uint8_t *d_text, uint64_t n, tc_bl
     try {
         t.push_back(timed());          // placement 0: the workspace the context has (sized by this very encode)
         const size_t cap0 = ctx->ws_cap;
+        // A workspace of mapped chunks (the default for long records) is not placed again: it lands in the fast
+        // mode by itself (profiles/r03_ws_recipes.txt), and one bench run whose search created and released
+        // several 80 GB chunked workspaces in a row ended in a GPU memory fault that no run with a single one
+        // ever showed -- cause not established (hipMemUnmap over all mappings at once returns success, so it was
+        // not the release as first suspected; scripts/dbg/vmm_unmap_probe.cpp), so the search stays with
+        // hipMalloc blocks (TC_WS_VMM=0), where round 2 ran it hundreds of times.
+        if (!ctx->ws_chunks.empty()) tries = 1;
         for (int k = 1; k < tries; k++) {
             double worst = 0;
             for (double v : t) worst = v > worst ? v : worst;
