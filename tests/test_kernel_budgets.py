@@ -21,6 +21,9 @@ BUDGETS = {
     "mtf_nib_apply_kernelI6BwtAccLb1EhE": (64, 0, 4),
     "mtf_ts_apply_kernelI6BwtAccLi5EE": (64, 0, 8),
     "radix_pass_kernelILb0ELb0ELi1ELb0ELb0EE": (160, 0, 3),
+    "14rle_nib_kernel10RleNibArgs": (128, 0, 4),          # round 3: the fused RLE -> wire-format kernel (2 x 512 threads per CU)
+    "15pack_nib_kernel11PackNibArgs": (96, 0, 5),
+    "fm_count_kernelILb1EE": (64, 0, 8),                   # round 3: two symbols per lookup
 }
 
 

@@ -199,7 +199,18 @@ class NativeGather:
         self._pending = (slot, list(sizes))
 
     def prime(self):
-        pass                # tc_comm_create has already built the communicator
+        """one small exchange, completed: RCCL builds its peer-to-peer connections on first use, which must not
+        happen inside a timed step"""
+        if self.world == 1:
+            return
+        C = self._C
+        tiny = torch.zeros(256, dtype=torch.uint8, device=self.device)
+        torch.cuda.synchronize(self.device)     # (the library posts on its own streams, not torch's)
+        sizes = (C.c_uint64 * self.world)()
+        recv = self._recv[0]
+        self.ctx._check(self.lib.tc_comm_gather(self._h, 0, C.c_void_p(tiny.data_ptr()), 256,
+                                                C.c_void_p(recv.data_ptr()) if recv is not None else None, self.cap, sizes))
+        self.ctx._check(self.lib.tc_comm_wait(self._h))
 
     def drain(self):
         self._finish()
