@@ -62,6 +62,7 @@ for it in range(cases):
                 d_t = torch.from_numpy(np.frombuffer(tb, np.uint8).copy()).cuda()
                 bound = int(ctx.lib.tc_container_bound(n + 2, 257))
                 d_o = torch.full((bound + 16,), 0x5A, dtype=torch.uint8, device="cuda")
+                torch.cuda.synchronize()     # (the library works on its own stream)
                 used = ctx.encode_container_dev(d_t.data_ptr(), n, d_o.data_ptr(), bound)
                 assert d_o[:used].cpu().numpy().tobytes() == blob, "fused container"
             bs = int(rng.integers(1, n + 2))

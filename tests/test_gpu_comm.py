@@ -101,6 +101,7 @@ def test_comm_stream_on_reserved_cus(monkeypatch):
     monkeypatch.setenv("TC_SA_MSD_MIN_LOG2", "10")
     with textcomp.Context(0) as plain:
         ref = torch.zeros(pcap, dtype=torch.uint8, device="cuda")
+        torch.cuda.synchronize()
         nref = plain.encode_container_dev(d_text.data_ptr(), n, ref.data_ptr(), pcap)
         assert plain.stats().msd_path == 1
     monkeypatch.setenv("TC_COMM_CUS", "8")
@@ -108,6 +109,7 @@ def test_comm_stream_on_reserved_cus(monkeypatch):
     g = NativeGather(ctx, pcap, torch.device("cuda", 0), depth=2)
     assert g.comm_cus == 8
     buf = torch.zeros(pcap, dtype=torch.uint8, device="cuda")
+    torch.cuda.synchronize()
     for step in range(2):
         g.acquire()
         nb = ctx.encode_container_dev(d_text.data_ptr(), n, buf.data_ptr(), pcap)

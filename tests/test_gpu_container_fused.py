@@ -56,6 +56,8 @@ def _both_ways(ctx, text):
     d_text = torch.from_numpy(np.ascontiguousarray(text)).cuda() if n else torch.zeros(16, dtype=torch.uint8, device="cuda")
     bound = int(lib.tc_container_bound(n + 2, 257))
     a = torch.full((bound + 64,), 0xAB, dtype=torch.uint8, device="cuda")     # (dirty buffers: the call must not rely on zeros)
+    b = torch.full((bound + 64,), 0xCD, dtype=torch.uint8, device="cuda")
+    torch.cuda.synchronize()      # the library works on its own stream: torch's fills must have landed first
     used_a = ctx.encode_container_dev(d_text.data_ptr(), n, a.data_ptr(), bound)
     cap = n + 2
     d_c = torch.empty(cap, dtype=torch.int32, device="cuda")
@@ -63,7 +65,6 @@ def _both_ways(ctx, text):
     blk = Block()
     blk.nruns, blk.run_count, blk.run_value = cap, d_c.data_ptr(), d_v.data_ptr()
     assert lib.tc_encode_dev(ctx.handle, C.c_void_p(d_text.data_ptr()), n, C.byref(blk)) == 0, lib.tc_last_error(ctx.handle)
-    b = torch.full((bound + 64,), 0xCD, dtype=torch.uint8, device="cuda")
     used_b = C.c_uint64(bound)
     assert lib.tc_block_to_container_dev(ctx.handle, C.byref(blk), C.c_void_p(b.data_ptr()), C.byref(used_b)) == 0
     return a[:used_a].cpu().numpy().tobytes(), b[:used_b.value].cpu().numpy().tobytes(), a, used_a
@@ -113,11 +114,12 @@ def test_fused_container_is_the_two_step_container_and_the_oracles(ctx, name):
     k = int(hruns)
     o_c = torch.zeros(k + 1, dtype=torch.int32, device="cuda")
     o_v = torch.zeros(k + 1, dtype=torch.int16, device="cuda")
+    d_out = torch.zeros(max(n, 1), dtype=torch.uint8, device="cuda")
+    torch.cuda.synchronize()
     out = Block()
     out.nruns, out.run_count, out.run_value = k, o_c.data_ptr(), o_v.data_ptr()
     assert ctx.lib.tc_container_to_block_dev(ctx.handle, C.c_void_p(d_a.data_ptr()), used, C.byref(out)) == 0, ctx.lib.tc_last_error(ctx.handle)
     assert np.array_equal(o_c[:k].cpu().numpy().astype(np.int64), counts)
-    d_out = torch.zeros(max(n, 1), dtype=torch.uint8, device="cuda")
     assert ctx.lib.tc_decode_dev(ctx.handle, C.byref(out), C.c_void_p(d_out.data_ptr())) == 0
     assert d_out[:n].cpu().numpy().tobytes() == text.tobytes()
 
@@ -125,15 +127,18 @@ def test_fused_container_is_the_two_step_container_and_the_oracles(ctx, name):
 def test_fused_container_empty_and_capacity(ctx):
     import torch
     buf = torch.zeros(4096, dtype=torch.uint8, device="cuda")
+    torch.cuda.synchronize()
     assert ctx.encode_container_dev(0, 0, buf.data_ptr(), 4096) == 640
     assert buf[:7].cpu().numpy().tobytes() == b"TCBLK01"
     t = torch.from_numpy(O.gen_acgtn(1, 200000)).cuda()
     used = C.c_uint64(640 + 1000)         # far too small: TC_ERR_CAPACITY and the bytes needed
     small = torch.zeros(640 + 1024, dtype=torch.uint8, device="cuda")
+    torch.cuda.synchronize()
     rc = ctx.lib.tc_encode_container_dev(ctx.handle, C.c_void_p(t.data_ptr()), 200000, C.c_void_p(small.data_ptr()), C.byref(used))
     assert rc == -2 and used.value > 640 + 60000
     need = used.value
     big = torch.zeros(need + 64, dtype=torch.uint8, device="cuda")
+    torch.cuda.synchronize()
     assert ctx.encode_container_dev(t.data_ptr(), 200000, big.data_ptr(), need) == need
     used = C.c_uint64(100)
     assert ctx.lib.tc_encode_container_dev(ctx.handle, C.c_void_p(t.data_ptr()), 200000, C.c_void_p(small.data_ptr()), C.byref(used)) == -2

@@ -10,6 +10,7 @@
 #include "tc_mtf.hpp"
 #include "tc_radix_host.hpp"
 #include "tc_rle.hpp"
+#include "tc_pack.hpp"
 #include "tc_sa.hpp"
 #include "tc_msd.hpp"
 
@@ -940,7 +941,9 @@ static void mtf_encode_device(tc_ctx *ctx, Arena &A, Acc acc, u64 N, const u32 *
         if (env_int("TC_MTF_FASTIN", 1) != 0) {
             u32 *flag = reinterpret_cast<u32 *>(ctx->d_scalars + 15);
             tc_memset_async(ctx, flag, 0, sizeof(u64));
-            if (d_idx8) mtf_nib_apply_kernel<Acc, true, u8><<<tiles, MTF_NT, 0, s>>>(acc, N, lut, t_perm, d_idx8, al.sigma, flag);
+            if (d_idx8 && al.sigma <= 8 && env_int("TC_MTF_SMALL", 1) != 0)   // (a DNA record: the list in 32 bits)
+                mtf_nib_apply_kernel<Acc, true, u8, true><<<tiles, MTF_NT, 0, s>>>(acc, N, lut, t_perm, d_idx8, al.sigma, flag);
+            else if (d_idx8) mtf_nib_apply_kernel<Acc, true, u8><<<tiles, MTF_NT, 0, s>>>(acc, N, lut, t_perm, d_idx8, al.sigma, flag);
             else mtf_nib_apply_kernel<Acc, true><<<tiles, MTF_NT, 0, s>>>(acc, N, lut, t_perm, d_idx, al.sigma, flag);
             TC_LAUNCH_CHECK(ctx);
             mtf_nib_final_kernel<Acc><<<1, 64, 0, s>>>(acc, N, lut, al.sigma, t_perm + tiles, flag);
@@ -1059,9 +1062,29 @@ static void rle_encode_device(tc_ctx *ctx, Arena &A, Acc acc, u64 N, u32 *d_coun
                               u64 cap, u64 *total, bool dry) {
     const bool idx_stream = std::is_same<Acc, U16Acc>::value || std::is_same<Acc, U8Acc>::value;
     const u32 tiles = tc_cdiv(N, idx_stream ? RLE16_TILE : RLE_TILE);
-    u64 *status = A.get<u64>(2 * (size_t)tiles + 4);
+    const u32 btiles = tc_cdiv(N, RN_TILE);                     // tiles of the blocked kernel (byte-wide index stream)
+    const u32 stiles = tiles > btiles ? tiles : btiles;
+    u64 *status = A.get<u64>(2 * (size_t)stiles + 4);
     if (dry) return;
-    tc_memset_async(ctx, status, 0, (2 * (size_t)tiles + 4) * sizeof(u64));
+    tc_memset_async(ctx, status, 0, (2 * (size_t)stiles + 4) * sizeof(u64));
+    if constexpr (std::is_same<Acc, U8Acc>::value) {
+        // byte-wide index stream (the fused encode): the blocked kernel (tc_pack.hpp); TC_RLE_BLOCKED=0: the striped one
+        if ((((uintptr_t)acc.v) & 15) == 0 && env_int("TC_RLE_BLOCKED", 1) != 0) {
+            RleBlkArgs b;
+            b.src = acc.v; b.N = N; b.counts = d_counts; b.vals = reinterpret_cast<u16 *>(d_syms); b.cap = cap;
+            b.status_a = status; b.status_b = status + btiles;
+            b.ticket = reinterpret_cast<u32 *>(status + 2 * (size_t)btiles);
+            b.scalars = ctx->d_scalars; b.err = ctx->d_err; b.ntiles = btiles;
+            u32 grid = tc_persistent_grid_for(ctx, rle_blk_kernel, RN_NT, 8);
+            if (grid > btiles) grid = btiles;
+            rle_blk_kernel<<<grid, RN_NT, 0, ctx->stream>>>(b);
+            TC_LAUNCH_CHECK(ctx);
+            tc_d2h(ctx, &ctx->h_scalars[2], ctx->d_scalars + 2, sizeof(u64));
+            TC_HIP(ctx, hipStreamSynchronize(ctx->stream));
+            *total = ctx->h_scalars[2];
+            return;
+        }
+    }
     RleArgs a;
     a.N = N; a.counts = d_counts; a.syms = d_syms; a.cap = cap;
     a.status_pair = status; a.status_sum = status + tiles;

@@ -141,6 +141,18 @@ __device__ __forceinline__ u64 nib_front(u64 list, u32 pos, u32 c) {
     u64 upto = (2ull << (4 * pos + 3)) - 1ull;     // nibbles [0, pos]
     return (list & ~upto) | ((list & lowmask) << 4) | (u64)c;
 }
+// The same two steps for an alphabet of at most 8 codes (a DNA record: 5 letters + the sentinel): the list is the low
+// 8 nibbles, ONE 32-bit register -- half the instructions of the 64-bit forms (no 64-bit shifts, subtracts, ctz).
+__device__ __forceinline__ u32 nib8_find(u32 list, u32 c) {
+    const u32 x = list ^ (0x11111111u * c);
+    const u32 t = (x - 0x11111111u) & ~x & 0x88888888u;
+    return (u32)__builtin_ctz(t) >> 2;
+}
+__device__ __forceinline__ u32 nib8_front(u32 list, u32 pos, u32 c) {
+    const u32 lowmask = (1u << (4 * pos)) - 1u;    // nibbles [0, pos)
+    const u32 upto = (lowmask << 4) | 15u;         // nibbles [0, pos]
+    return (list & ~upto) | ((list & lowmask) << 4) | c;
+}
 // a then b
 __device__ __forceinline__ NibSumm nib_combine(NibSumm a, NibSumm b) {
     int d = __popc(b.mask);
@@ -349,7 +361,8 @@ __global__ __launch_bounds__(MTF_NT) void mtf_nib_scan_kernel(u64 *t_perm, u32 *
 
 // FASTIN: the tile's incoming list is recovered in-kernel by nib_list_before (no summary /
 // scan launches); `flag` is raised when that fails and the host reruns the 3-kernel path.
-template <class Acc, bool FASTIN, class OT = u16>
+// SMALL: sigma <= 8 -- the pass over the chunk keeps its list in 32 bits (nib8_find / nib8_front)
+template <class Acc, bool FASTIN, class OT = u16, bool SMALL = false>
 __global__ __launch_bounds__(MTF_NT) void mtf_nib_apply_kernel(Acc acc, u64 N,
                                                                 Lut8 lut,
                                                                 const u64 *__restrict__ t_perm,
@@ -385,6 +398,32 @@ __global__ __launch_bounds__(MTF_NT) void mtf_nib_apply_kernel(Acc acc, u64 N,
     NibSumm mine{NIB_IDENT, 0u};
     u64 ev_code = 0, ev_pos0 = 0, ev_pos1 = 0;
     u32 nev = 0;
+    if (SMALL) {
+        u32 lst = (u32)NIB_IDENT, seen = 0, evc = 0;   // list, codes met, first occurrences (code per nibble: <= 8)
+#pragma unroll 4
+        for (int q = 0; q < MTF_CH / 4; q++) {
+            u32 wv = cw[q], ov = 0;
+#pragma unroll
+            for (int b = 0; b < 4; b++) {
+                const u32 c = (wv >> (8 * b)) & 0xff;
+                if (c != 0xFF) {
+                    const u32 pos = nib8_find(lst, c);
+                    lst = nib8_front(lst, pos, c);
+                    ov |= pos << (8 * b);
+                    if (!((seen >> c) & 1u)) {
+                        seen |= 1u << c;
+                        evc |= c << (4 * nev);
+                        ev_pos0 |= (u64)(4 * q + b) << (8 * nev);
+                        nev++;
+                    }
+                }
+            }
+            cw[q] = ov;
+        }
+        mine.perm = (NIB_IDENT & 0xFFFFFFFF00000000ull) | (u64)lst;
+        mine.mask = seen;
+        ev_code = evc;
+    } else {
 #pragma unroll 4
     for (int q = 0; q < MTF_CH / 4; q++) {
         u32 wv = cw[q], ov = 0;
@@ -406,6 +445,7 @@ __global__ __launch_bounds__(MTF_NT) void mtf_nib_apply_kernel(Acc acc, u64 N,
             }
         }
         cw[q] = ov;  // ranks overwrite the codes in place
+    }
     }
     NibSumm agg;
     NibSumm exc = nib_block_excl(mine, s_w, &agg);

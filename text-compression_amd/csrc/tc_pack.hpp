@@ -236,7 +236,9 @@ __global__ __launch_bounds__(PK_NT) void pack_nib_kernel(PackNibArgs a) {
 //   chunk are popcounts, their prefix over the tile one packed scan, their prefix over the tiles look-back B
 //   (sum), and the nibble strings are built -- position by position, four positions to a 32-bit group -- when
 //   their place in the stream is already known.
+#ifndef RN_NT
 #define RN_NT 512
+#endif
 #define RN_SUB 4
 #define RN_SUBSZ (RN_NT * 16)             // 8192 positions
 #define RN_TILE (RN_SUB * RN_SUBSZ)       // 32768 positions
@@ -273,6 +275,25 @@ __device__ __forceinline__ u32 seg_incl_scan(u32 v) {
         if ((int)lane_id() >= d) v = (u32)Op::apply(v, t);
     }
     return v;
+}
+
+// The last run end before a tile (1 + its position; 0: none), for wave 0 of the tile's workgroup.  It almost always
+// lies within the 64 positions in front of the tile: those are read directly -- no dependence on the predecessor
+// tile at all -- and only a run of 64 or more across the tile's edge falls back to the look-back chain.  Either way
+// the tile's own inclusive value (its last end, else the incoming one) is published for tiles that do chain.
+__device__ __forceinline__ u32 rn_last_end_before(const u8 *src, u64 tbase, u32 tile, u32 agg, u64 *status_a, u32 *err) {
+    if (tile == 0) {
+        if (lane_id() == 0) lb_store(&status_a[0], LB_FLAG_INC | (u64)agg);
+        return 0u;
+    }
+    const u64 p = tbase - 64 + lane_id();          // (tbase >= RN_TILE >= 64; p + 1 <= tbase < N)
+    const u64 m = __ballot(src[p] != src[p + 1]);
+    if (m) {
+        const u32 tin = (u32)(tbase - 64) + (u32)(63 - __builtin_clzll(m)) + 1u;
+        if (lane_id() == 0) lb_store(&status_a[tile], LB_FLAG_INC | (u64)(agg ? agg : tin));
+        return tin;
+    }
+    return (u32)lb_exclusive<OpMax>(status_a, tile, agg, err);
 }
 
 __global__ __launch_bounds__(RN_NT, 2) void rle_nib_kernel(RleNibArgs a) {
@@ -331,7 +352,7 @@ __global__ __launch_bounds__(RN_NT, 2) void rle_nib_kernel(RleNibArgs a) {
             const u32 agg = __shfl(inc, RN_NSEG - 1, 64);
             u32 ex = __shfl_up(inc, 1, 64);
             if (lane == 0) ex = 0;
-            const u32 tin = (u32)lb_exclusive<OpMax>(a.status_a, tile, agg, a.err);
+            const u32 tin = rn_last_end_before(a.src, tbase, tile, agg, a.status_a, a.err);
             if (lane < RN_NSEG) s_carry[lane] = ex > tin ? ex : tin;
         }
         __syncthreads();
@@ -451,6 +472,140 @@ __global__ __launch_bounds__(RN_NT, 2) void rle_nib_kernel(RleNibArgs a) {
         }
         __syncthreads();
         nib_image_out<RN_NT>(img, q0, tn, tile + 1 == a.ntiles, a.out, a.cap_units);
+    }
+}
+
+// ---- the same blocked formulation writing the run ARRAYS (tc_block: run_count u32[], run_value u16[]) -------------
+// seqToRLE of a byte-wide index stream (the fused encode of an alphabet of <= 256 symbols), replacing the striped
+// rle_encode_idx_kernel<u8> on that path: run ends, previous ends and the two look-backs exactly as in rle_nib_kernel;
+// a tile's runs are staged in LDS as one byte each for the length (255 = "255 or more": the owner stores those
+// lengths itself) and for the value, and leave as coalesced 4-byte / 2-byte stores.
+struct RleBlkArgs {
+    const u8 *src;   // 16-byte aligned; readable up to the next 16-byte boundary behind N
+    u64 N;
+    u32 *counts;
+    u16 *vals;
+    u64 cap;
+    u64 *status_a, *status_b;
+    u32 *ticket;
+    u64 *scalars;    // [2] total runs
+    u32 *err;
+    u32 ntiles;
+};
+
+__global__ __launch_bounds__(RN_NT, 2) void rle_blk_kernel(RleBlkArgs a) {
+    constexpr int NW = RN_NT / 64;
+    __shared__ u8 s_c8[RN_TILE], s_v8[RN_TILE];
+    __shared__ u32 s_last[RN_NSEG], s_carry[RN_NSEG], s_sum[RN_NSEG];
+    __shared__ u32 s_tile;
+    __shared__ u64 s_pref;
+    const int tid = threadIdx.x, lane = lane_id(), w = tid >> 6;
+    const u64 N = a.N;
+    for (;;) {
+        __syncthreads();   // the staged runs, s_tile and s_pref of the previous tile have been read by everybody
+        if (tid == 0) s_tile = atomicAdd(a.ticket, 1u);
+        __syncthreads();
+        const u32 tile = s_tile;
+        if (tile >= a.ntiles) break;
+        const u64 tbase = (u64)tile * RN_TILE;
+        const bool edge = tbase + RN_TILE >= N;
+        uint4 x[RN_SUB];
+        u32 E[RN_SUB], pv[RN_SUB];
+        u32 hasmask = 0;
+#pragma unroll
+        for (int s = 0; s < RN_SUB; s++) {
+            const u64 p0 = tbase + (u64)s * RN_SUBSZ + (u64)tid * 16;
+            uint4 q = make_uint4(0, 0, 0, 0);
+            if (!edge || p0 < N) q = *reinterpret_cast<const uint4 *>(a.src + p0);
+            u32 nx = __shfl_down(q.x, 1, 64);
+            if (lane == 63) nx = (!edge || p0 + 16 < N) ? (u32)a.src[p0 + 16] : 0u;
+            const u32 y0 = __builtin_amdgcn_alignbyte(q.y, q.x, 1), y1 = __builtin_amdgcn_alignbyte(q.z, q.y, 1);
+            const u32 y2 = __builtin_amdgcn_alignbyte(q.w, q.z, 1), y3 = __builtin_amdgcn_alignbyte(nx, q.w, 1);
+            u32 e = nz_bytes4(q.x ^ y0) | (nz_bytes4(q.y ^ y1) << 4) | (nz_bytes4(q.z ^ y2) << 8) | (nz_bytes4(q.w ^ y3) << 12);
+            if (edge) {
+                const u32 valid = p0 >= N ? 0u : (N - p0 >= 16 ? 0xffffu : ((1u << (u32)(N - p0)) - 1u));
+                e &= valid;
+                if (p0 < N && N - p0 <= 16) e |= 1u << (u32)(N - 1 - p0);
+            }
+            x[s] = q;
+            E[s] = e;
+            const u32 last1 = e ? (u32)p0 + 32u - (u32)__builtin_clz(e) : 0u;
+            const u64 m = __ballot(e != 0);
+            const u64 pm = m & lanemask_lt();
+            const int src = pm ? 63 - __builtin_clzll(pm) : 0;
+            pv[s] = __shfl(last1, src, 64);
+            if (pm) hasmask |= 1u << s;
+            const u32 wlast = m ? __shfl(last1, 63 - __builtin_clzll(m), 64) : 0u;
+            if (lane == 0) s_last[s * NW + w] = wlast;
+        }
+        __syncthreads();
+        if (w == 0) {
+            const u32 v = lane < RN_NSEG ? s_last[lane] : 0u;
+            const u32 inc = seg_incl_scan<OpMax>(v);
+            const u32 agg = __shfl(inc, RN_NSEG - 1, 64);
+            u32 ex = __shfl_up(inc, 1, 64);
+            if (lane == 0) ex = 0;
+            const u32 tin = rn_last_end_before(a.src, tbase, tile, agg, a.status_a, a.err);
+            if (lane < RN_NSEG) s_carry[lane] = ex > tin ? ex : tin;
+        }
+        __syncthreads();
+        u32 cnt[RN_SUB], inc[RN_SUB];
+#pragma unroll
+        for (int s = 0; s < RN_SUB; s++) {
+            cnt[s] = (u32)__popc(E[s]);
+            inc[s] = wave_incl_sum(cnt[s]);
+            if (lane == 63) s_sum[s * NW + w] = inc[s];
+        }
+        __syncthreads();
+        u32 excl[RN_SUB], truns;
+        {
+            const u32 v = lane < RN_NSEG ? s_sum[lane] : 0u;
+            const u32 sc = seg_incl_scan<OpSum>(v);
+            truns = __shfl(sc, RN_NSEG - 1, 64);
+#pragma unroll
+            for (int s = 0; s < RN_SUB; s++) {
+                const int g = s * NW + w;
+                const u32 before = g ? __shfl(sc, g - 1, 64) : 0u;
+                excl[s] = before + inc[s] - cnt[s];
+            }
+        }
+        if (w == 1) {
+            const u64 e = lb_exclusive<OpSum>(a.status_b, tile, (u64)truns, a.err);
+            if (lane == 0) {
+                s_pref = e;
+                if (tile + 1 == a.ntiles) a.scalars[2] = e + truns;
+            }
+        }
+        __syncthreads();
+        const u64 e0 = s_pref;
+#pragma unroll
+        for (int s = 0; s < RN_SUB; s++) {
+            const u32 p0 = (u32)(tbase + (u64)s * RN_SUBSZ + (u64)tid * 16);
+            const u32 xs[4] = {x[s].x, x[s].y, x[s].z, x[s].w};
+            u32 prev = ((hasmask >> s) & 1u) ? pv[s] : s_carry[s * NW + w];
+            u32 j = excl[s];
+#pragma unroll
+            for (int i = 0; i < 16; i++) {
+                if ((E[s] >> i) & 1u) {
+                    const u32 pos1 = p0 + (u32)i + 1u;
+                    const u32 c = pos1 - prev;
+                    prev = pos1;
+                    s_c8[j] = (u8)(c < 255u ? c : 255u);
+                    s_v8[j] = (u8)((xs[i >> 2] >> (8 * (i & 3))) & 0xffu);
+                    if (c >= 255u && e0 + j < a.cap) a.counts[e0 + j] = c;
+                    j++;
+                }
+            }
+        }
+        __syncthreads();
+        for (u32 i = tid; i < truns; i += RN_NT) {
+            const u64 g = e0 + i;
+            if (g < a.cap) {
+                const u32 c = s_c8[i];
+                if (c != 255u) a.counts[g] = c;
+                a.vals[g] = (u16)s_v8[i];
+            }
+        }
     }
 }
 

@@ -1250,7 +1250,7 @@ static void encode_container_device(tc_ctx *ctx, const u8 *d_text, u64 n, u8 *d_
             a.ticket = reinterpret_cast<u32 *>(status + 2 * (size_t)ntiles);
             a.totals = status + 2 * (size_t)ntiles + 8;
             a.err = ctx->d_err; a.ntiles = ntiles;
-            u32 grid = tc_persistent_grid_for(ctx, rle_nib_kernel, RN_NT, 4);
+            u32 grid = tc_persistent_grid_for(ctx, rle_nib_kernel, RN_NT, 8);
             if (grid > ntiles) grid = ntiles;
             rle_nib_kernel<<<grid, RN_NT, 0, s>>>(a);
             TC_LAUNCH_CHECK(ctx);
