@@ -62,6 +62,8 @@ def radix_launch_bytes(st, n):
     L = int(st.radix_launches)
     if L == 0:
         return 0
+    if getattr(st, "msd_keyonly", 0):      # keys only: 8 B read + 8 B written per suffix; the first level reads the text
+        return (16 * N * L - 7 * N) / L
     total = 24 * N * L
     if st.keygen_fused:
         total -= 11 * N
@@ -418,6 +420,7 @@ def main():
                     "unit": "GB/s", "frac": round(ach / 8000.0, 4), "traffic": None,
                     "launches_per_step": launches, "avg_launch_ms": round(avg_ms, 4),
                     "algorithmic_bytes_per_launch": int(per_launch), "first_pass_builds_keys": bool(st.keygen_fused),
+                    "keys_only": bool(getattr(st, "msd_keyonly", 0)),
                     "pipeline_algorithmic_bytes": A, "pipeline_bytes_per_input_byte": round(A / n, 1),
                     "pipeline_achieved_GBps": round(A / (dt / a.steps) / 1e9, 1)}
             # HBM bytes per launch from the PMC counters cannot be collected inside a timed run (rocprofv3

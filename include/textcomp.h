@@ -80,6 +80,9 @@ typedef struct tc_stats {
                                         long texts over a small alphabet); radix_launches / ms_radix then time
                                         msd_partition_kernel (first launch reads the text: 1 + 12 B per suffix,
                                         the others 12 + 12 B) */
+    uint32_t msd_keyonly;            /* 1: the MSD levels moved keys only (no suffix array was asked for: encode, BWT):
+                                        8 + 8 B per suffix per level (the first: 1 + 8) instead of 12 + 12; the suffix starts
+                                        of the tied set were found again by one pass over the text */
     uint32_t ticket_fallbacks;       /* suffix sorts of this ctx that had to be redone with the single tile-ticket
                                         counter because a look-back of the XCD-grouped ticket order ran into its
                                         spin limit (LSD passes only; 0 in a healthy run, cumulative per ctx) */

@@ -124,3 +124,49 @@ def test_msd_big_instance_keeps_long_buckets(ctx, monkeypatch):
         t[a:a + 300] = c
     _check(ctx, t, True)
     assert ctx.stats().rounds >= 3
+
+
+def test_msd_keyonly_levels_and_their_tied_set(ctx, monkeypatch):
+    """round 3: an encode asks for no suffix array, so the MSD levels move keys only and the (few) suffixes that stay
+    tied beyond the key get their suffix starts back from one pass over the text (tied_probe_kernel).  Copies of
+    22 .. 300 symbols make a few thousand ties in groups of two and more; texts of 3 and 16 symbol codes take
+    other field widths (5 and 2 symbols per field) through the rolling value."""
+    monkeypatch.setenv("TC_SA_MSD_MIN_LOG2", "10")
+    rng = np.random.default_rng(17)
+    for sigma, n in ((5, 400000), (2, 150000), (15, 200000)):
+        alpha = np.sort(rng.permutation(256)[:sigma]).astype(np.uint8)
+        t = alpha[rng.integers(0, sigma, n)]
+        for _ in range(30):
+            ln = int(rng.integers(22, 300))
+            a, b = int(rng.integers(0, n - ln)), int(rng.integers(0, n - ln))
+            t[b:b + ln] = t[a:a + ln].copy()
+        t[n - 40:] = t[1000:1040]          # a tie that reaches the end of the text
+        _check(ctx, t, True)               # (suffix array: with suffix starts; encode: keys only)
+        st = ctx.stats()                   # (of the decode's... no: of the last ENCODE, ctx.encode in _check)
+        blk = ctx.encode(t)
+        st = ctx.stats()
+        assert st.msd_path == 1 and st.msd_keyonly == 1 and st.rounds >= 2 and st.m[1] > 0
+        monkeypatch.setenv("TC_SA_MSD_KEYONLY", "0")
+        ref = ctx.encode(t)
+        assert ctx.stats().msd_keyonly == 0
+        monkeypatch.delenv("TC_SA_MSD_KEYONLY")
+        assert blk["primary"] == ref["primary"] and np.array_equal(blk["run_count"], ref["run_count"])
+        assert np.array_equal(blk["run_value"], ref["run_value"])
+
+
+def test_msd_keyonly_gives_way_when_too_many_suffixes_are_tied(ctx, monkeypatch):
+    """more ties than the table of the key-only levels is made for (2^15): the levels run once more with the suffix
+    starts moving along -- same block"""
+    monkeypatch.setenv("TC_SA_MSD_MIN_LOG2", "10")
+    monkeypatch.setenv("TC_SA_MSD", "2")       # (the collision sample would send this text to the LSD way)
+    rng = np.random.default_rng(23)
+    n = 600000
+    t = O.gen_acgtn(5, n).copy()
+    for _ in range(20):                        # 20 copies of 1000 symbols: ~40 000 tied suffixes (source and copy)
+        ln = 1000
+        a, b = int(rng.integers(0, n - ln)), int(rng.integers(0, n - ln))
+        t[b:b + ln] = t[a:a + ln].copy()
+    _check(ctx, t, True)
+    ctx.encode(t)
+    st = ctx.stats()
+    assert st.msd_path == 1 and st.msd_keyonly == 0 and (1 << 15) < st.m[1] < 75000

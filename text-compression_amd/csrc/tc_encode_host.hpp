@@ -81,6 +81,7 @@ struct SaBuffers {
     u32 *msd_tpre[MSD_LEVELS], *msd_seg[MSD_LEVELS];
     u32 *msd_joint;   // [256^3] child counts of the level-3 parents, gathered by the level-2 counting pass
     u32 msd_grid;
+    TiedTable tp;     // key-only levels: hash table of the tied keys (tc_sa.hpp)
 };
 
 // the MSD round 0 pays from this many suffixes on (level-3 buckets of >= ~64 members on DNA)
@@ -125,6 +126,10 @@ static size_t sa_carve(Arena &A, u64 N, SaBuffers &b, bool own_v1) {
             }
         }
         b.msd_joint = A.get<u32>((size_t)256 * 256 * 256);
+        b.tp.key = A.get<u64>((size_t)1 << TP_SLOT_BITS);
+        b.tp.grp = A.get<u32>((size_t)1 << TP_SLOT_BITS);
+        b.tp.cnt = A.get<u32>((size_t)1 << TP_SLOT_BITS);
+        b.tp.bloom = A.get<u32>(((size_t)1 << TP_BLOOM_LOG2) / 32);
     }
     return A.off;
 }
@@ -416,6 +421,9 @@ static void sa_run(tc_ctx *ctx, SaBuffers &b, const u8 *d_text, u64 n, u32 *d_sa
             // than by the LSD way, whose finish orders 14+ symbols instead of 12: 1 GiB genome-like
             // 188 ms against 116 ms.  So the sample decides for both instances.)
             const bool try_msd = msd_cand && cfg.P == 7 && (env_int("TC_SA_MSD", 1) == 2 || (msd_fits && msd_iid));
+            // no suffix array asked for (encode, BWT): the levels can move keys only (tc_msd.hpp, VALS = false); the
+            // small finish instance only (the big one writes sorted keys + suffix starts for its rank lookups)
+            bool keyonly = d_sa == nullptr && !msd_big && env_int("TC_SA_MSD_KEYONLY", 1) != 0;
             for (int way = try_msd ? 0 : 1; way < 2 && !have_groups; way++) {
             const bool msd = way == 0;
             const int tb = msd ? 8 * MSD_LEVELS : topbits;   // key bits that are globally ordered
@@ -454,7 +462,8 @@ static void sa_run(tc_ctx *ctx, SaBuffers &b, const u8 *d_text, u64 n, u32 *d_sa
                 // level 1 writes (k0, v0); level 2 (k1, va); level 3 (k0, v0); the finish reads (k0, v0)
                 // and writes va / L
                 u64 *kbuf[2] = {b.k0, b.k1};
-                u32 *vbuf[2] = {b.v0, va};
+                u32 *vbuf[2] = {keyonly ? nullptr : b.v0, keyonly ? nullptr : va};
+                st.msd_keyonly = keyonly ? 1u : 0u;
                 ctx->pev_used = 0;
                 st.keygen_fused = 1;
                 // the last level is "aligned" (one workgroup per parent): its child counts are gathered by the
@@ -500,7 +509,10 @@ static void sa_run(tc_ctx *ctx, SaBuffers &b, const u8 *d_text, u64 n, u32 *d_sa
                     TC_LAUNCH_CHECK(ctx);
                     const bool ev = ctx->profile && ctx->pev_used < 16;
                     if (ev) TC_HIP(ctx, hipEventRecord(ctx->pev[2 * ctx->pev_used], s));
-                    if (l == 0) msd_partition_kernel<true><<<G, MSD_NT, 0, s>>>(ML, nullptr, nullptr, kbuf[0], vbuf[0], d_text, kg);
+                    if (keyonly) {
+                        if (l == 0) msd_partition_kernel<true, false><<<G, MSD_NT, 0, s>>>(ML, nullptr, nullptr, kbuf[0], nullptr, d_text, kg);
+                        else msd_partition_kernel<false, false><<<G, MSD_NT, 0, s>>>(ML, kin, nullptr, kbuf[l & 1], nullptr, d_text, kg);
+                    } else if (l == 0) msd_partition_kernel<true><<<G, MSD_NT, 0, s>>>(ML, nullptr, nullptr, kbuf[0], vbuf[0], d_text, kg);
                     else msd_partition_kernel<false><<<G, MSD_NT, 0, s>>>(ML, kin, vin, kbuf[l & 1], vbuf[l & 1], d_text, kg);
                     TC_LAUNCH_CHECK(ctx);
                     if (ev) {
@@ -522,10 +534,13 @@ static void sa_run(tc_ctx *ctx, SaBuffers &b, const u8 *d_text, u64 n, u32 *d_sa
                 // (the last level's segment table is dead by now: the list of over-long buckets goes there)
                 mf.whole_list = b.msd_seg[MSD_LEVELS - 1];
                 mf.whole_cap = 1u << 20;
+                mf.out_khi = b.v0;   // (key-only: the value buffers are free; region layout as out_idx)
                 if (msd_big) {
                     msd_finish_kernel<MSDF_BIG_NT, MSDF_BIG_ITEMS, 1, 5, true><<<np / 256, MSDF_BIG_NT, 0, s>>>(mf);
                     TC_LAUNCH_CHECK(ctx);
                     msd_whole_kernel<<<1024, MSDW_NT, 0, s>>>(mf);
+                } else if (keyonly) {
+                    msd_finish_kernel<256, 8, 4, 1, false, false><<<np / 256, 256, 0, s>>>(mf);
                 } else {
                     msd_finish_kernel<256, 8, 4, 1, false><<<np / 256, 256, 0, s>>>(mf);
                 }
@@ -561,8 +576,12 @@ static void sa_run(tc_ctx *ctx, SaBuffers &b, const u8 *d_text, u64 n, u32 *d_sa
             }
             finish_regions_kernel<<<1, 64, 0, s>>>(fa.rcount, fa.rcap, roff, counters);
             TC_LAUNCH_CHECK(ctx);
-            finish_compact_kernel<<<1024, 256, 0, s>>>(roff, fa.rcap, b.act[1][0], b.act[1][1], b.act[1][2],
-                                                      b.act[0][0], b.act[0][1], b.act[0][2]);
+            if (msd && keyonly)
+                finish_compact_kernel<<<1024, 256, 0, s>>>(roff, fa.rcap, b.act[1][0], b.act[1][1], b.act[1][2],
+                                                          b.act[0][0], b.act[0][1], b.act[0][2], b.v0, b.act[0][3], (u32)b.sparse_cap);
+            else
+                finish_compact_kernel<<<1024, 256, 0, s>>>(roff, fa.rcap, b.act[1][0], b.act[1][1], b.act[1][2],
+                                                          b.act[0][0], b.act[0][1], b.act[0][2]);
             TC_LAUNCH_CHECK(ctx);
             fa.out_slot = b.act[0][0]; fa.out_idx = b.act[0][1]; fa.out_grp = b.act[0][2];
             tc_d2h(ctx, &ctx->h_scalars[12], ctx->d_scalars + 12, sizeof(u64));
@@ -572,6 +591,43 @@ static void sa_run(tc_ctx *ctx, SaBuffers &b, const u8 *d_text, u64 n, u32 *d_sa
                 fprintf(stderr, "textcomp: round 0 %s way%s: tied %u, flags 0x%x (1 over-long bucket left to the fix pass, 2 whole buckets tied, 4 bucket above the finish chunk, 8 joint counts off)\n",
                         msd ? "MSD" : "LSD", msd && msd_big ? " (big finish)" : "", fm, over);
             if (msd && (over & (4u | 8u))) continue;   // a level-3 bucket beyond the finish chunk (or counts that overflowed): the LSD way
+            if (msd && keyonly) {
+                // the tied members are known by slot, group and key: find their suffix starts again (tc_sa.hpp).  More
+                // ties than the table is made for, or a pass that does not find exactly fm positions: the levels
+                // are run once more with the suffix starts moving along.
+                bool ok = fm <= TP_MAX_TIED && (u64)fm + 1024 <= b.sparse_cap && !(over & 2u);
+                if (ok && fm > 0) {
+                    tc_memset_async(ctx, b.tp.key, 0, sizeof(u64) << TP_SLOT_BITS);
+                    tc_memset_async(ctx, b.tp.cnt, 0, sizeof(u32) << TP_SLOT_BITS);
+                    tc_memset_async(ctx, b.tp.bloom, 0, ((size_t)1 << TP_BLOOM_LOG2) / 8);
+                    u32 *d_total = reinterpret_cast<u32 *>(ctx->d_scalars + 11);
+                    tc_memset_async(ctx, d_total, 0, sizeof(u64));
+                    u32 FB = 1;
+                    for (u32 j = 0; j < cfg.s; j++) FB *= cfg.B;
+                    tied_table_kernel<<<tc_cdiv(fm, 256), 256, 0, s>>>(b.act[0][1], b.act[0][3], b.act[0][2], fm, FB, cfg.P, b.tp);
+                    TC_LAUNCH_CHECK(ctx);
+                    RadixKeyGen kgp;
+                    kgp.n_text = (u32)n; kgp.B = cfg.B; kgp.w = cfg.w; kgp.s = cfg.s; kgp.P = cfg.P;
+                    memcpy(kgp.lut, cfg.lut, sizeof kgp.lut);
+                    u64 Bh1 = 1;
+                    for (u32 j = 0; j + 1 < cfg.P * cfg.s; j++) Bh1 *= cfg.B;
+                    u32 pgrid = (u32)ctx->num_cus * 3;
+                    if (pgrid > tc_cdiv(n, TPK_TILE)) pgrid = tc_cdiv(n, TPK_TILE);
+                    tied_probe_kernel<<<pgrid, TPK_NT, 0, s>>>(d_text, (u32)n, kgp, Bh1, b.tp, b.act[0][0], b.act[0][1],
+                                                              b.act[0][2], d_total, fm);
+                    TC_LAUNCH_CHECK(ctx);
+                    tc_d2h(ctx, &ctx->h_scalars[11], ctx->d_scalars + 11, sizeof(u64));
+                    TC_HIP(ctx, hipStreamSynchronize(s));
+                    ok = (u32)ctx->h_scalars[11] == fm;
+                }
+                if (env_int("TC_SA_TRACE", 0))
+                    fprintf(stderr, "textcomp: key-only levels: %u tied suffixes %s\n", fm, ok ? "found again in the text" : "-- NOT recoverable: the levels run again with suffix starts");
+                if (!ok) {
+                    keyonly = false;
+                    way = -1;      // (the loop's increment makes it the MSD way again)
+                    continue;
+                }
+            }
             u32 slot_bits = (u32)rbits;
             if (!msd && (over & 1u) && fm <= fa.fix_cap && env_int("TC_SA_TIER2", 1) != 0) {
                 // some buckets are longer than a wave window: the second pass turns them into tied

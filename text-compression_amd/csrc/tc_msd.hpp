@@ -396,18 +396,22 @@ __global__ __launch_bounds__(256) void msd_scan_kernel(MsdLevel L, u32 G, u32 *m
 // while it is staged; they are consumed before tile t's stores are issued, so no wave ever waits for a
 // store.
 typedef u32 msd_u32x4 __attribute__((ext_vector_type(4)));
-template <bool KEYGEN>
+// VALS = false (round 3): the level moves KEYS ONLY -- 8 + 8 instead of 12 + 12 bytes per suffix.  An encode
+// (BWT -> MTF -> RLE) needs the last column, which rides in the key's low byte; the suffix START is needed only
+// for the few suffixes that stay tied beyond the key, and those are found again afterwards by one pass over the
+// text (tied_probe_kernel, tc_sa.hpp).  Callers that want the suffix array itself keep VALS = true.
+template <bool KEYGEN, bool VALS = true>
 __global__ __launch_bounds__(MSD_NT) void msd_partition_kernel(MsdLevel L, const u64 *kin, const u32 *vin,
                                                                u64 *kout, u32 *vout, const u8 *text,
                                                                RadixKeyGen kg) {
     // (no __restrict__ on purpose: loads that may alias the stores keep their place in program order)
     // staging of the tile sorted by digit; the key-generation image overlays it
     __shared__ __attribute__((aligned(16))) u64 s_keys[MSD_TILE];
-    __shared__ __attribute__((aligned(16))) u32 s_vals[MSD_TILE];
+    __shared__ __attribute__((aligned(16))) u32 s_vals[VALS ? MSD_TILE : 4];
     // pairs that do not fill a group yet, per digit (slots [0, r); the first ph slots of a
     // segment's first group are phantoms standing for the positions before the segment's range)
     __shared__ __attribute__((aligned(16))) u64 c_keys[256 * MSD_GROUP];
-    __shared__ __attribute__((aligned(16))) u32 c_vals[256 * MSD_GROUP];
+    __shared__ __attribute__((aligned(16))) u32 c_vals[VALS ? 256 * MSD_GROUP : 4];
     // MSD_SUB counters per digit (a lane uses counter lane % MSD_SUB): fewer lanes of a wave meet on one
     // LDS address in the ranking atomics; a digit's sub-segments lie side by side in the staging area
     __shared__ u32 s_cnt[256 * MSD_SUB], s_dstart[256 * MSD_SUB], s_r[256], s_cur[256], s_ph[256];
@@ -508,7 +512,7 @@ __global__ __launch_bounds__(MSD_NT) void msd_partition_kernel(MsdLevel L, const
             val[k] = 0;
             if (p < f.valid) {
                 key[k] = kin[f.base + p];
-                val[k] = vin[f.base + p];
+                if (VALS) val[k] = vin[f.base + p];
             }
         }
     };
@@ -535,7 +539,7 @@ __global__ __launch_bounds__(MSD_NT) void msd_partition_kernel(MsdLevel L, const
                 const u32 *vp = vin + nb + gs;
                 asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(nk4[2 * g]) : "v"(kp) : "memory");
                 asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(nk4[2 * g + 1]) : "v"(kp + 2) : "memory");
-                asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(nv4[g]) : "v"(vp) : "memory");
+                if (VALS) asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(nv4[g]) : "v"(vp) : "memory");
             }
         }
     };
@@ -544,7 +548,15 @@ __global__ __launch_bounds__(MSD_NT) void msd_partition_kernel(MsdLevel L, const
             asm volatile("s_waitcnt vmcnt(0)" : "+v"(nraw) : : "memory");
         } else {
             static_assert(MSD_ITEMS == 4 || MSD_ITEMS == 8, "land() lists the prefetch registers");
-            if (MSD_ITEMS == 8)
+            if (!VALS) {
+                if (MSD_ITEMS == 8)
+                    asm volatile("s_waitcnt vmcnt(0)"
+                                 : "+v"(nk4[0]), "+v"(nk4[1]), "+v"(nk4[MSD_ITEMS / 2 - 2]), "+v"(nk4[MSD_ITEMS / 2 - 1])
+                                 :
+                                 : "memory");
+                else
+                    asm volatile("s_waitcnt vmcnt(0)" : "+v"(nk4[0]), "+v"(nk4[1]) : : "memory");
+            } else if (MSD_ITEMS == 8)
                 asm volatile("s_waitcnt vmcnt(0)"
                              : "+v"(nk4[0]), "+v"(nk4[1]), "+v"(nk4[MSD_ITEMS / 2 - 2]), "+v"(nk4[MSD_ITEMS / 2 - 1]), "+v"(nv4[0]),
                                "+v"(nv4[MSD_ITEMS / 4 - 1])
@@ -573,6 +585,10 @@ __global__ __launch_bounds__(MSD_NT) void msd_partition_kernel(MsdLevel L, const
     auto detach = [&]() {
         if (KEYGEN) {
             asm volatile("" : "+v"(raw) : : "memory");
+        } else if (!VALS) {
+            asm volatile("" : "+v"(key[0]), "+v"(key[1]), "+v"(key[2]), "+v"(key[3]) : : "memory");
+            if (MSD_ITEMS == 8)
+                asm volatile("" : "+v"(key[MSD_ITEMS - 4]), "+v"(key[MSD_ITEMS - 3]), "+v"(key[MSD_ITEMS - 2]), "+v"(key[MSD_ITEMS - 1]) : : "memory");
         } else {
             asm volatile("" : "+v"(key[0]), "+v"(key[1]), "+v"(key[2]), "+v"(key[3]), "+v"(val[0]), "+v"(val[1]), "+v"(val[2]), "+v"(val[3]) : : "memory");
             if (MSD_ITEMS == 8)
@@ -794,7 +810,7 @@ __global__ __launch_bounds__(MSD_NT) void msd_partition_kernel(MsdLevel L, const
                 s_keys[o] = key[k];
                 // (KEYGEN: the value is the suffix start -- which suffix slot k of this thread holds
                 // depends on the key-generation form used for the tile)
-                s_vals[o] = KEYGEN ? ti.base + (fastkg ? 8 * tid + k : p) : val[k];
+                if (VALS) s_vals[o] = KEYGEN ? ti.base + (fastkg ? 8 * tid + k : p) : val[k];
             }
         }
 #ifdef MSD_PROFILE
@@ -812,8 +828,10 @@ __global__ __launch_bounds__(MSD_NT) void msd_partition_kernel(MsdLevel L, const
             for (int k = 0; k < MSD_ITEMS; k++) {
                 const msd_u32x4 q4 = nk4[k >> 1];
                 key[k] = (k & 1) ? ((u64)q4.w << 32 | q4.z) : ((u64)q4.y << 32 | q4.x);
-                const msd_u32x4 v4 = nv4[k >> 2];
-                val[k] = (k & 3) == 0 ? v4.x : (k & 3) == 1 ? v4.y : (k & 3) == 2 ? v4.z : v4.w;
+                if (VALS) {
+                    const msd_u32x4 v4 = nv4[k >> 2];
+                    val[k] = (k & 3) == 0 ? v4.x : (k & 3) == 1 ? v4.y : (k & 3) == 2 ? v4.z : v4.w;
+                }
             }
         }
         __syncthreads();   // (B3)
@@ -838,17 +856,17 @@ __global__ __launch_bounds__(MSD_NT) void msd_partition_kernel(MsdLevel L, const
                 for (u32 k = 0; k < ng; k++) {
                     const u32 e = k * MSD_GROUP + l;
                     u64 kk;
-                    u32 vv;
+                    u32 vv = 0;
                     if (e < r) {
                         kk = c_keys[d * MSD_GROUP + e];
-                        vv = c_vals[d * MSD_GROUP + e];
+                        if (VALS) vv = c_vals[d * MSD_GROUP + e];
                     } else {
                         kk = s_keys[ds + e - r];
-                        vv = s_vals[ds + e - r];
+                        if (VALS) vv = s_vals[ds + e - r];
                     }
                     if (k > 0 || l >= ph) {
                         kout[cur + e] = kk;
-                        vout[cur + e] = vv;
+                        if (VALS) vout[cur + e] = vv;
                     }
                 }
                 const u32 newr = ng ? ((r + c) & (MSD_GROUP - 1)) : r + c;
@@ -856,11 +874,11 @@ __global__ __launch_bounds__(MSD_NT) void msd_partition_kernel(MsdLevel L, const
                     if (l < newr) {
                         const u32 o = ds + (ng * MSD_GROUP - r) + l;
                         c_keys[d * MSD_GROUP + l] = s_keys[o];
-                        c_vals[d * MSD_GROUP + l] = s_vals[o];
+                        if (VALS) c_vals[d * MSD_GROUP + l] = s_vals[o];
                     }
                 } else if (l >= r && l < newr) {
                     c_keys[d * MSD_GROUP + l] = s_keys[ds + l - r];
-                    c_vals[d * MSD_GROUP + l] = s_vals[ds + l - r];
+                    if (VALS) c_vals[d * MSD_GROUP + l] = s_vals[ds + l - r];
                 }
                 if (l == 0) {
                     s_r[d] = newr;
@@ -891,7 +909,7 @@ __global__ __launch_bounds__(MSD_NT) void msd_partition_kernel(MsdLevel L, const
                 if (j >= s_ph[d] && j < s_r[d]) {
                     const u32 pos = s_cur[d] + j;
                     kout[pos] = c_keys[x];
-                    vout[pos] = c_vals[x];
+                    if (VALS) vout[pos] = c_vals[x];
                 }
             }
             __syncthreads();
@@ -917,6 +935,7 @@ struct MsdFinishArgs {
     u64 *kout;           // SORTEDKEYS: the keys in final order
     u32 *whole_list;     // SORTEDKEYS: (start, length) of the over-long buckets
     u32 whole_cap;
+    u32 *out_khi;        // VALS = false: key bits 40..63 of every tied member (out_idx then holds bits 8..39)
 };
 
 // Over-long buckets of the SORTEDKEYS instance (repeats, poly-A: no chunk holds them): msd_finish_kernel only
@@ -970,7 +989,10 @@ __global__ __launch_bounds__(MSDW_NT) void msd_whole_kernel(MsdFinishArgs a) {
 // DNA at 1 GiB: ~4096; one bucket per chunk of <= 8192 pairs, 8192 bins).  SORTEDKEYS: the keys are also
 // written in their final order (kout), so that rank lookups of the doubling rounds are a binary search
 // instead of a count inside an unsorted bucket.
-template <int MSDF_NT, int MSDF_ITEMS, int MSDF_CH, int MSDF_XB, bool SORTEDKEYS>
+// VALS = false (the key-only levels of an encode, round 3): no suffix starts come in and no suffix array goes
+// out -- 8 bytes read and 1 written per suffix instead of 12 and 5; a tied member leaves with its KEY (56 bits
+// in out_idx / out_khi) instead of its suffix start.
+template <int MSDF_NT, int MSDF_ITEMS, int MSDF_CH, int MSDF_XB, bool SORTEDKEYS, bool VALS = true>
 __global__ __launch_bounds__(MSDF_NT) void msd_finish_kernel(MsdFinishArgs a) {
     constexpr u32 MSDF_TILE = MSDF_NT * MSDF_ITEMS;
     constexpr u32 BINS_PER_CHILD = 256u << MSDF_XB;
@@ -980,8 +1002,9 @@ __global__ __launch_bounds__(MSDF_NT) void msd_finish_kernel(MsdFinishArgs a) {
     static_assert(MSDF_TILE < 65536, "16-bit bin counters");
     __shared__ u32 s_off[MAXBINS / 2 + 2];   // [bin] u16: count, then exclusive offset; [nbins] = pairs
     __shared__ u32 s_low[MSDF_TILE];   // remaining key bits, in bin order
-    __shared__ u32 s_idx[MSDF_TILE];   // suffix starts, in final order
-    __shared__ u8 s_L[MSDF_TILE];      // preceding bytes, in final order
+    __shared__ u32 s_idx[VALS ? MSDF_TILE : 4];   // suffix starts, in final order
+    __shared__ __attribute__((aligned(16))) u8 s_L[MSDF_TILE + 8];   // preceding bytes, in final order (VALS = false: shifted by start & 3,
+                                                                      // so that aligned words of the image are aligned words of L)
     __shared__ u32 s_cc[256], s_cs[256];
     __shared__ u32 s_chunk[5];         // first child, children spanned, first position, pairs, next child
     __shared__ u32 s_scan[MSDF_NT / 64 + 1];
@@ -1035,6 +1058,7 @@ __global__ __launch_bounds__(MSDF_NT) void msd_finish_kernel(MsdFinishArgs a) {
         if (c0 >= 256) break;
         if (tot == 0) continue;
         const u32 nbins = span * BINS_PER_CHILD;
+        const u32 lsh = (u32)((uintptr_t)(a.L + start) & 3u);   // (VALS = false) where the chunk starts inside its first word of L
         for (u32 i = tid; i <= nbins / 2; i += MSDF_NT) s_off[i] = 0;
         __syncthreads();
         u64 key[MSDF_ITEMS];
@@ -1046,7 +1070,7 @@ __global__ __launch_bounds__(MSDF_NT) void msd_finish_kernel(MsdFinishArgs a) {
             const u32 i = k * MSDF_NT + tid;
             if (i < tot) {
                 key[k] = kp[i];
-                val[k] = vp[i];
+                if (VALS) val[k] = vp[i];
             }
         }
 #pragma unroll
@@ -1120,22 +1144,39 @@ __global__ __launch_bounds__(MSDF_NT) void msd_finish_kernel(MsdFinishArgs a) {
                         const u32 o = base + (u32)__popcll(tb & lanemask_lt());
                         if (o < a.rcap) {
                             a.out_slot[rbase + o] = start + rank;
-                            a.out_idx[rbase + o] = val[k];
+                            a.out_idx[rbase + o] = VALS ? val[k] : mine;
+                            if (!VALS) a.out_khi[rbase + o] = (u32)(key[k] >> 40);
                             a.out_grp[rbase + o] = start + s + lt;
                         }
                     }
                 }
                 if (in) {
-                    s_idx[rank] = val[k];
-                    s_L[rank] = (u8)(key[k] & 0xff);
+                    if (VALS) s_idx[rank] = val[k];
+                    s_L[rank + (VALS ? 0u : lsh)] = (u8)(key[k] & 0xff);
                     if (SORTEDKEYS) a.kout[start + rank] = key[k];
                 }
             }
         }
         __syncthreads();
-        for (u32 i = tid; i < tot; i += MSDF_NT) {
-            a.sa_out[start + i] = s_idx[i];
-            a.L[start + i] = s_L[i];
+        if (VALS) {
+            for (u32 i = tid; i < tot; i += MSDF_NT) {
+                a.sa_out[start + i] = s_idx[i];
+                a.L[start + i] = s_L[i];
+            }
+        } else {
+            // the last column is all that leaves: whole 32-bit words where the chunk covers them, bytes at its two ends
+            const u32 sh = lsh, nw = (sh + tot + 3u) >> 2;
+            u8 *Lw = a.L + (start - sh);
+            const u32 *sw = reinterpret_cast<const u32 *>(s_L);
+            for (u32 w = tid; w < nw; w += MSDF_NT) {
+                const u32 lo = 4u * w, hi = lo + 4u;
+                if (lo >= sh && hi <= sh + tot) {
+                    reinterpret_cast<u32 *>(Lw)[w] = sw[w];
+                } else {
+                    for (u32 q = lo; q < hi; q++)
+                        if (q >= sh && q < sh + tot) Lw[q] = s_L[q];
+                }
+            }
         }
     }
 }

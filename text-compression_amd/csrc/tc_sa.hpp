@@ -1035,7 +1035,9 @@ __global__ __launch_bounds__(256) void finish_compact_kernel(const u32 *__restri
                                                              const u32 *__restrict__ in_idx,
                                                              const u32 *__restrict__ in_grp,
                                                              u32 *__restrict__ out_slot, u32 *__restrict__ out_idx,
-                                                             u32 *__restrict__ out_grp) {
+                                                             u32 *__restrict__ out_grp,
+                                                             const u32 *__restrict__ in_x = nullptr, u32 *__restrict__ out_x = nullptr,
+                                                             u32 x_cap = 0) {
     const u32 total = roff[64];
     for (u64 k = (u64)blockIdx.x * 256 + threadIdx.x; k < total; k += (u64)gridDim.x * 256) {
         u32 lo = 0, hi = FIN_REGIONS;   // the region whose range holds entry k
@@ -1047,6 +1049,120 @@ __global__ __launch_bounds__(256) void finish_compact_kernel(const u32 *__restri
         out_slot[k] = in_slot[src];
         out_idx[k] = in_idx[src];
         out_grp[k] = in_grp[src];
+        if (in_x && k < x_cap) out_x[k] = in_x[src];   // (key-only levels: the upper key bits of a tied member)
+    }
+}
+
+// ---- key-only MSD levels (tc_msd.hpp, VALS = false): the suffix starts of the tied members, found again ------
+// The levels moved keys only, so a member of the tied set is known by its slot, its group and its KEY -- the P * s
+// symbols it shares with the other members of its group.  Its suffix start is some position of the text where
+// those symbols occur, and ANY assignment of a group's positions to the group's slots will do: the members are
+// tied, the doubling rounds order them.  So: the keys go into a hash table (value = the group's first slot, a
+// counter), one pass over the text computes every position's P * s-symbol value by a rolling base-B number and
+// probes -- through a Bloom filter in LDS, so that a position that is not tied (all but a few thousand of 2^30)
+// costs one LDS bit test -- and every hit takes the next slot of its group.  A group of c members occurs exactly
+// c times in the text, so the pass ends with exactly m entries (the caller checks that).
+#define TP_SLOT_BITS 17
+#define TP_BLOOM_LOG2 18
+#define TP_MAX_TIED (1u << 15)
+struct TiedTable {
+    u64 *key;      // [2^TP_SLOT_BITS] dense value of the key's symbols (never 0 for a tied suffix); 0 = empty
+    u32 *grp;      // first slot of the group
+    u32 *cnt;      // members found so far
+    u32 *bloom;    // [2^TP_BLOOM_LOG2 / 32]
+};
+__device__ __forceinline__ u64 tp_mix(u64 v) { return v * 0x9E3779B97F4A7C15ull; }
+
+// members (klo = key bits 8..39, khi = key bits 40..63, grp) -> table.  FB = B^s: a field is an s-digit base-B number.
+__global__ __launch_bounds__(256) void tied_table_kernel(const u32 *__restrict__ klo, const u32 *__restrict__ khi,
+                                                         const u32 *__restrict__ grp, u32 m, u32 FB, u32 P, TiedTable T) {
+    const u32 k = blockIdx.x * 256 + threadIdx.x;
+    if (k >= m) return;
+    const u64 key56 = ((u64)khi[k] << 32) | klo[k];
+    u64 v = 0;
+    for (u32 f = 0; f < P; f++) v = v * FB + ((key56 >> (48 - 8 * f)) & 255u);
+    const u64 hx = tp_mix(v);
+    const u32 hb = (u32)(hx >> (64 - TP_BLOOM_LOG2));
+    atomicOr(&T.bloom[hb >> 5], 1u << (hb & 31));
+    u32 slot = (u32)(hx >> (64 - TP_SLOT_BITS));
+    for (u32 probe = 0; probe < (1u << TP_SLOT_BITS); probe++) {
+        const u64 old = atomicCAS((unsigned long long *)&T.key[slot], 0ull, (unsigned long long)v);
+        if (old == 0ull || old == v) {
+            T.grp[slot] = grp[k];   // (the same value from every member of the group)
+            return;
+        }
+        slot = (slot + 1) & ((1u << TP_SLOT_BITS) - 1u);
+    }
+}
+
+#define TPK_NT 256
+#define TPK_PER 64
+#define TPK_TILE (TPK_NT * TPK_PER)
+#define TPK_PAD(p) ((p) + ((p) >> 6) * 4u)     // a thread's 64 codes start 68 bytes apart: conflict-free byte reads
+__global__ __launch_bounds__(TPK_NT) void tied_probe_kernel(const u8 *__restrict__ text, u32 n, RadixKeyGen kg, u64 Bh1,
+                                                            TiedTable T, u32 *__restrict__ out_slot,
+                                                            u32 *__restrict__ out_idx, u32 *__restrict__ out_grp,
+                                                            u32 *total, u32 cap) {
+    __shared__ u32 s_bloom[(1u << TP_BLOOM_LOG2) / 32];
+    __shared__ u8 s_code[TPK_PAD(TPK_TILE + 64) + 16];
+    __shared__ u8 s_lut[256];
+    const u32 tid = threadIdx.x;
+    for (u32 i = tid; i < (1u << TP_BLOOM_LOG2) / 32; i += TPK_NT) s_bloom[i] = T.bloom[i];
+    s_lut[tid] = (u8)kg.lut[tid];
+    const u32 h = kg.P * kg.s, B = kg.B;   // symbols per key (<= 56), digit base
+    const u32 ntiles = (n + TPK_TILE - 1) / TPK_TILE;
+    for (u32 tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        const u32 base = tile * TPK_TILE;
+        __syncthreads();   // (the previous tile's codes have been read; first tile: bloom and lut are in place)
+        for (u32 p = tid * 16; p < TPK_TILE + 64; p += TPK_NT * 16) {
+            // 16 codes per step from one 16-byte load where the text allows (its start is 16-byte aligned by contract
+            // of the callers' buffers or not -- the load is only taken when the address is)
+            const u64 g = (u64)base + p;
+            u32 x[4] = {0, 0, 0, 0};
+            if (g + 16 <= n && ((((uintptr_t)text) + g) & 15) == 0) {
+                const uint4 q = *reinterpret_cast<const uint4 *>(text + g);
+                x[0] = q.x; x[1] = q.y; x[2] = q.z; x[3] = q.w;
+#pragma unroll
+                for (int j = 0; j < 16; j++) s_code[TPK_PAD(p + j)] = s_lut[(x[j >> 2] >> (8 * (j & 3))) & 255u];
+            } else {
+                for (int j = 0; j < 16; j++) s_code[TPK_PAD(p + j)] = g + j < n ? s_lut[text[g + j]] : (u8)0;
+            }
+        }
+        __syncthreads();
+        const u32 p0 = tid * TPK_PER;
+        if (base + p0 < n) {
+            u64 v = 0;
+            for (u32 j = 0; j < h; j++) v = v * B + s_code[TPK_PAD(p0 + j)];
+#pragma unroll 4
+            for (u32 j = 0; j < TPK_PER; j++) {
+                const u32 pos = base + p0 + j;
+                if (pos < n) {
+                    const u64 hx = tp_mix(v);
+                    const u32 hb = (u32)(hx >> (64 - TP_BLOOM_LOG2));
+                    if ((s_bloom[hb >> 5] >> (hb & 31)) & 1u) {
+                        u32 slot = (u32)(hx >> (64 - TP_SLOT_BITS));
+                        for (u32 probe = 0; probe < (1u << TP_SLOT_BITS); probe++) {
+                            const u64 kk = T.key[slot];
+                            if (kk == v) {
+                                const u32 jj = atomicAdd(&T.cnt[slot], 1u);
+                                const u32 o = atomicAdd(total, 1u);
+                                if (o < cap) {
+                                    const u32 g0 = T.grp[slot];
+                                    out_slot[o] = g0 + jj;
+                                    out_idx[o] = pos;
+                                    out_grp[o] = g0;
+                                }
+                                break;
+                            }
+                            if (kk == 0ull) break;
+                            slot = (slot + 1) & ((1u << TP_SLOT_BITS) - 1u);
+                        }
+                    }
+                }
+                // roll: drop the symbol at pos, take the one h further on (0 behind the text)
+                v = (v - (u64)s_code[TPK_PAD(p0 + j)] * Bh1) * B + s_code[TPK_PAD(p0 + j + h)];
+            }
+        }
     }
 }
 

@@ -35,7 +35,7 @@ class Stats(C.Structure):
                 ("ms_mtf", C.c_float), ("ms_rle", C.c_float), ("ms_total", C.c_float),
                 ("radix_launches", C.c_uint32), ("ms_radix", C.c_float),
                 ("keygen_fused", C.c_uint32), ("finish_pass", C.c_uint32),
-                ("sample_dups", C.c_uint32), ("msd_path", C.c_uint32),
+                ("sample_dups", C.c_uint32), ("msd_path", C.c_uint32), ("msd_keyonly", C.c_uint32),
                 ("ticket_fallbacks", C.c_uint32)]
 
 
