@@ -602,19 +602,19 @@ static void sa_run(tc_ctx *ctx, SaBuffers &b, const u8 *d_text, u64 n, u32 *d_sa
                     tc_memset_async(ctx, b.tp.bloom, 0, ((size_t)1 << TP_BLOOM_LOG2) / 8);
                     u32 *d_total = reinterpret_cast<u32 *>(ctx->d_scalars + 11);
                     tc_memset_async(ctx, d_total, 0, sizeof(u64));
-                    u32 FB = 1;
-                    for (u32 j = 0; j < cfg.s; j++) FB *= cfg.B;
-                    tied_table_kernel<<<tc_cdiv(fm, 256), 256, 0, s>>>(b.act[0][1], b.act[0][3], b.act[0][2], fm, FB, cfg.P, b.tp);
+                    tied_table_kernel<<<tc_cdiv(fm, 256), 256, 0, s>>>(b.act[0][1], b.act[0][3], b.act[0][2], fm, cfg.B, cfg.s, cfg.P, b.tp);
                     TC_LAUNCH_CHECK(ctx);
                     RadixKeyGen kgp;
                     kgp.n_text = (u32)n; kgp.B = cfg.B; kgp.w = cfg.w; kgp.s = cfg.s; kgp.P = cfg.P;
                     memcpy(kgp.lut, cfg.lut, sizeof kgp.lut);
-                    u64 Bh1 = 1;
-                    for (u32 j = 0; j + 1 < cfg.P * cfg.s; j++) Bh1 *= cfg.B;
                     u32 pgrid = (u32)ctx->num_cus * 3;
                     if (pgrid > tc_cdiv(n, TPK_TILE)) pgrid = tc_cdiv(n, TPK_TILE);
-                    tied_probe_kernel<<<pgrid, TPK_NT, 0, s>>>(d_text, (u32)n, kgp, Bh1, b.tp, b.act[0][0], b.act[0][1],
-                                                              b.act[0][2], d_total, fm);
+                    switch (cfg.s) {   // (symbols per field: B^s <= 256)
+#define TC_PROBE(S) case S: tied_probe_kernel<S><<<pgrid, TPK_NT, 0, s>>>(d_text, (u32)n, kgp, b.tp, b.act[0][0], b.act[0][1], b.act[0][2], d_total, fm); break;
+                        TC_PROBE(1) TC_PROBE(2) TC_PROBE(3) TC_PROBE(4) TC_PROBE(5) TC_PROBE(6) TC_PROBE(7) TC_PROBE(8)
+#undef TC_PROBE
+                        default: TC_FAIL(ctx, TC_ERR_INTERNAL, "key-only levels: %u symbols per field", cfg.s);
+                    }
                     TC_LAUNCH_CHECK(ctx);
                     tc_d2h(ctx, &ctx->h_scalars[11], ctx->d_scalars + 11, sizeof(u64));
                     TC_HIP(ctx, hipStreamSynchronize(s));

@@ -1072,19 +1072,34 @@ struct TiedTable {
     u32 *bloom;    // [2^TP_BLOOM_LOG2 / 32]
 };
 __device__ __forceinline__ u64 tp_mix(u64 v) { return v * 0x9E3779B97F4A7C15ull; }
+// The filter's hash is a cyclic polynomial over the symbol codes (rotate-and-xor: three cheap 32-bit operations
+// per position of the text to roll it), the table's key is the exact base-B value of the h symbols, computed
+// only for the positions that pass the filter.
+__device__ __forceinline__ u32 tp_sym(u32 c) { return __umul24(c, 0x9E3779u); }   // (one full-rate multiply; code 0 -> 0)
+__device__ __forceinline__ u32 tp_rotl(u32 x, u32 r) { return __builtin_amdgcn_alignbit(x, x, (32u - r) & 31u); }
 
-// members (klo = key bits 8..39, khi = key bits 40..63, grp) -> table.  FB = B^s: a field is an s-digit base-B number.
+// members (klo = key bits 8..39, khi = key bits 40..63, grp) -> table.  A field is an s-digit base-B number.
 __global__ __launch_bounds__(256) void tied_table_kernel(const u32 *__restrict__ klo, const u32 *__restrict__ khi,
-                                                         const u32 *__restrict__ grp, u32 m, u32 FB, u32 P, TiedTable T) {
+                                                         const u32 *__restrict__ grp, u32 m, u32 B, u32 sdig, u32 P,
+                                                         TiedTable T) {
     const u32 k = blockIdx.x * 256 + threadIdx.x;
     if (k >= m) return;
     const u64 key56 = ((u64)khi[k] << 32) | klo[k];
     u64 v = 0;
-    for (u32 f = 0; f < P; f++) v = v * FB + ((key56 >> (48 - 8 * f)) & 255u);
-    const u64 hx = tp_mix(v);
-    const u32 hb = (u32)(hx >> (64 - TP_BLOOM_LOG2));
+    u32 H = 0;
+    for (u32 f = 0; f < P; f++) {
+        const u32 g = (u32)(key56 >> (48 - 8 * f)) & 255u;
+        u32 div = 1;
+        for (u32 j = 1; j < sdig; j++) div *= B;
+        for (u32 j = 0; j < sdig; j++, div /= B) {
+            const u32 c = (g / div) % B;
+            v = v * B + c;
+            H = tp_rotl(H, 1) ^ tp_sym(c);
+        }
+    }
+    const u32 hb = H >> (32 - TP_BLOOM_LOG2);
     atomicOr(&T.bloom[hb >> 5], 1u << (hb & 31));
-    u32 slot = (u32)(hx >> (64 - TP_SLOT_BITS));
+    u32 slot = (u32)(tp_mix(v) >> (64 - TP_SLOT_BITS));
     for (u32 probe = 0; probe < (1u << TP_SLOT_BITS); probe++) {
         const u64 old = atomicCAS((unsigned long long *)&T.key[slot], 0ull, (unsigned long long)v);
         if (old == 0ull || old == v) {
@@ -1098,30 +1113,33 @@ __global__ __launch_bounds__(256) void tied_table_kernel(const u32 *__restrict__
 #define TPK_NT 256
 #define TPK_PER 64
 #define TPK_TILE (TPK_NT * TPK_PER)
-#define TPK_PAD(p) ((p) + ((p) >> 6) * 4u)     // a thread's 64 codes start 68 bytes apart: conflict-free byte reads
-__global__ __launch_bounds__(TPK_NT) void tied_probe_kernel(const u8 *__restrict__ text, u32 n, RadixKeyGen kg, u64 Bh1,
+#define TPK_PAD(p) ((p) + ((p) >> 6) * 4u)     // a thread's 64 codes start 68 bytes apart: conflict-free reads
+// S = symbols per field (the key has P = 7 fields): the window of 64 + 7 S codes a thread rolls over sits in
+// registers, every byte selection is a constant -- ~12 VALU and one LDS bit test per position of the text
+template <int S>
+__global__ __launch_bounds__(TPK_NT) void tied_probe_kernel(const u8 *__restrict__ text, u32 n, RadixKeyGen kg,
                                                             TiedTable T, u32 *__restrict__ out_slot,
                                                             u32 *__restrict__ out_idx, u32 *__restrict__ out_grp,
                                                             u32 *total, u32 cap) {
+    constexpr u32 h = 7 * S;                       // symbols per key
+    constexpr int WD = (64 + h + 3) / 4;           // dwords of the window
+    static_assert(h <= 56 && WD <= 30, "the window is 16 own dwords + at most 14 of the next thread's");
     __shared__ u32 s_bloom[(1u << TP_BLOOM_LOG2) / 32];
-    __shared__ u8 s_code[TPK_PAD(TPK_TILE + 64) + 16];
+    __shared__ __attribute__((aligned(16))) u8 s_code[TPK_PAD(TPK_TILE + 64) + 16];
     __shared__ u8 s_lut[256];
     const u32 tid = threadIdx.x;
+    const u32 B = kg.B;
     for (u32 i = tid; i < (1u << TP_BLOOM_LOG2) / 32; i += TPK_NT) s_bloom[i] = T.bloom[i];
     s_lut[tid] = (u8)kg.lut[tid];
-    const u32 h = kg.P * kg.s, B = kg.B;   // symbols per key (<= 56), digit base
     const u32 ntiles = (n + TPK_TILE - 1) / TPK_TILE;
     for (u32 tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
         const u32 base = tile * TPK_TILE;
-        __syncthreads();   // (the previous tile's codes have been read; first tile: bloom and lut are in place)
+        __syncthreads();   // (the previous tile's codes have been read; first tile: the tables are in place)
         for (u32 p = tid * 16; p < TPK_TILE + 64; p += TPK_NT * 16) {
-            // 16 codes per step from one 16-byte load where the text allows (its start is 16-byte aligned by contract
-            // of the callers' buffers or not -- the load is only taken when the address is)
             const u64 g = (u64)base + p;
-            u32 x[4] = {0, 0, 0, 0};
             if (g + 16 <= n && ((((uintptr_t)text) + g) & 15) == 0) {
                 const uint4 q = *reinterpret_cast<const uint4 *>(text + g);
-                x[0] = q.x; x[1] = q.y; x[2] = q.z; x[3] = q.w;
+                const u32 x[4] = {q.x, q.y, q.z, q.w};
 #pragma unroll
                 for (int j = 0; j < 16; j++) s_code[TPK_PAD(p + j)] = s_lut[(x[j >> 2] >> (8 * (j & 3))) & 255u];
             } else {
@@ -1131,36 +1149,48 @@ __global__ __launch_bounds__(TPK_NT) void tied_probe_kernel(const u8 *__restrict
         __syncthreads();
         const u32 p0 = tid * TPK_PER;
         if (base + p0 < n) {
-            u64 v = 0;
-            for (u32 j = 0; j < h; j++) v = v * B + s_code[TPK_PAD(p0 + j)];
-#pragma unroll 4
-            for (u32 j = 0; j < TPK_PER; j++) {
+            u32 W[WD];
+            {
+                const u32 *own = reinterpret_cast<const u32 *>(s_code + 68u * tid);        // = TPK_PAD(p0)
+                const u32 *nxt = reinterpret_cast<const u32 *>(s_code + 68u * (tid + 1));
+#pragma unroll
+                for (int i = 0; i < WD; i++) W[i] = i < 16 ? own[i] : nxt[i - 16];
+            }
+            auto code = [&](int x) -> u32 { return (W[x >> 2] >> (8 * (x & 3))) & 255u; };
+            u32 H = 0;
+#pragma unroll
+            for (int j = 0; j < (int)h; j++) H = tp_rotl(H, 1) ^ tp_sym(code(j));
+            u64 hits = 0;
+#pragma unroll
+            for (int j = 0; j < TPK_PER; j++) {
+                const u32 hb = H >> (32 - TP_BLOOM_LOG2);
+                hits |= (u64)((s_bloom[hb >> 5] >> (hb & 31)) & 1u) << j;
+                H = tp_rotl(H, 1) ^ tp_rotl(tp_sym(code(j)), h & 31u) ^ tp_sym(code(j + (int)h));
+            }
+            while (hits) {      // (rare) the exact value of the h symbols at such a position, and the table
+                const u32 j = (u32)__builtin_ctzll(hits);
+                hits &= hits - 1;
                 const u32 pos = base + p0 + j;
-                if (pos < n) {
-                    const u64 hx = tp_mix(v);
-                    const u32 hb = (u32)(hx >> (64 - TP_BLOOM_LOG2));
-                    if ((s_bloom[hb >> 5] >> (hb & 31)) & 1u) {
-                        u32 slot = (u32)(hx >> (64 - TP_SLOT_BITS));
-                        for (u32 probe = 0; probe < (1u << TP_SLOT_BITS); probe++) {
-                            const u64 kk = T.key[slot];
-                            if (kk == v) {
-                                const u32 jj = atomicAdd(&T.cnt[slot], 1u);
-                                const u32 o = atomicAdd(total, 1u);
-                                if (o < cap) {
-                                    const u32 g0 = T.grp[slot];
-                                    out_slot[o] = g0 + jj;
-                                    out_idx[o] = pos;
-                                    out_grp[o] = g0;
-                                }
-                                break;
-                            }
-                            if (kk == 0ull) break;
-                            slot = (slot + 1) & ((1u << TP_SLOT_BITS) - 1u);
+                if (pos >= n) break;
+                u64 v = 0;
+                for (u32 x = 0; x < h; x++) v = v * B + s_code[TPK_PAD(p0 + j + x)];
+                u32 slot = (u32)(tp_mix(v) >> (64 - TP_SLOT_BITS));
+                for (u32 probe = 0; probe < (1u << TP_SLOT_BITS); probe++) {
+                    const u64 kk = T.key[slot];
+                    if (kk == v) {
+                        const u32 jj = atomicAdd(&T.cnt[slot], 1u);
+                        const u32 o = atomicAdd(total, 1u);
+                        if (o < cap) {
+                            const u32 g0 = T.grp[slot];
+                            out_slot[o] = g0 + jj;
+                            out_idx[o] = pos;
+                            out_grp[o] = g0;
                         }
+                        break;
                     }
+                    if (kk == 0ull) break;
+                    slot = (slot + 1) & ((1u << TP_SLOT_BITS) - 1u);
                 }
-                // roll: drop the symbol at pos, take the one h further on (0 behind the text)
-                v = (v - (u64)s_code[TPK_PAD(p0 + j)] * Bh1) * B + s_code[TPK_PAD(p0 + j + h)];
             }
         }
     }
