@@ -421,9 +421,15 @@ static void sa_run(tc_ctx *ctx, SaBuffers &b, const u8 *d_text, u64 n, u32 *d_sa
             // than by the LSD way, whose finish orders 14+ symbols instead of 12: 1 GiB genome-like
             // 188 ms against 116 ms.  So the sample decides for both instances.)
             const bool try_msd = msd_cand && cfg.P == 7 && (env_int("TC_SA_MSD", 1) == 2 || (msd_fits && msd_iid));
-            // no suffix array asked for (encode, BWT): the levels can move keys only (tc_msd.hpp, VALS = false); the
-            // small finish instance only (the big one writes sorted keys + suffix starts for its rank lookups)
-            bool keyonly = d_sa == nullptr && !msd_big && env_int("TC_SA_MSD_KEYONLY", 1) != 0;
+            // no suffix array asked for (encode, BWT): the levels can move keys only (tc_msd.hpp, VALS = false).  Both
+            // finish instances; the big one's over-long buckets (whole tied groups: msd_whole_kernel works from the
+            // suffix starts) send the text through the levels again with the starts moving along
+            // -- so it is only tried when few ties are expected: an iid text of this entropy leaves about
+            // N^2 / 2^(entropy x key symbols) suffixes equal on the whole key (1 GiB: 5-letter DNA 2 300, measured
+            // 2 404; 4-letter DNA 262 000, measured 261 586 -- more than the table of tied keys is made for)
+            const double tied_est = (double)N * (double)N / exp2(cfg.entropy * (double)(cfg.P * cfg.s));
+            bool keyonly = d_sa == nullptr && (tied_est < (double)TP_MAX_TIED / 4.0 || env_int("TC_SA_MSD_KEYONLY", 1) == 2) &&
+                           env_int("TC_SA_MSD_KEYONLY", 1) != 0;
             for (int way = try_msd ? 0 : 1; way < 2 && !have_groups; way++) {
             const bool msd = way == 0;
             const int tb = msd ? 8 * MSD_LEVELS : topbits;   // key bits that are globally ordered
@@ -535,7 +541,10 @@ static void sa_run(tc_ctx *ctx, SaBuffers &b, const u8 *d_text, u64 n, u32 *d_sa
                 mf.whole_list = b.msd_seg[MSD_LEVELS - 1];
                 mf.whole_cap = 1u << 20;
                 mf.out_khi = b.v0;   // (key-only: the value buffers are free; region layout as out_idx)
-                if (msd_big) {
+                if (msd_big && keyonly) {
+                    msd_finish_kernel<MSDF_BIG_NT, MSDF_BIG_ITEMS, 1, 5, true, false><<<np / 256, MSDF_BIG_NT, 0, s>>>(mf);
+                    // (no msd_whole_kernel: listed buckets raise bit 1 of the flags, which ends the key-only attempt below)
+                } else if (msd_big) {
                     msd_finish_kernel<MSDF_BIG_NT, MSDF_BIG_ITEMS, 1, 5, true><<<np / 256, MSDF_BIG_NT, 0, s>>>(mf);
                     TC_LAUNCH_CHECK(ctx);
                     msd_whole_kernel<<<1024, MSDW_NT, 0, s>>>(mf);
