@@ -28,10 +28,11 @@ res={"detail": out, "commit": __import__("os").environ.get("TC_COMMIT", "?"),
      "note": "1 GiB ACGTN bench; traffic = 2*FETCH_SIZE + WRITE_SIZE of the largest dispatch of each kernel; "
              "*_bytes_per_launch = mean over that kernel's full-length launches of one step"}
 # mean over the launches of one step (the partition levels differ: level 1 reads the text, not a key array)
+keyonly=any("msd_partition_kernel<false, false>" in k for k in tot)   # the encode's levels move keys only (round 3)
 for name,pat in (("radix_pass_kernel","radix_pass_kernel<false"),("msd_partition_kernel","msd_partition_kernel")):
     fe=[];wr=[]
     for k,d in tot.items():
-        if pat in k:
+        if pat in k and not (name=="msd_partition_kernel" and keyonly and ", false>" not in k):   # (not the FM leg's index builds)
             big=max(d["WRITE_SIZE"]+[0])
             for f,w in zip(sorted(d["FETCH_SIZE"])[::-1], sorted(d["WRITE_SIZE"])[::-1]):
                 if w > 0.5*big: fe.append(2*f); wr.append(w)

@@ -11,19 +11,25 @@ PKG = os.path.join(ROOT, "text-compression_amd")
 
 # mangled-name fragment -> (max VGPRs, max scratch bytes per lane, min waves per SIMD)
 BUDGETS = {
-    "msd_finish_kernelILi256ELi8ELi4ELi1ELb0EE": (96, 0, 5),
-    "msd_finish_kernelILi512ELi12ELi1ELi5ELb1EE": (128, 0, 4),
-    "msd_partition_kernelILb0EE": (128, 0, 4),
-    "msd_partition_kernelILb1EE": (128, 16, 4),
+    "msd_finish_kernelILi256ELi8ELi4ELi1ELb0ELb1EE": (96, 0, 5),
+    "msd_finish_kernelILi512ELi12ELi1ELi5ELb1ELb1EE": (128, 0, 4),
+    "msd_partition_kernelILb0ELb1EE": (128, 0, 4),
+    "msd_partition_kernelILb1ELb1EE": (128, 16, 4),
     "msd_count_kernelILb0ELb1EE": (64, 0, 4),
     "13finish_kernel10FinishArgs": (96, 0, 5),
     "rle_encode_idx_kernelIhE": (128, 0, 4),
-    "mtf_nib_apply_kernelI6BwtAccLb1EhE": (64, 0, 4),
+    "mtf_nib_apply_kernelI6BwtAccLb1EhLb0EE": (64, 0, 4),
+    "mtf_nib_apply_kernelI6BwtAccLb1EhLb1EE": (48, 0, 4),     # round 3: the list in 32 bits
     "mtf_ts_apply_kernelI6BwtAccLi5EE": (64, 0, 8),
     "radix_pass_kernelILb0ELb0ELi1ELb0ELb0EE": (160, 0, 3),
     "14rle_nib_kernel10RleNibArgs": (128, 0, 4),          # round 3: the fused RLE -> wire-format kernel (2 x 512 threads per CU)
     "15pack_nib_kernel11PackNibArgs": (96, 0, 5),
     "fm_count_kernelILb1EE": (64, 0, 8),                   # round 3: two symbols per lookup
+    "14rle_blk_kernel10RleBlkArgs": (96, 0, 4),            # round 3: blocked RLE of the byte-wide index stream
+    "msd_partition_kernelILb0ELb0EE": (128, 0, 4),         # round 3: key-only levels
+    "msd_partition_kernelILb1ELb0EE": (128, 16, 4),
+    "msd_finish_kernelILi256ELi8ELi4ELi1ELb0ELb0EE": (80, 0, 6),
+    "tied_probe_kernelILi3EE": (96, 0, 3),
 }
 
 
