@@ -34,7 +34,9 @@
 #pragma once
 #include "tc_sa.hpp"
 
+#ifndef MSD_NT
 #define MSD_NT 1024
+#endif
 #ifndef MSD_ITEMS
 #define MSD_ITEMS 8
 #endif
@@ -425,7 +427,7 @@ __global__ __launch_bounds__(MSD_NT) void msd_partition_kernel(MsdLevel L, const
     __shared__ u16 s_klut[KEYGEN ? 256 : 1];
     __shared__ u32 s_scan2[2];
     static_assert(MSD_GROUP == 8 || MSD_GROUP == 16 || MSD_GROUP == 32, "group = 8, 16 or 32 pairs");
-    static_assert(((size_t)MSD_TILE * 12 + 256 * MSD_GROUP * 12 + 8192) * MSD_BPC <= 163840, "LDS budget");
+    static_assert(((size_t)MSD_TILE * (VALS ? 12 : 8) + 256 * MSD_GROUP * (VALS ? 12 : 8) + 8192) * (VALS ? 1 : MSD_BPC) <= 163840, "LDS budget");
     __shared__ MsdTileInfo s_info[4];
 
     const u32 tid = threadIdx.x, G = gridDim.x, b = msd_logical_wg(blockIdx.x, G);

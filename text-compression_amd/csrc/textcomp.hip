@@ -171,7 +171,7 @@ static void bwt_host(tc_ctx *ctx, const u8 *text, u64 n, u8 *L, u32 *sa, u64 *pr
     auto plan = [&](Arena &A, bool dry, u8 *&d_text, u8 *&d_L, u32 *&d_sa) {
         d_text = A.get<u8>(n + 16);
         d_L = A.get<u8>(N + 16);
-        d_sa = A.get<u32>(N);
+        d_sa = sa ? A.get<u32>(N) : nullptr;    // (no suffix array asked for: the sort may move keys only)
         sa_build(ctx, A, d_text, n, d_sa, d_L, primary, nullptr, dry);
     };
     u8 *d_text, *d_L;
