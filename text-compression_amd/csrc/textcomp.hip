@@ -18,7 +18,7 @@
 // side back-pressure: TCC_EA0_{WR,RD}REQ_DRAM_CREDIT_STALL 3.5x / 6x higher, address translation alike;
 // profiles/r03_mode_pmc.txt), with chunks of 2^24 .. 2^34 bytes 30 fresh contexts of 32 landed in the fast one
 // (profiles/r03_ws_recipes.txt).  TC_WS_VMM = log2 of the chunk size (default 28; 0: always
-// hipMalloc); workspaces under 1 GiB are plain hipMalloc blocks.
+// hipMalloc); workspaces under 32 GiB (TC_WS_VMM_MIN_LOG2) are plain hipMalloc blocks.
 struct TcWs {
     char *p = nullptr;
     size_t cap = 0, mapped = 0;
@@ -101,7 +101,10 @@ static bool ws_alloc_vmm(tc_ctx *ctx, size_t want, int chunk_log2, TcWs &w) {
 // a workspace of `want` bytes (exactly `want` when exact: a second placement of an existing size)
 static bool ws_alloc(tc_ctx *ctx, size_t want, TcWs &w) {
     const int vmm = env_int("TC_WS_VMM", 28);
-    if (vmm >= 21 && vmm <= 36 && want >= ((size_t)1 << 30) && ws_alloc_vmm(ctx, want, vmm, w)) return true;
+    // (from TC_WS_VMM_MIN_LOG2 = 2^35 bytes on: the workspace of a record of about 2^29 bytes -- where the two modes
+    // of the partition levels are worth avoiding; smaller workspaces are plain blocks)
+    const size_t vmm_min = (size_t)1 << env_int("TC_WS_VMM_MIN_LOG2", 35);
+    if (vmm >= 21 && vmm <= 36 && want >= vmm_min && ws_alloc_vmm(ctx, want, vmm, w)) return true;
     if (hipMalloc((void **)&w.p, want) != hipSuccess) {
         (void)hipGetLastError();
         w.p = nullptr;
