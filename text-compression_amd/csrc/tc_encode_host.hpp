@@ -1124,7 +1124,7 @@ static void mtf_encode_device(tc_ctx *ctx, Arena &A, Acc acc, u64 N, const u32 *
 // ------------------------------------------------------------------------- RLE
 template <class Acc, class SymT>
 static void rle_encode_device(tc_ctx *ctx, Arena &A, Acc acc, u64 N, u32 *d_counts, SymT *d_syms,
-                              u64 cap, u64 *total, bool dry) {
+                              u64 cap, u64 *total, bool dry, bool small16 = false /* values < 16 (byte-wide stream) */) {
     const bool idx_stream = std::is_same<Acc, U16Acc>::value || std::is_same<Acc, U8Acc>::value;
     const u32 tiles = tc_cdiv(N, idx_stream ? RLE16_TILE : RLE_TILE);
     const u32 btiles = tc_cdiv(N, RN_TILE);                     // tiles of the blocked kernel (byte-wide index stream)
@@ -1140,9 +1140,16 @@ static void rle_encode_device(tc_ctx *ctx, Arena &A, Acc acc, u64 N, u32 *d_coun
             b.status_a = status; b.status_b = status + btiles;
             b.ticket = reinterpret_cast<u32 *>(status + 2 * (size_t)btiles);
             b.scalars = ctx->d_scalars; b.err = ctx->d_err; b.ntiles = btiles;
-            u32 grid = tc_persistent_grid_for(ctx, rle_blk_kernel, RN_NT, 8);
-            if (grid > btiles) grid = btiles;
-            rle_blk_kernel<<<grid, RN_NT, 0, ctx->stream>>>(b);
+            b.wide = ((((uintptr_t)d_counts) | ((uintptr_t)d_syms)) & 15) == 0 ? 1u : 0u;
+            if (small16) {    // (values < 16: one staged byte per run)
+                u32 grid = tc_persistent_grid_for(ctx, rle_blk_kernel<true>, RN_NT, 8);
+                if (grid > btiles) grid = btiles;
+                rle_blk_kernel<true><<<grid, RN_NT, 0, ctx->stream>>>(b);
+            } else {
+                u32 grid = tc_persistent_grid_for(ctx, rle_blk_kernel<false>, RN_NT, 8);
+                if (grid > btiles) grid = btiles;
+                rle_blk_kernel<false><<<grid, RN_NT, 0, ctx->stream>>>(b);
+            }
             TC_LAUNCH_CHECK(ctx);
             tc_d2h(ctx, &ctx->h_scalars[2], ctx->d_scalars + 2, sizeof(u64));
             TC_HIP(ctx, hipStreamSynchronize(ctx->stream));
@@ -1209,7 +1216,7 @@ static void encode_device(tc_ctx *ctx, const u8 *d_text, u64 n, tc_block *out, u
         if (!dry) TC_HIP(ctx, hipEventRecord(ctx->ev[2], s));
         if (idx8) {
             U8Acc iacc{reinterpret_cast<const u8 *>(d_idx)};
-            rle_encode_device<U8Acc, u16>(ctx, A, iacc, N, out->run_count, out->run_value, cap, &total, dry);
+            rle_encode_device<U8Acc, u16>(ctx, A, iacc, N, out->run_count, out->run_value, cap, &total, dry, sigma <= 16);
         } else {
             U16Acc iacc{d_idx};
             rle_encode_device<U16Acc, u16>(ctx, A, iacc, N, out->run_count, out->run_value, cap, &total, dry);

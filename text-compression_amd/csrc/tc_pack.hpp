@@ -258,6 +258,7 @@ struct RleNibArgs {
     u64 *totals;     // [0] runs (atomicAdd), [1] nibbles, [2] escapes (written by the last tile)
     u32 *err;
     u32 ntiles;
+    int diag;        // timing-only ablation bits (TC_RLE_DIAG; results are wrong): 1 no look-back B, 2 no strings, 4 no output
 };
 
 // bits 0..3: which of the four bytes of d are non-zero
@@ -395,7 +396,8 @@ __global__ __launch_bounds__(RN_NT, 2) void rle_nib_kernel(RleNibArgs a) {
         }
         const u32 tn = tile_cnt & 0xffffu, te = tile_cnt >> 16;
         if (w == 1) {
-            const u64 e = lb_exclusive<OpSum>(a.status_b, tile, NIB_LB(tn, te), a.err);
+            const u64 e = (a.diag & 1) ? NIB_LB((u64)tile * 27000ull, (u64)tile * 50ull)
+                                       : lb_exclusive<OpSum>(a.status_b, tile, NIB_LB(tn, te), a.err);
             if (lane == 0) {
                 s_pref = e;
                 if (tile + 1 == a.ntiles) {
@@ -413,6 +415,7 @@ __global__ __launch_bounds__(RN_NT, 2) void rle_nib_kernel(RleNibArgs a) {
         const u64 q0 = s_pref >> NIB_LB_SHIFT, e0 = NIB_LB_ESC(s_pref);
         const u32 a0 = (u32)(q0 & 31u);
         // ---- 4: the nibble strings, into the tile's image --------------------------------------------------
+        if (!(a.diag & 2))
 #pragma unroll
         for (int s = 0; s < RN_SUB; s++) {
             const u32 p0 = (u32)(tbase + (u64)s * RN_SUBSZ + (u64)tid * 16);
@@ -471,7 +474,7 @@ __global__ __launch_bounds__(RN_NT, 2) void rle_nib_kernel(RleNibArgs a) {
             }
         }
         __syncthreads();
-        nib_image_out<RN_NT>(img, q0, tn, tile + 1 == a.ntiles, a.out, a.cap_units);
+        if (!(a.diag & 4)) nib_image_out<RN_NT>(img, q0, tn, tile + 1 == a.ntiles, a.out, a.cap_units);
     }
 }
 
@@ -491,11 +494,18 @@ struct RleBlkArgs {
     u64 *scalars;    // [2] total runs
     u32 *err;
     u32 ntiles;
+    u32 wide;        // counts and vals are 16-byte aligned: groups of 8 runs may leave as 16-byte stores
 };
 
-__global__ __launch_bounds__(RN_NT, 2) void rle_blk_kernel(RleBlkArgs a) {
+// PACK4 (values < 16: the index stream of an alphabet of at most 16 symbols): one staged byte per run, value in the low
+// and min(length, 15) in the high nibble (15 = "15 or more") -- 32 KB of staging instead of 64, twice the workgroups per CU
+template <bool PACK4>
+__global__ __launch_bounds__(RN_NT, 4) void rle_blk_kernel(RleBlkArgs a) {
     constexpr int NW = RN_NT / 64;
-    __shared__ u8 s_c8[RN_TILE], s_v8[RN_TILE];
+    constexpr u32 LONGC = PACK4 ? 15u : 255u;
+    // (run j of the tile is staged at index j + (e0 & 7): groups of 8 staged runs that are 8-byte aligned in LDS are
+    // then 32-byte aligned in run_count[] and 16-byte aligned in run_value[] -- they leave as 16-byte stores)
+    __shared__ __attribute__((aligned(16))) u8 s_c8[RN_TILE + 16], s_v8[PACK4 ? 16 : RN_TILE + 16];
     __shared__ u32 s_last[RN_NSEG], s_carry[RN_NSEG], s_sum[RN_NSEG];
     __shared__ u32 s_tile;
     __shared__ u64 s_pref;
@@ -578,32 +588,66 @@ __global__ __launch_bounds__(RN_NT, 2) void rle_blk_kernel(RleBlkArgs a) {
         }
         __syncthreads();
         const u64 e0 = s_pref;
+        const u32 sh = (u32)(e0 & 7u);
 #pragma unroll
         for (int s = 0; s < RN_SUB; s++) {
             const u32 p0 = (u32)(tbase + (u64)s * RN_SUBSZ + (u64)tid * 16);
             const u32 xs[4] = {x[s].x, x[s].y, x[s].z, x[s].w};
             u32 prev = ((hasmask >> s) & 1u) ? pv[s] : s_carry[s * NW + w];
-            u32 j = excl[s];
+            u32 j = excl[s] + sh;
 #pragma unroll
             for (int i = 0; i < 16; i++) {
                 if ((E[s] >> i) & 1u) {
                     const u32 pos1 = p0 + (u32)i + 1u;
                     const u32 c = pos1 - prev;
                     prev = pos1;
-                    s_c8[j] = (u8)(c < 255u ? c : 255u);
-                    s_v8[j] = (u8)((xs[i >> 2] >> (8 * (i & 3))) & 0xffu);
-                    if (c >= 255u && e0 + j < a.cap) a.counts[e0 + j] = c;
+                    const u32 v = (xs[i >> 2] >> (8 * (i & 3))) & 0xffu;
+                    const u32 cc = c < LONGC ? c : LONGC;
+                    if (PACK4) {
+                        s_c8[j] = (u8)((v & 15u) | (cc << 4));
+                    } else {
+                        s_c8[j] = (u8)cc;
+                        s_v8[j] = (u8)v;
+                    }
+                    if (c >= LONGC && e0 + (j - sh) < a.cap) a.counts[e0 + (j - sh)] = c;
                     j++;
                 }
             }
         }
         __syncthreads();
-        for (u32 i = tid; i < truns; i += RN_NT) {
-            const u64 g = e0 + i;
-            if (g < a.cap) {
-                const u32 c = s_c8[i];
-                if (c != 255u) a.counts[g] = c;
-                a.vals[g] = (u16)s_v8[i];
+        // groups of 8 staged runs: whole groups inside [sh, sh + truns) and below the capacity leave as three 16-byte
+        // stores (unless one of them is a long run, whose length its owner has stored), the rest run by run
+        const u64 gbase = e0 - sh;                       // run index of staged slot 0 (a multiple of 8)
+        const u32 ngroups = (sh + truns + 7u) >> 3;
+        for (u32 q = tid; q < ngroups; q += RN_NT) {
+            const u32 lo = 8u * q;
+            const u64 cw = *reinterpret_cast<const u64 *>(s_c8 + lo);
+            const u64 vw = PACK4 ? 0ull : *reinterpret_cast<const u64 *>(s_v8 + lo);
+            u32 c[8], v[8];
+            bool plain = a.wide && lo >= sh && lo + 8u <= sh + truns && gbase + lo + 8u <= a.cap;
+#pragma unroll
+            for (int k = 0; k < 8; k++) {
+                const u32 b = (u32)(cw >> (8 * k)) & 255u;
+                c[k] = PACK4 ? b >> 4 : b;
+                v[k] = PACK4 ? b & 15u : (u32)(vw >> (8 * k)) & 255u;
+                plain = plain && c[k] != LONGC;
+            }
+            if (plain) {
+                uint4 *pc = reinterpret_cast<uint4 *>(a.counts + gbase + lo);
+                pc[0] = make_uint4(c[0], c[1], c[2], c[3]);
+                pc[1] = make_uint4(c[4], c[5], c[6], c[7]);
+                *reinterpret_cast<uint4 *>(a.vals + gbase + lo) =
+                    make_uint4(v[0] | (v[1] << 16), v[2] | (v[3] << 16), v[4] | (v[5] << 16), v[6] | (v[7] << 16));
+            } else {
+#pragma unroll
+                for (int k = 0; k < 8; k++) {
+                    const u32 i = lo + (u32)k;
+                    const u64 g = gbase + i;
+                    if (i >= sh && i < sh + truns && g < a.cap) {
+                        if (c[k] != LONGC) a.counts[g] = c[k];
+                        a.vals[g] = (u16)v[k];
+                    }
+                }
             }
         }
     }

@@ -1253,6 +1253,7 @@ static void encode_container_device(tc_ctx *ctx, const u8 *d_text, u64 n, u8 *d_
             a.ticket = reinterpret_cast<u32 *>(status + 2 * (size_t)ntiles);
             a.totals = status + 2 * (size_t)ntiles + 8;
             a.err = ctx->d_err; a.ntiles = ntiles;
+            a.diag = env_int("TC_RLE_DIAG", 0);
             u32 grid = tc_persistent_grid_for(ctx, rle_nib_kernel, RN_NT, 8);
             if (grid > ntiles) grid = ntiles;
             rle_nib_kernel<<<grid, RN_NT, 0, s>>>(a);
@@ -1271,7 +1272,7 @@ static void encode_container_device(tc_ctx *ctx, const u8 *d_text, u64 n, u8 *d_
             A.off = rle_mark;
             if (idx8) {
                 U8Acc iacc{reinterpret_cast<const u8 *>(d_idx)};
-                rle_encode_device<U8Acc, u16>(ctx, A, iacc, N, r_cnt, r_val, N + 2, &total, false);
+                rle_encode_device<U8Acc, u16>(ctx, A, iacc, N, r_cnt, r_val, N + 2, &total, false, sigma <= 16);
             } else {
                 U16Acc iacc{d_idx};
                 rle_encode_device<U16Acc, u16>(ctx, A, iacc, N, r_cnt, r_val, N + 2, &total, false);
