@@ -549,7 +549,7 @@ static void sa_run(tc_ctx *ctx, SaBuffers &b, const u8 *d_text, u64 n, u32 *d_sa
                     TC_LAUNCH_CHECK(ctx);
                     msd_whole_kernel<<<1024, MSDW_NT, 0, s>>>(mf);
                 } else if (keyonly) {
-                    msd_finish_kernel<256, 8, 4, 1, false, false><<<np / 256, 256, 0, s>>>(mf);
+                    msd_finish_kernel<MSDF_KO_NT, MSDF_CAP_SMALL / MSDF_KO_NT, 4, 1, false, false><<<np / 256, MSDF_KO_NT, 0, s>>>(mf);
                 } else {
                     msd_finish_kernel<256, 8, 4, 1, false><<<np / 256, 256, 0, s>>>(mf);
                 }

@@ -53,6 +53,9 @@
 #endif
 #define MSD_LEVELS 3
 #define MSDF_CAP_SMALL 2048                // pairs per chunk of the finish kernel's instance for small buckets
+#ifndef MSDF_KO_NT
+#define MSDF_KO_NT 256                     // threads of that instance in its key-only form
+#endif
 #ifndef MSDF_BIG_NT
 #define MSDF_BIG_NT 512
 #endif
