@@ -548,6 +548,23 @@ static void sa_run(tc_ctx *ctx, SaBuffers &b, const u8 *d_text, u64 n, u32 *d_sa
                     msd_finish_kernel<MSDF_BIG_NT, MSDF_BIG_ITEMS, 1, 5, true><<<np / 256, MSDF_BIG_NT, 0, s>>>(mf);
                     TC_LAUNCH_CHECK(ctx);
                     msd_whole_kernel<<<1024, MSDW_NT, 0, s>>>(mf);
+                } else if (keyonly && env_int("TC_MSD_FINISH_KO", 1) != 0) {
+                    // (equal-mass bins from the level-1 digit counts: tc_msd.hpp, msd_finish_ko_kernel)
+                    MsdFinishLut *flut = reinterpret_cast<MsdFinishLut *>(b.msd_seg[MSD_LEVELS - 1] + 2 * (size_t)mf.whole_cap);
+                    msd_finish_lut_kernel<<<1, 256, 0, s>>>(b.msd_pcnt[1], flut);
+                    TC_LAUNCH_CHECK(ctx);
+                    msd_finish_ko_kernel<3><<<np / 256, 256, 0, s>>>(mf, flut);
+#ifdef MSDK_PROFILE
+                    {
+                        u64 h[10];
+                        tc_d2h(ctx, h, ctx->d_scalars + 112, sizeof h);
+                        TC_HIP(ctx, hipStreamSynchronize(s));
+                        const double c = (double)(h[8] | 1);
+                        fprintf(stderr, "finish (key-only): chunks %llu, keys per chunk %.0f | cycles per chunk: land %.0f B %.0f zero+B %.0f bins+B %.0f scan+B %.0f scatter+B %.0f walk+prefetch+rank+B %.0f copy-out %.0f\n",
+                                (unsigned long long)h[8], h[9] / c, h[0] / c, h[1] / c, h[2] / c, h[3] / c, h[4] / c, h[5] / c, h[6] / c, h[7] / c);
+                        tc_memset_async(ctx, ctx->d_scalars + 112, 0, sizeof h);
+                    }
+#endif
                 } else if (keyonly) {
                     msd_finish_kernel<MSDF_KO_NT, MSDF_CAP_SMALL / MSDF_KO_NT, 4, 1, false, false><<<np / 256, MSDF_KO_NT, 0, s>>>(mf);
                 } else {
@@ -605,6 +622,17 @@ static void sa_run(tc_ctx *ctx, SaBuffers &b, const u8 *d_text, u64 n, u32 *d_sa
                 // ties than the table is made for, or a pass that does not find exactly fm positions: the levels
                 // are run once more with the suffix starts moving along.
                 bool ok = fm <= TP_MAX_TIED && (u64)fm + 1024 <= b.sparse_cap && !(over & 2u);
+                if (env_int("TC_SA_TRACE", 0) >= 2 && ok && fm > 0) {   // (order-free sums of the tied members' keys, slots and groups)
+                    std::vector<u32> hk(fm), hh(fm), hs(fm), hg(fm);
+                    tc_d2h(ctx, hk.data(), b.act[0][1], fm * sizeof(u32));
+                    tc_d2h(ctx, hh.data(), b.act[0][3], fm * sizeof(u32));
+                    tc_d2h(ctx, hs.data(), b.act[0][0], fm * sizeof(u32));
+                    tc_d2h(ctx, hg.data(), b.act[0][2], fm * sizeof(u32));
+                    TC_HIP(ctx, hipStreamSynchronize(s));
+                    u64 a1 = 0, a2 = 0, a3 = 0, a4 = 0;
+                    for (u32 i = 0; i < fm; i++) { a1 += hk[i]; a2 += hh[i]; a3 += hs[i]; a4 += hg[i]; }
+                    fprintf(stderr, "textcomp: tied members: sum klo %llx khi %llx slot %llx grp %llx\n", (unsigned long long)a1, (unsigned long long)a2, (unsigned long long)a3, (unsigned long long)a4);
+                }
                 if (ok && fm > 0) {
                     tc_memset_async(ctx, b.tp.key, 0, sizeof(u64) << TP_SLOT_BITS);
                     tc_memset_async(ctx, b.tp.cnt, 0, sizeof(u32) << TP_SLOT_BITS);
@@ -630,7 +658,8 @@ static void sa_run(tc_ctx *ctx, SaBuffers &b, const u8 *d_text, u64 n, u32 *d_sa
                     ok = (u32)ctx->h_scalars[11] == fm;
                 }
                 if (env_int("TC_SA_TRACE", 0))
-                    fprintf(stderr, "textcomp: key-only levels: %u tied suffixes %s\n", fm, ok ? "found again in the text" : "-- NOT recoverable: the levels run again with suffix starts");
+                    fprintf(stderr, "textcomp: key-only levels: %u tied suffixes %s (the pass over the text met %u)\n", fm,
+                            ok ? "found again in the text" : "-- NOT recoverable: the levels run again with suffix starts", (u32)ctx->h_scalars[11]);
                 if (!ok) {
                     keyonly = false;
                     way = -1;      // (the loop's increment makes it the MSD way again)
@@ -1182,6 +1211,47 @@ static void rle_encode_device(tc_ctx *ctx, Arena &A, Acc acc, u64 N, u32 *d_coun
     *total = ctx->h_scalars[2];
 }
 
+// seqToMTF and seqToRLE of a last column over at most 8 symbols in one kernel (tc_pack.hpp, mtf_rle_kernel): the
+// index stream is never written.  false (nothing written that matters): another alphabet, unaligned run arrays, or a
+// tile whose incoming list the backward scan did not recover -- the caller runs the two stages.  TC_MTF_RLE=0: never.
+static bool mtf_rle_device(tc_ctx *ctx, Arena &A, BwtAcc acc, u64 N, const u32 *counts257, tc_block *out, u64 cap,
+                           u64 *total, u32 *sigma, bool dry) {
+    const u32 tiles = tc_cdiv(N, MTF_TILE);
+    u64 *status = A.get<u64>(2 * (size_t)tiles + 8);
+    if (dry || env_int("TC_MTF_RLE", 1) == 0 || env_int("TC_MTF_FORCE_GENERAL", 0) != 0) return false;
+    Alphabet al;
+    al.build(counts257);
+    if (al.sigma > 8 || N + 64 >= (1ull << 32)) return false;
+    hipStream_t s = ctx->stream;
+    MtfRleArgs a;
+    for (int v = 0; v < 257; v++) a.lut.v[v] = (u8)al.code_of_sym[v];
+    tc_memset_async(ctx, status, 0, (2 * (size_t)tiles + 8) * sizeof(u64));
+    a.acc = acc; a.N = N; a.sigma = al.sigma;
+    a.flag = reinterpret_cast<u32 *>(status + 2 * (size_t)tiles + 1);
+    a.counts = out->run_count; a.vals = reinterpret_cast<u16 *>(out->run_value); a.cap = cap;
+    a.status_a = status; a.status_b = status + tiles;
+    a.ticket = reinterpret_cast<u32 *>(status + 2 * (size_t)tiles);
+    a.scalars = ctx->d_scalars; a.err = ctx->d_err; a.ntiles = tiles;
+    a.wide = ((((uintptr_t)out->run_count) | ((uintptr_t)out->run_value)) & 15) == 0 ? 1u : 0u;
+    a.diag = (u32)env_int("TC_MTFRLE_DIAG", 0);
+    a.stagger = (u32)env_int("TC_MTFRLE_STAGGER", 0);
+    mtf_rle_kernel<<<tiles, MTF_NT, 0, s>>>(a);
+    TC_LAUNCH_CHECK(ctx);
+    u64 *d_final = status + 2 * (size_t)tiles + 2;
+    mtf_nib_final_kernel<BwtAcc><<<1, 64, 0, s>>>(acc, N, a.lut, al.sigma, d_final, a.flag);
+    TC_LAUNCH_CHECK(ctx);
+    tc_d2h(ctx, &ctx->h_scalars[15], a.flag, sizeof(u32));
+    tc_d2h(ctx, &ctx->h_scalars[8], d_final, sizeof(u64));
+    tc_d2h(ctx, &ctx->h_scalars[2], ctx->d_scalars + 2, sizeof(u64));
+    TC_HIP(ctx, hipStreamSynchronize(s));
+    if ((u32)ctx->h_scalars[15] != 0) return false;
+    const u64 perm = ctx->h_scalars[8];
+    for (u32 i = 0; i < al.sigma; i++) out->final_list[i] = al.sym_of_code[(perm >> (4 * i)) & 15];
+    *sigma = al.sigma;
+    *total = ctx->h_scalars[2];
+    return true;
+}
+
 // --------------------------------------------------------------- fused pipeline
 // bytestringToBWT -> bytestringBWTToMTFB -> runs of the index stream.
 static void encode_device(tc_ctx *ctx, const u8 *d_text, u64 n, tc_block *out, u64 cap) {
@@ -1211,6 +1281,12 @@ static void encode_device(tc_ctx *ctx, const u8 *d_text, u64 n, tc_block *out, u
         // small alphabets: the index stream between the two stages is one byte per symbol (the
         // same buffer, half used)
         bool idx8 = false;
+        if (mtf_rle_device(ctx, A, acc, N, counts257, out, cap, &total, &sigma, dry)) {   // (sigma <= 8: one kernel)
+            TC_HIP(ctx, hipEventRecord(ctx->ev[2], s));
+            TC_HIP(ctx, hipEventRecord(ctx->ev[3], s));
+            if (A.off < end_sa) A.off = end_sa;
+            return;
+        }
         mtf_encode_device<BwtAcc>(ctx, A, acc, N, dry ? nullptr : counts257, d_idx,
                                   out->final_list, &sigma, dry, reinterpret_cast<u8 *>(d_idx), &idx8);
         if (!dry) TC_HIP(ctx, hipEventRecord(ctx->ev[2], s));

@@ -1186,4 +1186,289 @@ __global__ __launch_bounds__(MSDF_NT) void msd_finish_kernel(MsdFinishArgs a) {
     }
 }
 
+// ---- the finish of the key-only levels, small buckets (round 3) -------------------------------------------------
+// msd_finish_kernel<256, 8, 4, 1, false, false> spends ~200 instructions per key, most of them in the ranking loop:
+// its bins are (child, field 3, top bit of field 4) taken as key BITS, but a field is s symbols in base B inside 8
+// bits (5-letter DNA: 125 live values of 256), so only ~210 of a child's 512 bins are ever used and a bin holds 2.6
+// keys on average -- the loop over the bin (as long as the longest bin of the wave) runs ~8 times.  Here
+//  * a bin is an equal-MASS interval of (field 3, field 4): bin = (A[f3] + ((W[f3] * C[f4]) >> 16)) >> 6 with A / W /
+//    C the cumulative / own share of a field value among the text's field-0 digits (the level-1 counts; a text that
+//    takes the MSD way looks iid at this depth, and any monotone map is CORRECT -- the ranking inside a bin compares
+//    all of bits 39..8).  MSDK_BPC bins per child, ~0.55 keys per bin;
+//  * the rank inside the bin: the first four slots of the bin straight-line, a loop only for a longer bin (rare);
+//  * 32-bit bins and offsets (one ds_read2 gives a bin's start and end), the chunk walk done by every thread from LDS
+//    (no single-thread section), key halves in registers throughout.
+// Same results as the generic instance (final places, last column, the tied set by (slot, key, group)).
+struct MsdFinishLut {
+    u32 a[256];      // cumulative share of the values below, in 1/64 bins (0 .. MSDK_BPC * 64)
+    u32 w[256];      // a[v + 1] - a[v]
+    u32 c[256];      // cumulative share in 1/65536 (<= 65535)
+};
+#define MSDK_BPC 1024
+__global__ __launch_bounds__(256) void msd_finish_lut_kernel(const u32 *__restrict__ cnt, MsdFinishLut *out) {
+    __shared__ u64 s_x[257];
+    __shared__ u64 s_tot;
+    const u32 t = threadIdx.x;
+    s_x[t] = cnt[t];
+    __syncthreads();
+    if (t == 0) {
+        u64 run = 0;
+        for (int i = 0; i < 256; i++) { const u64 c = s_x[i]; s_x[i] = run; run += c; }
+        s_x[256] = run;
+        s_tot = run ? run : 1;
+    }
+    __syncthreads();
+    const u64 tot = s_tot;
+    const u32 lo = (u32)(s_x[t] * (u64)(MSDK_BPC * 64) / tot), hi = t == 255 ? (u32)(MSDK_BPC * 64) : (u32)(s_x[t + 1] * (u64)(MSDK_BPC * 64) / tot);
+    out->a[t] = lo;
+    out->w[t] = hi - lo;
+    const u64 c16 = s_x[t] * 65536ull / tot;
+    out->c[t] = c16 > 65535 ? 65535u : (u32)c16;
+}
+
+// LDS-only barrier: orders the workgroup's LDS traffic and leaves global loads in flight (a __syncthreads() waits for
+// every memory operation the compiler knows of, and its vmcnt(0) also waits for the asm-issued prefetch below)
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
+template <int CH>
+__global__ __launch_bounds__(256, 6) void msd_finish_ko_kernel(MsdFinishArgs a, const MsdFinishLut *__restrict__ lut) {
+    constexpr u32 NT = 256, ITEMS = 8, TILE = NT * ITEMS, MAXBINS = CH * MSDK_BPC;
+    constexpr int BPT = MAXBINS / NT;
+    static_assert(CH == 3, "the chunk's live children are c0, l1, l2");
+    static_assert(TILE == MSDF_CAP_SMALL && TILE <= 2048 && MAXBINS <= 4096 && BPT * NT == MAXBINS && BPT % 4 == 0,
+                  "chunk of the small instance; bin | byte | slot in one word; whole 16-byte groups of bins per thread");
+    __shared__ __attribute__((aligned(16))) u32 s_off[MAXBINS + 4];   // [bin] count, then exclusive offset; [MAXBINS] = pairs
+    __shared__ u32 s_low[TILE + 4];                                    // key bits 39..8, in bin order
+    __shared__ __attribute__((aligned(16))) u8 s_L[TILE + 8];          // preceding bytes, in final order, shifted by start & 3
+    __shared__ uint2 s_aw[256];
+    __shared__ u16 s_c[256], s_cc[256];
+    __shared__ u32 s_scan[NT / 64 + 1];
+    const u32 q = blockIdx.x;
+    if (a.pcnt[q] == 0 || (a.counters[1] & 8u)) return;   // (bit 3: the level-3 counts did not add up)
+    const u32 tid = threadIdx.x, l = tid & 63;
+    {
+        const u32 c = a.ccnt[(size_t)q * 256 + tid];
+        s_cc[tid] = (u16)(c > 65535u ? 65535u : c);                    // (> TILE is all that matters of a long one)
+        s_aw[tid] = make_uint2(lut->a[tid], lut->w[tid]);
+        s_c[tid] = (u16)lut->c[tid];
+    }
+    const u32 region = blockIdx.x % FIN_REGIONS;
+    u32 *rctr = a.rcount + region * FIN_RSTRIDE;
+    const u32 rbase = region * a.rcap;
+    const u32 pstart = a.cstart[(size_t)q * 256];    // (the children of a parent lie one behind the other)
+    __syncthreads();
+    // a chunk: up to CH non-empty children (c0 < l1 < l2; 256: none) of at most TILE pairs together; `ch` walks the
+    // children, `run` the pairs before them.  Every thread walks the same counts (LDS broadcasts), the results scalar.
+    struct Chunk { u32 c0, l1, l2, tot, off; };
+    u32 ch = 0, run = 0;
+    auto walk = [&](Chunk &k) -> bool {
+        while (true) {
+            while (ch < 256 && s_cc[ch] == 0) ch++;
+            if (ch >= 256) return false;
+            if (s_cc[ch] <= TILE) break;
+            // a bucket no chunk can hold (repeats, poly-A): bit 2, the caller takes the LSD way
+            if (tid == 0) atomicOr(&a.counters[1], 4u);
+            run += a.ccnt[(size_t)q * 256 + ch];
+            ch++;
+        }
+        u32 c0 = ch, l1 = 256, l2 = 256, tot = s_cc[ch], nl = 1;
+        ch++;
+        while (ch < 256) {
+            const u32 c = s_cc[ch];
+            if (c) {
+                if (nl == (u32)CH || tot + c > TILE) break;
+                if (nl == 1) l1 = ch; else l2 = ch;
+                tot += c;
+                nl++;
+            }
+            ch++;
+        }
+        k.c0 = (u32)__builtin_amdgcn_readfirstlane((int)c0);
+        k.l1 = (u32)__builtin_amdgcn_readfirstlane((int)l1);
+        k.l2 = (u32)__builtin_amdgcn_readfirstlane((int)l2);
+        k.tot = (u32)__builtin_amdgcn_readfirstlane((int)tot);
+        k.off = (u32)__builtin_amdgcn_readfirstlane((int)run);
+        run += tot;
+        return true;
+    };
+    // the keys of a chunk by asm-issued loads (the compiler's wait counts do not see them: the rank phase and the
+    // copy-out of the chunk before run while they are in flight); a slot past the chunk re-reads its first key
+    u64 nk[ITEMS];
+    auto prefetch = [&](const Chunk &k) {
+        const u64 *kp = a.keys + pstart + k.off;
+#pragma unroll
+        for (int j = 0; j < (int)ITEMS; j++) {
+            const u32 i = j * NT + tid;
+            const u32 bo = (i < k.tot ? i : 0u) * 8u;
+            asm volatile("global_load_dwordx2 %0, %1, %2" : "=v"(nk[j]) : "v"(bo), "s"(kp) : "memory");
+        }
+    };
+    Chunk cur, nxt;
+    bool have = walk(cur);
+    if (have) prefetch(cur);
+#ifdef MSDK_PROFILE
+    u64 tq[10], acc[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+#define MSDK_T(i) tq[i] = __builtin_readcyclecounter()
+#else
+#define MSDK_T(i)
+#endif
+    while (have) {
+        MSDK_T(0);
+        const u32 c0 = cur.c0, l1 = cur.l1, l2 = cur.l2, tot = cur.tot, start = pstart + cur.off;
+        const u32 lsh = (u32)((uintptr_t)(a.L + start) & 3u);   // where the chunk starts inside its first word of L
+        u32 klo[ITEMS], khi[ITEMS];
+        asm volatile("s_waitcnt vmcnt(0)"
+                     : "+v"(nk[0]), "+v"(nk[1]), "+v"(nk[2]), "+v"(nk[3]), "+v"(nk[4]), "+v"(nk[5]), "+v"(nk[6]), "+v"(nk[7])
+                     :
+                     : "memory");
+#pragma unroll
+        for (int k = 0; k < (int)ITEMS; k++) {
+            klo[k] = (u32)nk[k];
+            khi[k] = (u32)(nk[k] >> 32);
+        }
+        MSDK_T(1);
+        lds_barrier();   // (the previous chunk's copy-out has read the LDS images)
+        MSDK_T(2);
+        {
+            uint4 *z = reinterpret_cast<uint4 *>(s_off + tid * BPT);
+#pragma unroll
+            for (int j = 0; j < BPT / 4; j++) z[j] = make_uint4(0u, 0u, 0u, 0u);
+        }
+        lds_barrier();
+        MSDK_T(3);
+        u32 bp[ITEMS];   // bin | preceding byte << 12 | slot << 20 (the slot: first the arrival number in the bin, then the place in bin order)
+#pragma unroll
+        for (int k = 0; k < (int)ITEMS; k++) {
+            const u32 i = k * NT + tid;
+            if (i < tot) {
+                const uint2 aw = s_aw[khi[k] & 255u];                  // field 3: key bits 39..32
+                const u32 c = s_c[klo[k] >> 24];                       // field 4: 31..24
+                u32 inner = (aw.x + (__umul24(aw.y, c) >> 16)) >> 6;
+                inner = inner < MSDK_BPC ? inner : MSDK_BPC - 1u;        // (a value the level-1 counts never met, past the last one)
+                const u32 child = (khi[k] >> 8) & 255u;
+                const u32 bin = ((u32)(child >= l1) + (u32)(child >= l2)) * MSDK_BPC + inner;
+                bp[k] = bin | ((klo[k] & 255u) << 12) | (atomicAdd(&s_off[bin], 1u) << 20);
+            }
+        }
+        __syncthreads();
+        MSDK_T(4);
+        {   // counts -> exclusive offsets; entry MAXBINS = pairs
+            uint4 *z = reinterpret_cast<uint4 *>(s_off + tid * BPT);
+            uint4 v[BPT / 4];
+            u32 sum = 0;
+#pragma unroll
+            for (int j = 0; j < BPT / 4; j++) {
+                v[j] = z[j];
+                sum += v[j].x + v[j].y + v[j].z + v[j].w;
+            }
+            u32 all;
+            u32 ex = block_excl_sum<NT>(sum, s_scan, &all);
+#pragma unroll
+            for (int j = 0; j < BPT / 4; j++) {
+                uint4 o;
+                o.x = ex; ex += v[j].x;
+                o.y = ex; ex += v[j].y;
+                o.z = ex; ex += v[j].z;
+                o.w = ex; ex += v[j].w;
+                z[j] = o;
+            }
+            if (tid == NT - 1) s_off[MAXBINS] = ex;
+        }
+        __syncthreads();
+        MSDK_T(5);
+#pragma unroll
+        for (int k = 0; k < (int)ITEMS; k++) {
+            const u32 i = k * NT + tid;
+            if (i < tot) {
+                bp[k] += s_off[bp[k] & 0xfffu] << 20;
+                s_low[bp[k] >> 20] = __builtin_amdgcn_alignbit(khi[k], klo[k], 8);
+            }
+        }
+        __syncthreads();   // (the key registers are dead from here: a tied member's upper bits are the parent and its child)
+        MSDK_T(6);
+        have = walk(nxt);
+        if (have) prefetch(nxt);
+#pragma unroll
+        for (int k = 0; k < (int)ITEMS; k++) {
+            if (k * NT < tot) {   // (block-uniform)
+                const u32 i = k * NT + tid;
+                const bool in = i < tot;
+                u32 s = 0, e = 0, mine = 0;
+                if (in) {
+                    s = s_off[bp[k] & 0xfffu];
+                    e = s_off[(bp[k] & 0xfffu) + 1];
+                    mine = s_low[bp[k] >> 20];
+                }
+                const u32 cnt = e - s;
+                u32 lt = 0, eq = 0;
+                {
+                    const u32 y0 = s_low[s], y1 = s_low[s + 1], y2 = s_low[s + 2], y3 = s_low[s + 3];
+                    lt += (u32)(cnt > 0 && y0 < mine) + (u32)(cnt > 1 && y1 < mine) + (u32)(cnt > 2 && y2 < mine) + (u32)(cnt > 3 && y3 < mine);
+                    eq += (u32)(cnt > 0 && y0 == mine) + (u32)(cnt > 1 && y1 == mine) + (u32)(cnt > 2 && y2 == mine) + (u32)(cnt > 3 && y3 == mine);
+                }
+                if (__any(cnt > 4)) {
+                    for (u32 u = s + 4; __any(u < e); u++) {
+                        if (u < e) {
+                            const u32 y = s_low[u];
+                            lt += y < mine;
+                            eq += y == mine;
+                        }
+                    }
+                }
+                u32 rank = s + lt;
+                const bool td = in && eq > 1;   // equal on all key bits: tied beyond the key
+                const u64 tb = __ballot(td);
+                if (tb) {
+                    // (rare) members of an equal run take consecutive places in the order of their bin slots
+                    if (td)
+                        for (u32 u = s; u < (bp[k] >> 20); u++) rank += s_low[u] == mine;
+                    u32 base = 0;
+                    if (l == 0) base = atomicAdd(rctr, (u32)__popcll(tb));
+                    base = __shfl(base, 0, 64);
+                    if (td) {
+                        const u32 o = base + (u32)__popcll(tb & lanemask_lt());
+                        if (o < a.rcap) {
+                            const u32 nb = (bp[k] & 0xfffu) / MSDK_BPC;   // which of the chunk's children
+                            a.out_slot[rbase + o] = start + rank;
+                            a.out_idx[rbase + o] = mine;
+                            a.out_khi[rbase + o] = (q << 8) | (nb == 0 ? c0 : (nb == 1 ? l1 : l2));   // key bits 63..40
+                            a.out_grp[rbase + o] = start + s + lt;
+                        }
+                    }
+                }
+                if (in) s_L[rank + lsh] = (u8)((bp[k] >> 12) & 0xffu);
+            }
+        }
+        lds_barrier();
+        MSDK_T(7);
+        {
+            // the last column is all that leaves: whole 32-bit words where the chunk covers them, bytes at its two ends
+            const u32 nw = (lsh + tot + 3u) >> 2;
+            u8 *Lw = a.L + (start - lsh);
+            const u32 *sw = reinterpret_cast<const u32 *>(s_L);
+            for (u32 w = tid; w < nw; w += NT) {
+                const u32 lo = 4u * w, hi = lo + 4u;
+                if (lo >= lsh && hi <= lsh + tot) {
+                    reinterpret_cast<u32 *>(Lw)[w] = sw[w];
+                } else {
+                    for (u32 x = lo; x < hi; x++)
+                        if (x >= lsh && x < lsh + tot) Lw[x] = s_L[x];
+                }
+            }
+        }
+#ifdef MSDK_PROFILE
+        MSDK_T(8);
+        for (int i = 0; i < 8; i++) acc[i] += tq[i + 1] - tq[i];
+        acc[8] += 1; acc[9] += tot;
+#endif
+        cur = nxt;
+    }
+#ifdef MSDK_PROFILE
+    if (tid == 0 && (q & 255u) == 43u) {
+        u64 *dbg = reinterpret_cast<u64 *>(a.counters) - 12 + 112;   // (counters = d_scalars + 12 words of 64 bits)
+        for (int i = 0; i < 10; i++) atomicAdd((unsigned long long *)&dbg[i], (unsigned long long)acc[i]);
+    }
+#endif
+}
+
 #endif  // __HIPCC__

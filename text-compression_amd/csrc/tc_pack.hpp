@@ -16,6 +16,7 @@
 // both with an escape list of (run index, count) pairs.
 #pragma once
 #include "tc_common.hpp"
+#include "tc_mtf.hpp"
 
 #define PK_NT 256
 #define PK_RPT 16                       // runs per thread per sub-tile
@@ -647,6 +648,286 @@ __global__ __launch_bounds__(RN_NT, 4) void rle_blk_kernel(RleBlkArgs a) {
                         if (c[k] != LONGC) a.counts[g] = c[k];
                         a.vals[g] = (u16)v[k];
                     }
+                }
+            }
+        }
+    }
+}
+
+// ---- MTF and RLE of a DNA-like record in ONE kernel (sigma <= 8, the fused encode) ------------------------------
+// seqToMTF (MTF/Internal.hs:128-175) as mtf_nib_apply_kernel<.., SMALL> does it -- a tile of 32768 symbols, a lane per
+// 128-symbol chunk, the list in one 32-bit register, the tile's incoming list by a backward scan of the last column --
+// and then, with the tile's ranks still in LDS, seqToRLE of them (RLE/Internal.hs:104-153) as rle_blk_kernel does it:
+// the index stream (1 GiB written, 1 GiB read again per 1 GiB record) never exists.  The successor of a tile's last
+// rank is the rank of the next tile's first symbol in this tile's OUTGOING list (incoming list, then the tile's
+// summary).  Tiles come by ticket; the last run end before a tile and the runs before it by look-back (the ranks in
+// front of the tile are in no memory, so the direct probe of rle_blk_kernel is not available here).
+struct MtfRleArgs {
+    BwtAcc acc;
+    u64 N;
+    Lut8 lut;
+    u32 sigma;
+    u32 *flag;       // raised when a tile's incoming list could not be recovered by the backward scan
+    u32 *counts;
+    u16 *vals;
+    u64 cap;
+    u64 *status_a, *status_b;
+    u32 *ticket;
+    u64 *scalars;    // [2] total runs
+    u32 *err;
+    u32 ntiles;
+    u32 wide;
+    u32 diag;        // TC_MTFRLE_DIAG (measurement only): 1 no run stores, 2 no MTF pass, 4 no block scan / replay
+    u32 stagger;     // the first blocks of a CU start apart: mode | sleeps << 8
+};
+
+// One pass over a lane's chunk from the identity list, sigma <= 8.  The image holds code * 0x11 per symbol (0xFF: past
+// the end), so v_perm of the loaded word is the code in all eight nibbles; the list is one 32-bit register; a first
+// occurrence is a rank not below the number of codes met so far (the unmet ones keep their order behind the met ones).
+// The ranks go back IN PLACE as nibbles (symbol i of the chunk: nibble i & 7 of word i >> 3) -- half the image, and
+// the form the run detection below wants.  evc / evp: code and chunk position of the first occurrences, k4 = 4 * count.
+template <bool PADS>
+__device__ __forceinline__ void nib8_chunk_ranks(u32 *cw, u32 &lst, u32 &seen, u32 &evc, u64 &evp, u32 &k4) {
+#pragma unroll 2
+    for (int q = 0; q < MTF_CH / 8; q++) {
+        const u32 w0 = cw[2 * q], w1 = cw[2 * q + 1];
+        u32 nw = 0;
+#pragma unroll
+        for (int b = 0; b < 8; b++) {
+            const u32 wv = b < 4 ? w0 : w1;
+            if (PADS && ((wv >> (8 * (b & 3))) & 0xffu) == 0xffu) continue;
+            const u32 bc = __builtin_amdgcn_perm(wv, wv, 0x01010101u * (u32)(b & 3));
+            const u32 x = bc ^ lst;
+            const u32 t = (x - 0x11111111u) & ~x & 0x88888888u;
+            const u32 f = (u32)__builtin_ctz(t);           // 4 * rank + 3
+            const u32 sh = f & 28u;
+            if (f > k4) {
+                const u32 c = bc & 7u;
+                seen |= 1u << c;
+                evc |= c << k4;
+                evp |= (u64)(8 * q + b) << (2 * k4);
+                k4 += 4;
+            }
+            const u32 hm = 0xFFFFFFF0u << sh;              // the nibbles behind the rank stay
+            const u32 al = __builtin_amdgcn_alignbit(lst, bc, 28);   // (list << 4) | code
+            lst = (lst & hm) | (al & ~hm);
+            nw |= b == 0 ? sh >> 2 : sh << (4 * b - 2);
+        }
+        cw[q] = nw;
+    }
+}
+
+__global__ __launch_bounds__(MTF_NT) void mtf_rle_kernel(MtfRleArgs a) {
+    constexpr int NW = MTF_NT / 64, SUBS = MTF_TILE / (MTF_NT * 16), NSEG = SUBS * NW;
+    static_assert(NSEG <= 64 && MTF_NT * MTF_STRIDE >= MTF_TILE + 16, "segment scan by one wave; the code image doubles as run staging");
+    __shared__ __attribute__((aligned(16))) u8 s_code[MTF_NT * MTF_STRIDE];
+    __shared__ u8 s_lut[260], s_lut11[260];
+    __shared__ NibSumm s_w[NW];
+    __shared__ u64 s_in;
+    __shared__ u32 s_next, s_tile;
+    __shared__ u32 s_last[NSEG], s_carry[NSEG], s_sum[NSEG];
+    __shared__ u64 s_pref;
+    const int tid = threadIdx.x, lane = lane_id(), w = tid >> 6;
+    const u64 N = a.N;
+    for (int i = tid; i < 257; i += MTF_NT) {
+        s_lut[i] = a.lut.v[i];
+        s_lut11[i] = (u8)((a.lut.v[i] & 7u) * 0x11u);
+    }
+    if (a.stagger && blockIdx.x < 1024u) {
+        const u32 mode = a.stagger & 255u, unit = a.stagger >> 8;
+        const u32 k = mode == 1 ? (blockIdx.x >> 8) & 3u : (mode == 2 ? blockIdx.x & 3u : (mode == 3 ? (blockIdx.x >> 3) & 3u : (blockIdx.x * 2654435761u) >> 30));
+        for (u32 i = 0; i < k * unit; i++) __builtin_amdgcn_s_sleep(127);
+    }
+    if (tid == 0) s_tile = atomicAdd(a.ticket, 1u);
+    __syncthreads();
+    const u32 tile = s_tile;
+    if (tile >= a.ntiles) return;
+    const u64 base = (u64)tile * MTF_TILE;
+    const bool edge = base + MTF_TILE >= N;
+    nib_stage(a.acc, N, base, s_lut11, s_code);
+    __syncthreads();
+    if (tid < 64) {
+        u64 l0 = NIB_IDENT;
+        const bool ok = nib_list_before(a.acc, base, a.sigma, s_lut, &l0);
+        if (tid == 0) {
+            s_in = l0;
+            if (!ok) atomicOr(a.flag, 1u);
+        }
+    }
+    // ---- MTF: one pass per chunk from the identity list; first occurrences replayed from the true incoming list
+    u32 *cw = reinterpret_cast<u32 *>(s_code + tid * MTF_STRIDE);
+    NibSumm mine{NIB_IDENT, 0u};
+    u64 evp = 0;
+    u32 evc = 0, k4 = 0;
+    {
+        u32 lst = (u32)NIB_IDENT, seen = 0;
+        if (a.diag & 2u) seen = 1;
+        else if (edge) nib8_chunk_ranks<true>(cw, lst, seen, evc, evp, k4);
+        else nib8_chunk_ranks<false>(cw, lst, seen, evc, evp, k4);
+        mine.perm = (NIB_IDENT & 0xFFFFFFFF00000000ull) | (u64)lst;
+        mine.mask = seen;
+    }
+    NibSumm agg{NIB_IDENT, 0u};
+    const NibSumm exc = (a.diag & 4u) ? mine : nib_block_excl(mine, s_w, &agg);
+    if (a.diag & 4u) __syncthreads();
+    {
+        u64 list = nib_combine(NibSumm{s_in, 0u}, exc).perm;
+        for (u32 e4 = 0; e4 < k4; e4 += 4) {
+            const u32 c = (evc >> e4) & 15u;
+            const u32 pp = (u32)(evp >> (2 * e4)) & 255u;
+            const u32 pos = nib_find(list, c);
+            list = nib_front(list, pos, c);
+            const u32 shf = 4u * (pp & 7u);
+            cw[pp >> 3] = (cw[pp >> 3] & ~(15u << shf)) | (pos << shf);
+        }
+    }
+    if (tid == 0) {   // the rank the next tile's first symbol will get: the successor of this tile's last rank
+        u32 nx = 0x100u;
+        if (base + MTF_TILE < N) {
+            const u64 outl = nib_combine(NibSumm{s_in, 0u}, agg).perm;
+            nx = nib_find(outl, (u32)s_lut[a.acc(base + MTF_TILE) + 1]);
+        }
+        s_next = nx;
+    }
+    __syncthreads();
+    // ---- RLE of the tile's ranks (rle_blk_kernel's phases on nibbles; a thread owns 16 consecutive ranks per sub-tile)
+    auto nibw = [&](u32 p) -> const u32 * {
+        return reinterpret_cast<const u32 *>(s_code + (p / MTF_CH) * MTF_STRIDE + (p % MTF_CH) / 2);
+    };
+    u32 n0[SUBS], n1[SUBS], E0[SUBS], E1[SUBS], pv[SUBS];
+    u32 hasmask = 0;
+#pragma unroll
+    for (int s = 0; s < SUBS; s++) {
+        const u32 pl = (u32)s * (MTF_NT * 16) + (u32)tid * 16;       // tile-local position of the group
+        const u64 p0 = base + pl;
+        const u32 *gp = nibw(pl);
+        const u32 a0 = gp[0], a1 = gp[1];
+        const u32 nx = pl + 16 < MTF_TILE ? nibw(pl + 16)[0] : s_next;
+        const u32 d0 = a0 ^ __builtin_amdgcn_alignbit(a1, a0, 4), d1 = a1 ^ __builtin_amdgcn_alignbit(nx, a1, 4);
+        u32 e0 = (((d0 & 0x77777777u) + 0x77777777u) | d0) & 0x88888888u;   // bit 4 i + 3: rank i differs from its successor
+        u32 e1 = (((d1 & 0x77777777u) + 0x77777777u) | d1) & 0x88888888u;
+        if (pl + 16 == MTF_TILE && (s_next & 0x100u)) e1 |= 0x80000000u;      // no successor: the stream ends with this tile
+        if (edge) {
+            const u32 nv = p0 >= N ? 0u : (N - p0 >= 16 ? 16u : (u32)(N - p0));
+            const u32 v0 = nv >= 8 ? 8u : nv, v1 = nv - v0;
+            e0 &= v0 >= 8 ? 0xffffffffu : ((1u << (4 * v0)) - 1u);
+            e1 &= v1 >= 8 ? 0xffffffffu : ((1u << (4 * v1)) - 1u);
+            if (nv && N - p0 <= 16) {                                          // the last position ends its run
+                if (nv <= 8) e0 |= 8u << (4 * (nv - 1));
+                else e1 |= 8u << (4 * (nv - 9));
+            }
+        }
+        n0[s] = a0; n1[s] = a1;
+        E0[s] = e0; E1[s] = e1;
+        const u32 last1 = e1 ? (u32)p0 + 16u - ((u32)__builtin_clz(e1) >> 2)
+                             : (e0 ? (u32)p0 + 8u - ((u32)__builtin_clz(e0) >> 2) : 0u);   // 1 + position of the last end
+        const u64 m = __ballot((e0 | e1) != 0);
+        const u64 pm = m & lanemask_lt();
+        const int src = pm ? 63 - __builtin_clzll(pm) : 0;
+        pv[s] = __shfl(last1, src, 64);
+        if (pm) hasmask |= 1u << s;
+        const u32 wlast = m ? __shfl(last1, 63 - __builtin_clzll(m), 64) : 0u;
+        if (lane == 0) s_last[s * NW + w] = wlast;
+    }
+    __syncthreads();
+    if (w == 0) {
+        const u32 v = lane < NSEG ? s_last[lane] : 0u;
+        const u32 inc = seg_incl_scan<OpMax>(v);
+        const u32 aggl = __shfl(inc, NSEG - 1, 64);
+        u32 ex = __shfl_up(inc, 1, 64);
+        if (lane == 0) ex = 0;
+        const u32 tin = (u32)lb_exclusive<OpMax>(a.status_a, tile, aggl, a.err);
+        if (lane < NSEG) s_carry[lane] = ex > tin ? ex : tin;
+    }
+    u32 cnt[SUBS], inc[SUBS];
+#pragma unroll
+    for (int s = 0; s < SUBS; s++) {
+        cnt[s] = (u32)__popc(E0[s]) + (u32)__popc(E1[s]);
+        inc[s] = wave_incl_sum(cnt[s]);
+        if (lane == 63) s_sum[s * NW + w] = inc[s];
+    }
+    __syncthreads();
+    u32 excl[SUBS], truns;
+    {
+        const u32 v = lane < NSEG ? s_sum[lane] : 0u;
+        const u32 sc = seg_incl_scan<OpSum>(v);
+        truns = __shfl(sc, NSEG - 1, 64);
+#pragma unroll
+        for (int s = 0; s < SUBS; s++) {
+            const int g = s * NW + w;
+            const u32 before = g ? __shfl(sc, g - 1, 64) : 0u;
+            excl[s] = before + inc[s] - cnt[s];
+        }
+    }
+    if (w == 1) {
+        const u64 e = lb_exclusive<OpSum>(a.status_b, tile, (u64)truns, a.err);
+        if (lane == 0) {
+            s_pref = e;
+            if (tile + 1 == a.ntiles) a.scalars[2] = e + truns;
+        }
+    }
+    __syncthreads();   // (also: every thread has its ranks in registers -- the image becomes the run staging area)
+    const u64 e0g = s_pref;
+    const u32 sh = (u32)(e0g & 7u);
+    const u64 gbase = e0g - sh;
+    const u32 lim = gbase >= a.cap ? 0u : (a.cap - gbase > 0xffffffffull ? 0xffffffffu : (u32)(a.cap - gbase));
+    u8 *s_c8 = s_code;
+#pragma unroll
+    for (int s = 0; s < SUBS; s++) {
+        if (!cnt[s]) continue;
+        const u32 p0 = (u32)(base + (u64)s * (MTF_NT * 16) + (u64)tid * 16);
+        const u32 prev = ((hasmask >> s) & 1u) ? pv[s] : s_carry[s * NW + w];
+        const int prel0 = (int)(prev - p0);                // <= 0: the previous end, relative to the group
+        int prel = prel0;
+        const u32 j0 = excl[s] + sh;
+        u32 j = j0;
+#pragma unroll
+        for (int i = 0; i < 16; i++) {
+            const u32 ek = i < 8 ? E0[s] : E1[s], nk = i < 8 ? n0[s] : n1[s];
+            if ((ek >> (4 * (i & 7) + 3)) & 1u) {
+                const u32 c = (u32)(i + 1 - prel);         // (>= 15 only for the group's first run, or bits 0 and 15 alone)
+                prel = i + 1;
+                s_c8[j] = (u8)(((nk >> (4 * (i & 7))) & 15u) | (c << 4));
+                j++;
+            }
+        }
+        const u32 fi = E0[s] ? (u32)__builtin_ctz(E0[s]) >> 2 : 8u + ((u32)__builtin_ctz(E1[s]) >> 2);
+        const u32 firstc = fi + 1u - (u32)prel0;
+        if (firstc >= 15u) {                               // a long run: count nibble 15, the count itself by its owner
+            s_c8[j0] |= 0xF0u;
+            if (j0 < lim) a.counts[gbase + j0] = firstc;
+        }
+        if (E0[s] == 0x8u && E1[s] == 0x80000000u) {
+            s_c8[j0 + 1] |= 0xF0u;
+            if (j0 + 1 < lim) a.counts[gbase + j0 + 1] = 15u;
+        }
+    }
+    __syncthreads();
+    const u32 ngroups = (sh + truns + 7u) >> 3;
+    for (u32 q = tid; q < ngroups; q += MTF_NT) {
+        const u32 lo = 8u * q;
+        const uint2 cwd = *reinterpret_cast<const uint2 *>(s_c8 + lo);
+        const u32 tx = cwd.x & 0xF0F0F0F0u, ty = cwd.y & 0xF0F0F0F0u;
+        // a count nibble of 15  <=>  a zero byte in t ^ 0xF0F0F0F0
+        const u32 zx = tx ^ 0xF0F0F0F0u, zy = ty ^ 0xF0F0F0F0u;
+        const bool any15 = (((zx - 0x01010101u) & ~zx & 0x80808080u) | ((zy - 0x01010101u) & ~zy & 0x80808080u)) != 0;
+        const bool plain = a.wide && !any15 && lo >= sh && lo + 8u <= sh + truns && lo + 8u <= lim;
+        if ((a.diag & 1u) && cwd.x != 0x12345678u) continue;
+        if (plain) {
+            uint4 *pc = reinterpret_cast<uint4 *>(a.counts + gbase + lo);
+            pc[0] = make_uint4((cwd.x >> 4) & 15u, (cwd.x >> 12) & 15u, (cwd.x >> 20) & 15u, cwd.x >> 28);
+            pc[1] = make_uint4((cwd.y >> 4) & 15u, (cwd.y >> 12) & 15u, (cwd.y >> 20) & 15u, cwd.y >> 28);
+            *reinterpret_cast<uint4 *>(a.vals + gbase + lo) =
+                make_uint4(__builtin_amdgcn_perm(0u, cwd.x, 0x0c010c00u) & 0x000F000Fu, __builtin_amdgcn_perm(0u, cwd.x, 0x0c030c02u) & 0x000F000Fu,
+                           __builtin_amdgcn_perm(0u, cwd.y, 0x0c010c00u) & 0x000F000Fu, __builtin_amdgcn_perm(0u, cwd.y, 0x0c030c02u) & 0x000F000Fu);
+        } else {
+#pragma unroll
+            for (int k = 0; k < 8; k++) {
+                const u32 bb = ((k < 4 ? cwd.x : cwd.y) >> (8 * (k & 3))) & 255u;
+                const u32 i = lo + (u32)k;
+                if (i >= sh && i < sh + truns && i < lim) {
+                    if ((bb >> 4) != 15u) a.counts[gbase + i] = bb >> 4;
+                    a.vals[gbase + i] = (u16)(bb & 15u);
                 }
             }
         }
