@@ -25,11 +25,14 @@ BUDGETS = {
     "14rle_nib_kernel10RleNibArgs": (128, 0, 4),          # round 3: the fused RLE -> wire-format kernel (2 x 512 threads per CU)
     "15pack_nib_kernel11PackNibArgs": (96, 0, 5),
     "fm_count_kernelILb1EE": (64, 0, 8),                   # round 3: two symbols per lookup
-    "14rle_blk_kernel10RleBlkArgs": (96, 0, 4),            # round 3: blocked RLE of the byte-wide index stream
+    "rle_blk_kernelILb1EE": (96, 0, 4),                    # round 3: blocked RLE of the byte-wide index stream
     "msd_partition_kernelILb0ELb0EE": (128, 0, 4),         # round 3: key-only levels
     "msd_partition_kernelILb1ELb0EE": (128, 16, 4),
     "msd_finish_kernelILi256ELi8ELi4ELi1ELb0ELb0EE": (80, 0, 6),
     "tied_probe_kernelILi3EE": (96, 0, 3),
+    "msd_finish_ko_kernelILi3EE": (80, 0, 6),              # round 3: equal-mass bins, prefetched keys.  NO scratch: a build
+                                                           # of it that spilled (12 bytes) gave wrong tied sets on the GPU
+    "14mtf_rle_kernel10MtfRleArgs": (96, 0, 4),            # round 3: MTF and RLE of a small-alphabet record in one kernel
 }
 
 

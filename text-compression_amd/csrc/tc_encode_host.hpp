@@ -632,6 +632,7 @@ static void sa_run(tc_ctx *ctx, SaBuffers &b, const u8 *d_text, u64 n, u32 *d_sa
                     u64 a1 = 0, a2 = 0, a3 = 0, a4 = 0;
                     for (u32 i = 0; i < fm; i++) { a1 += hk[i]; a2 += hh[i]; a3 += hs[i]; a4 += hg[i]; }
                     fprintf(stderr, "textcomp: tied members: sum klo %llx khi %llx slot %llx grp %llx\n", (unsigned long long)a1, (unsigned long long)a2, (unsigned long long)a3, (unsigned long long)a4);
+                    for (u32 i = 0; i < fm && i < 6; i++) fprintf(stderr, "textcomp:   member %u: klo %08x khi %06x slot %u grp %u\n", i, hk[i], hh[i], hs[i], hg[i]);
                 }
                 if (ok && fm > 0) {
                     tc_memset_async(ctx, b.tp.key, 0, sizeof(u64) << TP_SLOT_BITS);

@@ -1291,24 +1291,25 @@ __global__ __launch_bounds__(256, 6) void msd_finish_ko_kernel(MsdFinishArgs a, 
         run += tot;
         return true;
     };
-    // the keys of a chunk by asm-issued loads (the compiler's wait counts do not see them: the rank phase and the
-    // copy-out of the chunk before run while they are in flight); a slot past the chunk re-reads its first key
+    // the keys of the NEXT chunk are loaded while this one is ranked and copied out (the barriers in between are
+    // LDS-only, so nothing waits for them before their first use); a slot past the chunk re-reads its first key.
+    // Plain loads, not asm-issued ones: the register allocator is free to MOVE the destination of an asm load
+    // before its data has arrived (it did, in one build of this kernel: stale register contents became keys).
     u64 nk[ITEMS];
     auto prefetch = [&](const Chunk &k) {
         const u64 *kp = a.keys + pstart + k.off;
 #pragma unroll
         for (int j = 0; j < (int)ITEMS; j++) {
             const u32 i = j * NT + tid;
-            const u32 bo = (i < k.tot ? i : 0u) * 8u;
-            asm volatile("global_load_dwordx2 %0, %1, %2" : "=v"(nk[j]) : "v"(bo), "s"(kp) : "memory");
+            nk[j] = kp[i < k.tot ? i : 0u];
         }
     };
     Chunk cur, nxt;
     bool have = walk(cur);
     if (have) prefetch(cur);
 #ifdef MSDK_PROFILE
-    u64 tq[10], acc[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-#define MSDK_T(i) tq[i] = __builtin_readcyclecounter()
+    u32 tq[10], acc[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+#define MSDK_T(i) tq[i] = (u32)__builtin_readcyclecounter()
 #else
 #define MSDK_T(i)
 #endif
@@ -1317,10 +1318,6 @@ __global__ __launch_bounds__(256, 6) void msd_finish_ko_kernel(MsdFinishArgs a, 
         const u32 c0 = cur.c0, l1 = cur.l1, l2 = cur.l2, tot = cur.tot, start = pstart + cur.off;
         const u32 lsh = (u32)((uintptr_t)(a.L + start) & 3u);   // where the chunk starts inside its first word of L
         u32 klo[ITEMS], khi[ITEMS];
-        asm volatile("s_waitcnt vmcnt(0)"
-                     : "+v"(nk[0]), "+v"(nk[1]), "+v"(nk[2]), "+v"(nk[3]), "+v"(nk[4]), "+v"(nk[5]), "+v"(nk[6]), "+v"(nk[7])
-                     :
-                     : "memory");
 #pragma unroll
         for (int k = 0; k < (int)ITEMS; k++) {
             klo[k] = (u32)nk[k];

@@ -4,7 +4,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(os.path.dirname(_HERE), "libtextcomp.so")
+LIB_PATH = os.environ.get("TEXTCOMP_LIB") or os.path.join(os.path.dirname(_HERE), "libtextcomp.so")   # (TEXTCOMP_LIB: a variant build, for A/B runs)
 
 TC_OK = 0
 TC_ERR_ARG, TC_ERR_CAPACITY, TC_ERR_MALFORMED, TC_ERR_HIP, TC_ERR_OOM, TC_ERR_INTERNAL, TC_ERR_NCCL = (
