@@ -359,6 +359,42 @@ __global__ __launch_bounds__(MTF_NT) void mtf_nib_scan_kernel(u64 *t_perm, u32 *
     }
 }
 
+// One pass over a lane's chunk from the identity list, sigma <= 8.  The image holds code * 0x11 per symbol (0xFF: past
+// the end), so v_perm of the loaded word is the code in all eight nibbles; the list is one 32-bit register; a first
+// occurrence is a rank not below the number of codes met so far (the unmet ones keep their order behind the met ones).
+// The ranks go back IN PLACE as nibbles (symbol i of the chunk: nibble i & 7 of word i >> 3) -- half the image, and
+// the form the run detection below wants.  evc / evp: code and chunk position of the first occurrences, k4 = 4 * count.
+template <bool PADS>
+__device__ __forceinline__ void nib8_chunk_ranks(u32 *cw, u32 &lst, u32 &seen, u32 &evc, u64 &evp, u32 &k4) {
+#pragma unroll 2
+    for (int q = 0; q < MTF_CH / 8; q++) {
+        const u32 w0 = cw[2 * q], w1 = cw[2 * q + 1];
+        u32 nw = 0;
+#pragma unroll
+        for (int b = 0; b < 8; b++) {
+            const u32 wv = b < 4 ? w0 : w1;
+            if (PADS && ((wv >> (8 * (b & 3))) & 0xffu) == 0xffu) continue;
+            const u32 bc = __builtin_amdgcn_perm(wv, wv, 0x01010101u * (u32)(b & 3));
+            const u32 x = bc ^ lst;
+            const u32 t = (x - 0x11111111u) & ~x & 0x88888888u;
+            const u32 f = (u32)__builtin_ctz(t);           // 4 * rank + 3
+            const u32 sh = f & 28u;
+            if (f > k4) {
+                const u32 c = bc & 7u;
+                seen |= 1u << c;
+                evc |= c << k4;
+                evp |= (u64)(8 * q + b) << (2 * k4);
+                k4 += 4;
+            }
+            const u32 hm = 0xFFFFFFF0u << sh;              // the nibbles behind the rank stay
+            const u32 al = __builtin_amdgcn_alignbit(lst, bc, 28);   // (list << 4) | code
+            lst = (lst & hm) | (al & ~hm);
+            nw |= b == 0 ? sh >> 2 : sh << (4 * b - 2);
+        }
+        cw[q] = nw;
+    }
+}
+
 // FASTIN: the tile's incoming list is recovered in-kernel by nib_list_before (no summary /
 // scan launches); `flag` is raised when that fails and the host reruns the 3-kernel path.
 // SMALL: sigma <= 8 -- the pass over the chunk keeps its list in 32 bits (nib8_find / nib8_front)
@@ -371,10 +407,14 @@ __global__ __launch_bounds__(MTF_NT) void mtf_nib_apply_kernel(Acc acc, u64 N,
     __shared__ __attribute__((aligned(16))) u8 s_code[MTF_NT * MTF_STRIDE];
     __shared__ u8 s_lut[260];
     __shared__ NibSumm s_w[MTF_NT / 64];
-    for (int i = threadIdx.x; i < 257; i += MTF_NT) s_lut[i] = lut.v[i];
+    __shared__ u8 s_lut11[SMALL ? 260 : 4];   // SMALL: the image holds code * 0x11 (nib8_chunk_ranks)
+    for (int i = threadIdx.x; i < 257; i += MTF_NT) {
+        s_lut[i] = lut.v[i];
+        if (SMALL) s_lut11[i] = (u8)((lut.v[i] & 7u) * 0x11u);
+    }
     __syncthreads();
     const u64 base = (u64)blockIdx.x * MTF_TILE;
-    nib_stage(acc, N, base, s_lut, s_code);
+    nib_stage(acc, N, base, SMALL ? s_lut11 : s_lut, s_code);
     __syncthreads();
     // true incoming list of this lane's chunk: tile's incoming list, then the
     // block-local prefix applied to it.  Wave 0 recovers the tile's list FIRST (a global round
@@ -399,30 +439,14 @@ __global__ __launch_bounds__(MTF_NT) void mtf_nib_apply_kernel(Acc acc, u64 N,
     u64 ev_code = 0, ev_pos0 = 0, ev_pos1 = 0;
     u32 nev = 0;
     if (SMALL) {
-        u32 lst = (u32)NIB_IDENT, seen = 0, evc = 0;   // list, codes met, first occurrences (code per nibble: <= 8)
-#pragma unroll 4
-        for (int q = 0; q < MTF_CH / 4; q++) {
-            u32 wv = cw[q], ov = 0;
-#pragma unroll
-            for (int b = 0; b < 4; b++) {
-                const u32 c = (wv >> (8 * b)) & 0xff;
-                if (c != 0xFF) {
-                    const u32 pos = nib8_find(lst, c);
-                    lst = nib8_front(lst, pos, c);
-                    ov |= pos << (8 * b);
-                    if (!((seen >> c) & 1u)) {
-                        seen |= 1u << c;
-                        evc |= c << (4 * nev);
-                        ev_pos0 |= (u64)(4 * q + b) << (8 * nev);
-                        nev++;
-                    }
-                }
-            }
-            cw[q] = ov;
-        }
+        // (the ranks come back as NIBBLES, symbol i of the chunk in nibble i & 7 of word i >> 3)
+        u32 lst = (u32)NIB_IDENT, seen = 0, evc = 0, k4 = 0;
+        if (base + MTF_TILE >= N) nib8_chunk_ranks<true>(cw, lst, seen, evc, ev_pos0, k4);
+        else nib8_chunk_ranks<false>(cw, lst, seen, evc, ev_pos0, k4);
         mine.perm = (NIB_IDENT & 0xFFFFFFFF00000000ull) | (u64)lst;
         mine.mask = seen;
         ev_code = evc;
+        nev = k4 >> 2;
     } else {
 #pragma unroll 4
     for (int q = 0; q < MTF_CH / 4; q++) {
@@ -458,10 +482,38 @@ __global__ __launch_bounds__(MTF_NT) void mtf_nib_apply_kernel(Acc acc, u64 N,
             const u32 pp = (u32)((e < 8 ? ev_pos0 >> (8 * e) : ev_pos1 >> (8 * (e - 8))) & 255u);
             const u32 pos = nib_find(list, c);
             list = nib_front(list, pos, c);
-            cb[pp] = (u8)pos;
+            if (SMALL) {
+                const u32 shf = 4u * (pp & 7u);
+                cw[pp >> 3] = (cw[pp >> 3] & ~(15u << shf)) | (pos << shf);
+            } else {
+                cb[pp] = (u8)pos;
+            }
         }
     }
     __syncthreads();
+    if constexpr (SMALL) {
+        // the nibble image back to one byte per rank: 16 ranks (two words of the image) per store
+        static_assert(sizeof(OT) == 1, "the 32-bit list is for the byte-wide index stream");
+        auto spread = [](u32 h) -> u32 {   // four nibbles (bits 0..15) -> four bytes
+            u32 x = (h | (h << 8)) & 0x00FF00FFu;
+            return (x | (x << 4)) & 0x0F0F0F0Fu;
+        };
+        const bool al = (((uintptr_t)(idx + base)) & 15) == 0;
+        for (u32 g = threadIdx.x; g < MTF_TILE / 16; g += MTF_NT) {
+            const u32 p = 16 * g;
+            const u32 *sc = reinterpret_cast<const u32 *>(s_code + (p / MTF_CH) * MTF_STRIDE + (p % MTF_CH) / 2);
+            const u32 n0 = sc[0], n1 = sc[1];
+            const uint4 o = make_uint4(spread(n0 & 0xffffu), spread(n0 >> 16), spread(n1 & 0xffffu), spread(n1 >> 16));
+            if (al && base + p + 16 <= N) {
+                reinterpret_cast<uint4 *>(idx + base)[g] = o;
+            } else {
+                const u32 ow[4] = {o.x, o.y, o.z, o.w};
+                for (u32 q = 0; q < 16; q++)
+                    if (base + p + q < N) idx[base + p + q] = (OT)((ow[q >> 2] >> (8 * (q & 3))) & 0xffu);
+            }
+        }
+        return;
+    }
     if constexpr (sizeof(OT) == 1) {
         // byte stream (fused encode): 16 ranks per store, straight from the LDS image
         if ((((uintptr_t)(idx + base)) & 15) == 0) {

@@ -681,42 +681,6 @@ struct MtfRleArgs {
     u32 stagger;     // the first blocks of a CU start apart: mode | sleeps << 8
 };
 
-// One pass over a lane's chunk from the identity list, sigma <= 8.  The image holds code * 0x11 per symbol (0xFF: past
-// the end), so v_perm of the loaded word is the code in all eight nibbles; the list is one 32-bit register; a first
-// occurrence is a rank not below the number of codes met so far (the unmet ones keep their order behind the met ones).
-// The ranks go back IN PLACE as nibbles (symbol i of the chunk: nibble i & 7 of word i >> 3) -- half the image, and
-// the form the run detection below wants.  evc / evp: code and chunk position of the first occurrences, k4 = 4 * count.
-template <bool PADS>
-__device__ __forceinline__ void nib8_chunk_ranks(u32 *cw, u32 &lst, u32 &seen, u32 &evc, u64 &evp, u32 &k4) {
-#pragma unroll 2
-    for (int q = 0; q < MTF_CH / 8; q++) {
-        const u32 w0 = cw[2 * q], w1 = cw[2 * q + 1];
-        u32 nw = 0;
-#pragma unroll
-        for (int b = 0; b < 8; b++) {
-            const u32 wv = b < 4 ? w0 : w1;
-            if (PADS && ((wv >> (8 * (b & 3))) & 0xffu) == 0xffu) continue;
-            const u32 bc = __builtin_amdgcn_perm(wv, wv, 0x01010101u * (u32)(b & 3));
-            const u32 x = bc ^ lst;
-            const u32 t = (x - 0x11111111u) & ~x & 0x88888888u;
-            const u32 f = (u32)__builtin_ctz(t);           // 4 * rank + 3
-            const u32 sh = f & 28u;
-            if (f > k4) {
-                const u32 c = bc & 7u;
-                seen |= 1u << c;
-                evc |= c << k4;
-                evp |= (u64)(8 * q + b) << (2 * k4);
-                k4 += 4;
-            }
-            const u32 hm = 0xFFFFFFF0u << sh;              // the nibbles behind the rank stay
-            const u32 al = __builtin_amdgcn_alignbit(lst, bc, 28);   // (list << 4) | code
-            lst = (lst & hm) | (al & ~hm);
-            nw |= b == 0 ? sh >> 2 : sh << (4 * b - 2);
-        }
-        cw[q] = nw;
-    }
-}
-
 __global__ __launch_bounds__(MTF_NT) void mtf_rle_kernel(MtfRleArgs a) {
     constexpr int NW = MTF_NT / 64, SUBS = MTF_TILE / (MTF_NT * 16), NSEG = SUBS * NW;
     static_assert(NSEG <= 64 && MTF_NT * MTF_STRIDE >= MTF_TILE + 16, "segment scan by one wave; the code image doubles as run staging");
