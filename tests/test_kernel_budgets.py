@@ -29,7 +29,7 @@ BUDGETS = {
     "msd_partition_kernelILb0ELb0EE": (128, 0, 4),         # round 3: key-only levels
     "msd_partition_kernelILb1ELb0EE": (128, 16, 4),
     "msd_finish_kernelILi256ELi8ELi4ELi1ELb0ELb0EE": (80, 0, 6),
-    "tied_probe_kernelILi3EE": (96, 0, 3),
+    "tied_probe_kernelILi3EE": (128, 0, 3),               # (LDS holds 3 workgroups per CU; the next tile's text sits in 20 registers)
     "msd_finish_ko_kernelILi3EE": (80, 0, 6),              # round 3: equal-mass bins, prefetched keys.  NO scratch: a build
                                                            # of it that spilled (12 bytes) gave wrong tied sets on the GPU
     "14mtf_rle_kernel10MtfRleArgs": (96, 0, 4),            # round 3: MTF and RLE of a small-alphabet record in one kernel

@@ -268,4 +268,8 @@ __device__ __forceinline__ u64 lb_exclusive(u64 *status, u32 tile, u64 aggregate
     return excl;
 }
 
+// LDS-only barrier: orders the workgroup's LDS traffic and leaves global loads in flight -- a __syncthreads() waits
+// for every memory operation the compiler knows of, so a prefetch issued before it is waited for right there.
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
 #endif  // __HIPCC__

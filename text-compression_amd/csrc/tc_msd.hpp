@@ -1226,9 +1226,6 @@ __global__ __launch_bounds__(256) void msd_finish_lut_kernel(const u32 *__restri
     out->c[t] = c16 > 65535 ? 65535u : (u32)c16;
 }
 
-// LDS-only barrier: orders the workgroup's LDS traffic and leaves global loads in flight (a __syncthreads() waits for
-// every memory operation the compiler knows of, and its vmcnt(0) also waits for the asm-issued prefetch below)
-__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
 template <int CH>
 __global__ __launch_bounds__(256, 6) void msd_finish_ko_kernel(MsdFinishArgs a, const MsdFinishLut *__restrict__ lut) {

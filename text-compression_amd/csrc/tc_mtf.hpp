@@ -182,10 +182,33 @@ __device__ __forceinline__ void nib_stage(Acc acc, u64 N, u64 base, const u8 *s_
     }
 }
 // (L, primary): 16 bytes per lane per load, codes written as 4 dwords into the padded image
-template <>
-__device__ __forceinline__ void nib_stage<BwtAcc>(BwtAcc acc, u64 N, u64 base, const u8 *s_lut, u8 *s_code) {
+struct NibNoHook { __device__ __forceinline__ void operator()() const {} };
+// `mid` runs between a tile's loads and their conversion (its own memory latency then overlaps theirs)
+template <class Mid>
+__device__ __forceinline__ void nib_stage_hook(BwtAcc acc, u64 N, u64 base, const u8 *s_lut, u8 *s_code, Mid mid) {
     const u8 *src = acc.L + base;
-    if ((((uintptr_t)src) & 15) == 0) {
+    if ((((uintptr_t)src) & 15) == 0 && base + MTF_TILE <= N) {
+        // a tile inside the record: ALL of a thread's loads first, then the conversions (a load per loop turn, each
+        // waited for before the next is issued, was 8 memory latencies in a row: 12 of a tile's ~34 us)
+        constexpr int NL = MTF_TILE / 16 / MTF_NT;
+        uint4 v[NL];
+#pragma unroll
+        for (int i = 0; i < NL; i++) v[i] = reinterpret_cast<const uint4 *>(src)[i * MTF_NT + threadIdx.x];
+        mid();
+#pragma unroll
+        for (int i = 0; i < NL; i++) {
+            const u32 p0 = (u32)(i * MTF_NT + threadIdx.x) * 16;
+            const u32 x[4] = {v[i].x, v[i].y, v[i].z, v[i].w};
+            u32 out[4];
+#pragma unroll
+            for (int q = 0; q < 4; q++)
+                out[q] = (u32)s_lut[(x[q] & 255) + 1] | ((u32)s_lut[((x[q] >> 8) & 255) + 1] << 8) |
+                         ((u32)s_lut[((x[q] >> 16) & 255) + 1] << 16) | ((u32)s_lut[(x[q] >> 24) + 1] << 24);
+            u32 *dst = reinterpret_cast<u32 *>(s_code + (p0 / MTF_CH) * MTF_STRIDE + (p0 % MTF_CH));
+            dst[0] = out[0]; dst[1] = out[1]; dst[2] = out[2]; dst[3] = out[3];
+        }
+    } else if ((((uintptr_t)src) & 15) == 0) {
+        mid();
         for (u32 c = threadIdx.x; c < MTF_TILE / 16; c += MTF_NT) {
             const u32 p0 = c * 16;
             const u64 j0 = base + p0;
@@ -205,6 +228,7 @@ __device__ __forceinline__ void nib_stage<BwtAcc>(BwtAcc acc, u64 N, u64 base, c
             dst[0] = out[0]; dst[1] = out[1]; dst[2] = out[2]; dst[3] = out[3];
         }
     } else {
+        mid();
         for (u32 p = threadIdx.x; p < MTF_TILE; p += MTF_NT) {
             u64 j = base + p;
             s_code[(p / MTF_CH) * MTF_STRIDE + (p % MTF_CH)] = j < N ? s_lut[(u32)src[p] + 1] : (u8)0xFF;
@@ -218,6 +242,11 @@ __device__ __forceinline__ void nib_stage<BwtAcc>(BwtAcc acc, u64 N, u64 base, c
             s_code[(p / MTF_CH) * MTF_STRIDE + (p % MTF_CH)] = s_lut[0];
         }
     }
+}
+
+template <>
+__device__ __forceinline__ void nib_stage<BwtAcc>(BwtAcc acc, u64 N, u64 base, const u8 *s_lut, u8 *s_code) {
+    nib_stage_hook(acc, N, base, s_lut, s_code, NibNoHook{});
 }
 
 __device__ __forceinline__ NibSumm nib_chunk_summary(const u8 *s_code) {
@@ -414,20 +443,27 @@ __global__ __launch_bounds__(MTF_NT) void mtf_nib_apply_kernel(Acc acc, u64 N,
     }
     __syncthreads();
     const u64 base = (u64)blockIdx.x * MTF_TILE;
-    nib_stage(acc, N, base, SMALL ? s_lut11 : s_lut, s_code);
-    __syncthreads();
-    // true incoming list of this lane's chunk: tile's incoming list, then the
-    // block-local prefix applied to it.  Wave 0 recovers the tile's list FIRST (a global round
-    // trip) while the other waves already summarise their chunks; the barriers of the block scan
-    // publish it.
+    // true incoming list of this lane's chunk: tile's incoming list, then the block-local prefix applied to it.
+    // Wave 0 recovers the tile's list (a global round trip or two) while the tile's own loads are in flight (a last
+    // column: between its loads and their conversion); the barriers publish it.
     __shared__ u64 s_in;
-    if (FASTIN && threadIdx.x < 64) {
-        u64 l0 = NIB_IDENT;
-        bool ok = nib_list_before(acc, base, sigma, s_lut, &l0);
-        if (threadIdx.x == 0) {
-            s_in = l0;
-            if (!ok) atomicOr(flag, 1u);
+    auto list_in = [&]() {
+        if (FASTIN && threadIdx.x < 64) {
+            u64 l0 = NIB_IDENT;
+            bool ok = nib_list_before(acc, base, sigma, s_lut, &l0);
+            if (threadIdx.x == 0) {
+                s_in = l0;
+                if (!ok) atomicOr(flag, 1u);
+            }
         }
+    };
+    if constexpr (std::is_same<Acc, BwtAcc>::value) {
+        nib_stage_hook(acc, N, base, SMALL ? s_lut11 : s_lut, s_code, list_in);
+        __syncthreads();
+    } else {
+        nib_stage(acc, N, base, SMALL ? s_lut11 : s_lut, s_code);
+        __syncthreads();
+        list_in();
     }
     // ONE full pass per chunk, from the identity list.  The rank of a symbol that already occurred
     // in the chunk does not depend on the incoming list (everything in front of it was used since),

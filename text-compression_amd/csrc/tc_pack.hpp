@@ -320,13 +320,21 @@ __global__ __launch_bounds__(RN_NT, 2) void rle_nib_kernel(RleNibArgs a) {
         uint4 x[RN_SUB];
         u32 E[RN_SUB], pv[RN_SUB];
         u32 hasmask = 0;
+        u32 nxl[RN_SUB];   // (lane 63) the byte behind the wave's last group
+#pragma unroll
+        for (int s = 0; s < RN_SUB; s++) {   // all of the tile's loads first: one memory latency, not RN_SUB in a row
+            const u64 p0 = tbase + (u64)s * RN_SUBSZ + (u64)tid * 16;
+            x[s] = make_uint4(0, 0, 0, 0);
+            nxl[s] = 0;
+            if (!edge || p0 < N) x[s] = *reinterpret_cast<const uint4 *>(a.src + p0);
+            if (lane == 63 && (!edge || p0 + 16 < N)) nxl[s] = (u32)a.src[p0 + 16];
+        }
 #pragma unroll
         for (int s = 0; s < RN_SUB; s++) {
             const u64 p0 = tbase + (u64)s * RN_SUBSZ + (u64)tid * 16;
-            uint4 q = make_uint4(0, 0, 0, 0);
-            if (!edge || p0 < N) q = *reinterpret_cast<const uint4 *>(a.src + p0);
+            const uint4 q = x[s];
             u32 nx = __shfl_down(q.x, 1, 64);
-            if (lane == 63) nx = (!edge || p0 + 16 < N) ? (u32)a.src[p0 + 16] : 0u;
+            if (lane == 63) nx = nxl[s];
             const u32 y0 = __builtin_amdgcn_alignbyte(q.y, q.x, 1), y1 = __builtin_amdgcn_alignbyte(q.z, q.y, 1);
             const u32 y2 = __builtin_amdgcn_alignbyte(q.w, q.z, 1), y3 = __builtin_amdgcn_alignbyte(nx, q.w, 1);
             u32 e = nz_bytes4(q.x ^ y0) | (nz_bytes4(q.y ^ y1) << 4) | (nz_bytes4(q.z ^ y2) << 8) | (nz_bytes4(q.w ^ y3) << 12);
@@ -523,13 +531,21 @@ __global__ __launch_bounds__(RN_NT, 4) void rle_blk_kernel(RleBlkArgs a) {
         uint4 x[RN_SUB];
         u32 E[RN_SUB], pv[RN_SUB];
         u32 hasmask = 0;
+        u32 nxl[RN_SUB];   // (lane 63) the byte behind the wave's last group
+#pragma unroll
+        for (int s = 0; s < RN_SUB; s++) {   // all of the tile's loads first: one memory latency, not RN_SUB in a row
+            const u64 p0 = tbase + (u64)s * RN_SUBSZ + (u64)tid * 16;
+            x[s] = make_uint4(0, 0, 0, 0);
+            nxl[s] = 0;
+            if (!edge || p0 < N) x[s] = *reinterpret_cast<const uint4 *>(a.src + p0);
+            if (lane == 63 && (!edge || p0 + 16 < N)) nxl[s] = (u32)a.src[p0 + 16];
+        }
 #pragma unroll
         for (int s = 0; s < RN_SUB; s++) {
             const u64 p0 = tbase + (u64)s * RN_SUBSZ + (u64)tid * 16;
-            uint4 q = make_uint4(0, 0, 0, 0);
-            if (!edge || p0 < N) q = *reinterpret_cast<const uint4 *>(a.src + p0);
+            const uint4 q = x[s];
             u32 nx = __shfl_down(q.x, 1, 64);
-            if (lane == 63) nx = (!edge || p0 + 16 < N) ? (u32)a.src[p0 + 16] : 0u;
+            if (lane == 63) nx = nxl[s];
             const u32 y0 = __builtin_amdgcn_alignbyte(q.y, q.x, 1), y1 = __builtin_amdgcn_alignbyte(q.z, q.y, 1);
             const u32 y2 = __builtin_amdgcn_alignbyte(q.w, q.z, 1), y3 = __builtin_amdgcn_alignbyte(nx, q.w, 1);
             u32 e = nz_bytes4(q.x ^ y0) | (nz_bytes4(q.y ^ y1) << 4) | (nz_bytes4(q.z ^ y2) << 8) | (nz_bytes4(q.w ^ y3) << 12);
@@ -708,16 +724,21 @@ __global__ __launch_bounds__(MTF_NT) void mtf_rle_kernel(MtfRleArgs a) {
     if (tile >= a.ntiles) return;
     const u64 base = (u64)tile * MTF_TILE;
     const bool edge = base + MTF_TILE >= N;
-    nib_stage(a.acc, N, base, s_lut11, s_code);
-    __syncthreads();
-    if (tid < 64) {
-        u64 l0 = NIB_IDENT;
-        const bool ok = nib_list_before(a.acc, base, a.sigma, s_lut, &l0);
-        if (tid == 0) {
-            s_in = l0;
-            if (!ok) atomicOr(a.flag, 1u);
+    // (wave 0 recovers the tile's incoming list, and thread 0 fetches the symbol behind the tile, while the tile's own
+    // loads are in flight: their latencies overlap instead of following one another)
+    u32 nsym = 0;
+    nib_stage_hook(a.acc, N, base, s_lut11, s_code, [&]() {
+        if (tid == 0 && base + MTF_TILE < N) nsym = (u32)(a.acc(base + MTF_TILE) + 1);
+        if (tid < 64) {
+            u64 l0 = NIB_IDENT;
+            const bool ok = nib_list_before(a.acc, base, a.sigma, s_lut, &l0);
+            if (tid == 0) {
+                s_in = l0;
+                if (!ok) atomicOr(a.flag, 1u);
+            }
         }
-    }
+    });
+    __syncthreads();
     // ---- MTF: one pass per chunk from the identity list; first occurrences replayed from the true incoming list
     u32 *cw = reinterpret_cast<u32 *>(s_code + tid * MTF_STRIDE);
     NibSumm mine{NIB_IDENT, 0u};
@@ -749,7 +770,7 @@ __global__ __launch_bounds__(MTF_NT) void mtf_rle_kernel(MtfRleArgs a) {
         u32 nx = 0x100u;
         if (base + MTF_TILE < N) {
             const u64 outl = nib_combine(NibSumm{s_in, 0u}, agg).perm;
-            nx = nib_find(outl, (u32)s_lut[a.acc(base + MTF_TILE) + 1]);
+            nx = nib_find(outl, (u32)s_lut[nsym]);
         }
         s_next = nx;
     }

@@ -45,9 +45,8 @@ __global__ __launch_bounds__(256) void hist256_kernel(const u8 *__restrict__ tex
     u32 *h = s_h + (threadIdx.x & 63);
     const u64 nvec = ((uintptr_t)text & 15) ? 0 : n / 16;
     const uint4 *tv = reinterpret_cast<const uint4 *>(text);
-    for (u64 i = (u64)blockIdx.x * 256 + threadIdx.x; i < nvec; i += (u64)gridDim.x * 256) {
-        uint4 v = tv[i];
-        u32 x[4] = {v.x, v.y, v.z, v.w};
+    auto tally = [&](const uint4 v) {
+        const u32 x[4] = {v.x, v.y, v.z, v.w};
 #pragma unroll
         for (int q = 0; q < 4; q++) {
             atomicAdd(&h[(x[q] & 255) * 64], 1u);
@@ -55,7 +54,15 @@ __global__ __launch_bounds__(256) void hist256_kernel(const u8 *__restrict__ tex
             atomicAdd(&h[((x[q] >> 16) & 255) * 64], 1u);
             atomicAdd(&h[(x[q] >> 24) * 64], 1u);
         }
+    };
+    // four loads in flight per thread (8 waves per CU, one load each, left the memory latency exposed)
+    const u64 stride = (u64)gridDim.x * 256;
+    u64 i = (u64)blockIdx.x * 256 + threadIdx.x;
+    for (; i + 3 * stride < nvec; i += 4 * stride) {
+        const uint4 v0 = tv[i], v1 = tv[i + stride], v2 = tv[i + 2 * stride], v3 = tv[i + 3 * stride];
+        tally(v0); tally(v1); tally(v2); tally(v3);
     }
+    for (; i < nvec; i += stride) tally(tv[i]);
     for (u64 i = nvec * 16 + (u64)blockIdx.x * 256 + threadIdx.x; i < n; i += (u64)gridDim.x * 256)
         atomicAdd(&h[(u32)text[i] * 64], 1u);
     __syncthreads();
@@ -1132,21 +1139,42 @@ __global__ __launch_bounds__(TPK_NT) void tied_probe_kernel(const u8 *__restrict
     for (u32 i = tid; i < (1u << TP_BLOOM_LOG2) / 32; i += TPK_NT) s_bloom[i] = T.bloom[i];
     s_lut[tid] = (u8)kg.lut[tid];
     const u32 ntiles = (n + TPK_TILE - 1) / TPK_TILE;
+    // a tile's text is fetched while the tile before it is probed: all of a thread's 16-byte units by loads issued
+    // together (one per loop turn, each waited for before the next, was 4-5 memory latencies in a row per tile),
+    // behind an LDS-only barrier so that nothing waits for them before their conversion
+    constexpr int NU = (TPK_TILE + 64 + TPK_NT * 16 - 1) / (TPK_NT * 16);
+    uint4 raw[NU];
+    auto unit_ok = [&](u32 base, int i) -> bool {
+        const u32 p = ((u32)i * TPK_NT + tid) * 16;
+        const u64 g = (u64)base + p;
+        return p < TPK_TILE + 64 && g + 16 <= n && ((((uintptr_t)text) + g) & 15) == 0;
+    };
+    auto fetch = [&](u32 base) {
+#pragma unroll
+        for (int i = 0; i < NU; i++) {
+            raw[i] = make_uint4(0, 0, 0, 0);
+            if (unit_ok(base, i)) raw[i] = *reinterpret_cast<const uint4 *>(text + (u64)base + ((u32)i * TPK_NT + tid) * 16);
+        }
+    };
+    if (blockIdx.x < ntiles) fetch(blockIdx.x * TPK_TILE);
     for (u32 tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
         const u32 base = tile * TPK_TILE;
         __syncthreads();   // (the previous tile's codes have been read; first tile: the tables are in place)
-        for (u32 p = tid * 16; p < TPK_TILE + 64; p += TPK_NT * 16) {
+#pragma unroll
+        for (int i = 0; i < NU; i++) {
+            const u32 p = ((u32)i * TPK_NT + tid) * 16;
+            if (p >= TPK_TILE + 64) continue;
             const u64 g = (u64)base + p;
-            if (g + 16 <= n && ((((uintptr_t)text) + g) & 15) == 0) {
-                const uint4 q = *reinterpret_cast<const uint4 *>(text + g);
-                const u32 x[4] = {q.x, q.y, q.z, q.w};
+            if (unit_ok(base, i)) {
+                const u32 x[4] = {raw[i].x, raw[i].y, raw[i].z, raw[i].w};
 #pragma unroll
                 for (int j = 0; j < 16; j++) s_code[TPK_PAD(p + j)] = s_lut[(x[j >> 2] >> (8 * (j & 3))) & 255u];
             } else {
                 for (int j = 0; j < 16; j++) s_code[TPK_PAD(p + j)] = g + j < n ? s_lut[text[g + j]] : (u8)0;
             }
         }
-        __syncthreads();
+        if (tile + gridDim.x < ntiles) fetch((tile + gridDim.x) * TPK_TILE);
+        lds_barrier();
         const u32 p0 = tid * TPK_PER;
         if (base + p0 < n) {
             u32 W[WD];
