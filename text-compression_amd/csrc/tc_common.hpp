@@ -245,7 +245,11 @@ __device__ __forceinline__ u64 lb_exclusive(u64 *status, u32 tile, u64 aggregate
         u64 s = LB_FLAG_INC;  // virtual tiles before 0: inclusive identity
         if (idx >= 0) s = lb_load(&status[idx]);
         u64 invalid = __ballot((s >> 62) == 0);
-        if (invalid) {
+        u64 incmask = __ballot((s >> 62) == 2);
+        // lanes strictly beyond the first inclusive one do not contribute -- and are not waited for either (a window
+        // holds tiles of 64 workgroups: waiting for all of them made every tile wait for the slowest of its neighbours)
+        int first_inc = incmask ? __builtin_ctzll(incmask) : 64;
+        if (invalid & (first_inc >= 63 ? ~0ull : ((2ull << first_inc) - 1ull))) {
             if (++spins > LB_SPIN_LIMIT) {
                 if (lane_id() == 0) atomicOr(err, 1u);
                 break;
@@ -253,9 +257,6 @@ __device__ __forceinline__ u64 lb_exclusive(u64 *status, u32 tile, u64 aggregate
             __builtin_amdgcn_s_sleep(1);
             continue;
         }
-        u64 incmask = __ballot((s >> 62) == 2);
-        // lanes strictly beyond the first inclusive one do not contribute
-        int first_inc = incmask ? __builtin_ctzll(incmask) : 64;
         u64 v = ((int)lane_id() <= first_inc) ? LB_VALUE(s) : Op::identity();
         // reduce across the wave (order-insensitive ops only: sum / max)
 #pragma unroll
@@ -266,6 +267,36 @@ __device__ __forceinline__ u64 lb_exclusive(u64 *status, u32 tile, u64 aggregate
     }
     if (lane_id() == 0) lb_store(&status[tile], LB_FLAG_INC | Op::apply(excl, aggregate));
     return excl;
+}
+
+// The same for "the last non-zero value before this tile" where the values grow with the tile (positions of run ends):
+// the answer is the NEAREST predecessor's value that is not zero (or an inclusive one), so the wait is for that tile
+// and the ones between only -- normally tile - 1 alone -- not for all 64 tiles of a look-back window.  A tile with a
+// non-zero aggregate publishes it as inclusive at once.
+__device__ __forceinline__ u64 lb_exclusive_last(u64 *status, u32 tile, u64 aggregate, u32 *err) {
+    if (lane_id() == 0) lb_store(&status[tile], ((tile == 0 || aggregate != 0) ? LB_FLAG_INC : LB_FLAG_AGG) | aggregate);
+    if (tile == 0) return 0;
+    i64 look = (i64)tile - 1;
+    u32 spins = 0;
+    while (true) {
+        const i64 idx = look - (i64)lane_id();
+        u64 s = LB_FLAG_INC;   // virtual tiles before 0: nothing before them
+        if (idx >= 0) s = lb_load(&status[idx]);
+        const u64 ends = __ballot((s >> 62) == 2 || ((s >> 62) == 1 && LB_VALUE(s) != 0));   // lanes that settle the answer
+        const u64 invalid = __ballot((s >> 62) == 0);
+        const int first_end = ends ? __builtin_ctzll(ends) : 64;
+        const u64 nearer = first_end >= 64 ? ~0ull : ((1ull << first_end) - 1ull);
+        if (invalid & nearer) {   // a nearer tile has not published yet
+            if (++spins > LB_SPIN_LIMIT) {
+                if (lane_id() == 0) atomicOr(err, 1u);
+                return 0;
+            }
+            __builtin_amdgcn_s_sleep(1);
+            continue;
+        }
+        if (ends) return LB_VALUE(__shfl(s, first_end, 64));
+        look -= 64;   // 64 valid tiles, all without a run end
+    }
 }
 
 // LDS-only barrier: orders the workgroup's LDS traffic and leaves global loads in flight -- a __syncthreads() waits

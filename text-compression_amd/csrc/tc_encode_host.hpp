@@ -1245,6 +1245,17 @@ static bool mtf_rle_device(tc_ctx *ctx, Arena &A, BwtAcc acc, u64 N, const u32 *
     tc_d2h(ctx, &ctx->h_scalars[8], d_final, sizeof(u64));
     tc_d2h(ctx, &ctx->h_scalars[2], ctx->d_scalars + 2, sizeof(u64));
     TC_HIP(ctx, hipStreamSynchronize(s));
+#ifdef MTFRLE_PROFILE
+    {
+        u64 h[9];
+        tc_d2h(ctx, h, ctx->d_scalars + 112, sizeof h);
+        TC_HIP(ctx, hipStreamSynchronize(s));
+        const double c = (double)(h[8] | 1);
+        fprintf(stderr, "mtf_rle: tiles %llu | cycles per tile: stage+B %.0f pass %.0f scan+replay+B %.0f ends+B %.0f lookback A/counts+B %.0f lookback B+B %.0f emit+B %.0f copy-out %.0f\n",
+                (unsigned long long)h[8], h[0] / c, h[1] / c, h[2] / c, h[3] / c, h[4] / c, h[5] / c, h[6] / c, h[7] / c);
+        tc_memset_async(ctx, ctx->d_scalars + 112, 0, sizeof h);
+    }
+#endif
     if ((u32)ctx->h_scalars[15] != 0) return false;
     const u64 perm = ctx->h_scalars[8];
     for (u32 i = 0; i < al.sigma; i++) out->final_list[i] = al.sym_of_code[(perm >> (4 * i)) & 15];

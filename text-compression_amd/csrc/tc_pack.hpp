@@ -705,7 +705,7 @@ __global__ __launch_bounds__(MTF_NT) void mtf_rle_kernel(MtfRleArgs a) {
     __shared__ NibSumm s_w[NW];
     __shared__ u64 s_in;
     __shared__ u32 s_next, s_tile;
-    __shared__ u32 s_last[NSEG], s_carry[NSEG], s_sum[NSEG];
+    __shared__ u32 s_last[NSEG], s_carry[NSEG], s_sum[NSEG], s_wruns[NW];
     __shared__ u64 s_pref;
     const int tid = threadIdx.x, lane = lane_id(), w = tid >> 6;
     const u64 N = a.N;
@@ -722,6 +722,13 @@ __global__ __launch_bounds__(MTF_NT) void mtf_rle_kernel(MtfRleArgs a) {
     __syncthreads();
     const u32 tile = s_tile;
     if (tile >= a.ntiles) return;
+#ifdef MTFRLE_PROFILE
+    u32 tq[10];
+#define MR_T(i) tq[i] = (u32)__builtin_readcyclecounter()
+#else
+#define MR_T(i)
+#endif
+    MR_T(0);
     const u64 base = (u64)tile * MTF_TILE;
     const bool edge = base + MTF_TILE >= N;
     // (wave 0 recovers the tile's incoming list, and thread 0 fetches the symbol behind the tile, while the tile's own
@@ -739,6 +746,7 @@ __global__ __launch_bounds__(MTF_NT) void mtf_rle_kernel(MtfRleArgs a) {
         }
     });
     __syncthreads();
+    MR_T(1);
     // ---- MTF: one pass per chunk from the identity list; first occurrences replayed from the true incoming list
     u32 *cw = reinterpret_cast<u32 *>(s_code + tid * MTF_STRIDE);
     NibSumm mine{NIB_IDENT, 0u};
@@ -752,6 +760,7 @@ __global__ __launch_bounds__(MTF_NT) void mtf_rle_kernel(MtfRleArgs a) {
         mine.perm = (NIB_IDENT & 0xFFFFFFFF00000000ull) | (u64)lst;
         mine.mask = seen;
     }
+    MR_T(2);
     NibSumm agg{NIB_IDENT, 0u};
     const NibSumm exc = (a.diag & 4u) ? mine : nib_block_excl(mine, s_w, &agg);
     if (a.diag & 4u) __syncthreads();
@@ -775,12 +784,13 @@ __global__ __launch_bounds__(MTF_NT) void mtf_rle_kernel(MtfRleArgs a) {
         s_next = nx;
     }
     __syncthreads();
+    MR_T(3);
     // ---- RLE of the tile's ranks (rle_blk_kernel's phases on nibbles; a thread owns 16 consecutive ranks per sub-tile)
     auto nibw = [&](u32 p) -> const u32 * {
         return reinterpret_cast<const u32 *>(s_code + (p / MTF_CH) * MTF_STRIDE + (p % MTF_CH) / 2);
     };
     u32 n0[SUBS], n1[SUBS], E0[SUBS], E1[SUBS], pv[SUBS];
-    u32 hasmask = 0;
+    u32 hasmask = 0, myruns = 0;
 #pragma unroll
     for (int s = 0; s < SUBS; s++) {
         const u32 pl = (u32)s * (MTF_NT * 16) + (u32)tid * 16;       // tile-local position of the group
@@ -804,6 +814,7 @@ __global__ __launch_bounds__(MTF_NT) void mtf_rle_kernel(MtfRleArgs a) {
         }
         n0[s] = a0; n1[s] = a1;
         E0[s] = e0; E1[s] = e1;
+        myruns += (u32)__popc(e0) + (u32)__popc(e1);
         const u32 last1 = e1 ? (u32)p0 + 16u - ((u32)__builtin_clz(e1) >> 2)
                              : (e0 ? (u32)p0 + 8u - ((u32)__builtin_clz(e0) >> 2) : 0u);   // 1 + position of the last end
         const u64 m = __ballot((e0 | e1) != 0);
@@ -814,15 +825,30 @@ __global__ __launch_bounds__(MTF_NT) void mtf_rle_kernel(MtfRleArgs a) {
         const u32 wlast = m ? __shfl(last1, 63 - __builtin_clzll(m), 64) : 0u;
         if (lane == 0) s_last[s * NW + w] = wlast;
     }
+    {   // the tile's run count, for the look-back over the run counts to start together with the one over the run ends
+        const u32 wr = wave_incl_sum(myruns);
+        if (lane == 63) s_wruns[w] = wr;
+    }
     __syncthreads();
+    MR_T(4);
     if (w == 0) {
         const u32 v = lane < NSEG ? s_last[lane] : 0u;
         const u32 inc = seg_incl_scan<OpMax>(v);
         const u32 aggl = __shfl(inc, NSEG - 1, 64);
         u32 ex = __shfl_up(inc, 1, 64);
         if (lane == 0) ex = 0;
-        const u32 tin = (u32)lb_exclusive<OpMax>(a.status_a, tile, aggl, a.err);
+        const u32 tin = (u32)lb_exclusive_last(a.status_a, tile, aggl, a.err);
         if (lane < NSEG) s_carry[lane] = ex > tin ? ex : tin;
+    }
+    if (w == 1) {
+        u32 tr = 0;
+#pragma unroll
+        for (int i = 0; i < NW; i++) tr += s_wruns[i];
+        const u64 e = lb_exclusive<OpSum>(a.status_b, tile, (u64)tr, a.err);
+        if (lane == 0) {
+            s_pref = e;
+            if (tile + 1 == a.ntiles) a.scalars[2] = e + tr;
+        }
     }
     u32 cnt[SUBS], inc[SUBS];
 #pragma unroll
@@ -832,6 +858,7 @@ __global__ __launch_bounds__(MTF_NT) void mtf_rle_kernel(MtfRleArgs a) {
         if (lane == 63) s_sum[s * NW + w] = inc[s];
     }
     __syncthreads();
+    MR_T(5);
     u32 excl[SUBS], truns;
     {
         const u32 v = lane < NSEG ? s_sum[lane] : 0u;
@@ -844,14 +871,9 @@ __global__ __launch_bounds__(MTF_NT) void mtf_rle_kernel(MtfRleArgs a) {
             excl[s] = before + inc[s] - cnt[s];
         }
     }
-    if (w == 1) {
-        const u64 e = lb_exclusive<OpSum>(a.status_b, tile, (u64)truns, a.err);
-        if (lane == 0) {
-            s_pref = e;
-            if (tile + 1 == a.ntiles) a.scalars[2] = e + truns;
-        }
-    }
-    __syncthreads();   // (also: every thread has its ranks in registers -- the image becomes the run staging area)
+    // (no barrier here: the runs before the tile were published before the last one, and every thread has had its
+    // ranks in registers since the first barrier of this part -- the image becomes the run staging area)
+    MR_T(6);
     const u64 e0g = s_pref;
     const u32 sh = (u32)(e0g & 7u);
     const u64 gbase = e0g - sh;
@@ -888,6 +910,7 @@ __global__ __launch_bounds__(MTF_NT) void mtf_rle_kernel(MtfRleArgs a) {
         }
     }
     __syncthreads();
+    MR_T(7);
     const u32 ngroups = (sh + truns + 7u) >> 3;
     for (u32 q = tid; q < ngroups; q += MTF_NT) {
         const u32 lo = 8u * q;
@@ -917,6 +940,14 @@ __global__ __launch_bounds__(MTF_NT) void mtf_rle_kernel(MtfRleArgs a) {
             }
         }
     }
+#ifdef MTFRLE_PROFILE
+    MR_T(8);
+    if (tid == 0 && (tile & 63u) == 7u) {
+        u64 *dbg = a.scalars + 112;
+        for (int i = 0; i < 8; i++) atomicAdd((unsigned long long *)&dbg[i], (unsigned long long)(tq[i + 1] - tq[i]));
+        atomicAdd((unsigned long long *)&dbg[8], 1ull);
+    }
+#endif
 }
 
 #define UP_NT 256
