@@ -1219,7 +1219,8 @@ __global__ __launch_bounds__(256) void msd_finish_lut_kernel(const u32 *__restri
     }
     __syncthreads();
     const u64 tot = s_tot;
-    const u32 lo = (u32)(s_x[t] * (u64)(MSDK_BPC * 64) / tot), hi = t == 255 ? (u32)(MSDK_BPC * 64) : (u32)(s_x[t + 1] * (u64)(MSDK_BPC * 64) / tot);
+    // (65535, not 65536: a and w share a 32-bit word in the finish kernel, and the bin inside the child stays < MSDK_BPC)
+    const u32 lo = (u32)(s_x[t] * (u64)(MSDK_BPC * 64 - 1) / tot), hi = t == 255 ? (u32)(MSDK_BPC * 64 - 1) : (u32)(s_x[t + 1] * (u64)(MSDK_BPC * 64 - 1) / tot);
     out->a[t] = lo;
     out->w[t] = hi - lo;
     const u64 c16 = s_x[t] * 65536ull / tot;
@@ -1237,7 +1238,7 @@ __global__ __launch_bounds__(256, 6) void msd_finish_ko_kernel(MsdFinishArgs a, 
     __shared__ __attribute__((aligned(16))) u32 s_off[MAXBINS + 4];   // [bin] count, then exclusive offset; [MAXBINS] = pairs
     __shared__ u32 s_low[TILE + 4];                                    // key bits 39..8, in bin order
     __shared__ __attribute__((aligned(16))) u8 s_L[TILE + 8];          // preceding bytes, in final order, shifted by start & 3
-    __shared__ uint2 s_aw[256];
+    __shared__ u32 s_aw[256];                                          // a | w << 16
     __shared__ u16 s_c[256], s_cc[256];
     __shared__ u32 s_scan[NT / 64 + 1];
     const u32 q = blockIdx.x;
@@ -1246,7 +1247,7 @@ __global__ __launch_bounds__(256, 6) void msd_finish_ko_kernel(MsdFinishArgs a, 
     {
         const u32 c = a.ccnt[(size_t)q * 256 + tid];
         s_cc[tid] = (u16)(c > 65535u ? 65535u : c);                    // (> TILE is all that matters of a long one)
-        s_aw[tid] = make_uint2(lut->a[tid], lut->w[tid]);
+        s_aw[tid] = lut->a[tid] | (lut->w[tid] << 16);
         s_c[tid] = (u16)lut->c[tid];
     }
     const u32 region = blockIdx.x % FIN_REGIONS;
@@ -1335,10 +1336,9 @@ __global__ __launch_bounds__(256, 6) void msd_finish_ko_kernel(MsdFinishArgs a, 
         for (int k = 0; k < (int)ITEMS; k++) {
             const u32 i = k * NT + tid;
             if (i < tot) {
-                const uint2 aw = s_aw[khi[k] & 255u];                  // field 3: key bits 39..32
+                const u32 aw = s_aw[khi[k] & 255u];                    // field 3: key bits 39..32
                 const u32 c = s_c[klo[k] >> 24];                       // field 4: 31..24
-                u32 inner = (aw.x + (__umul24(aw.y, c) >> 16)) >> 6;
-                inner = inner < MSDK_BPC ? inner : MSDK_BPC - 1u;        // (a value the level-1 counts never met, past the last one)
+                const u32 inner = ((aw & 0xffffu) + (__umul24(aw >> 16, c) >> 16)) >> 6;   // < MSDK_BPC: a + w <= 65535
                 const u32 child = (khi[k] >> 8) & 255u;
                 const u32 bin = ((u32)(child >= l1) + (u32)(child >= l2)) * MSDK_BPC + inner;
                 bp[k] = bin | ((klo[k] & 255u) << 12) | (atomicAdd(&s_off[bin], 1u) << 20);
@@ -1391,14 +1391,21 @@ __global__ __launch_bounds__(256, 6) void msd_finish_ko_kernel(MsdFinishArgs a, 
                 if (in) {
                     s = s_off[bp[k] & 0xfffu];
                     e = s_off[(bp[k] & 0xfffu) + 1];
-                    mine = s_low[bp[k] >> 20];
                 }
                 const u32 cnt = e - s;
-                u32 lt = 0, eq = 0;
-                {
-                    const u32 y0 = s_low[s], y1 = s_low[s + 1], y2 = s_low[s + 2], y3 = s_low[s + 3];
-                    lt += (u32)(cnt > 0 && y0 < mine) + (u32)(cnt > 1 && y1 < mine) + (u32)(cnt > 2 && y2 < mine) + (u32)(cnt > 3 && y3 < mine);
-                    eq += (u32)(cnt > 0 && y0 == mine) + (u32)(cnt > 1 && y1 == mine) + (u32)(cnt > 2 && y2 == mine) + (u32)(cnt > 3 && y3 == mine);
+                u32 lt = 0, eq = cnt ? 1u : 0u;
+                // (the kernel is bound by its LDS traffic: a key alone in its bin -- six in ten -- reads nothing more, the
+                // others their own bits and the bin's first two slots, one in ten slots 2 and 3 as well)
+                if (cnt > 1) {
+                    mine = s_low[bp[k] >> 20];
+                    const u32 y0 = s_low[s], y1 = s_low[s + 1];
+                    u32 y2 = 0, y3 = 0;
+                    if (cnt > 2) {
+                        y2 = s_low[s + 2];
+                        y3 = s_low[s + 3];
+                    }
+                    lt = (u32)(y0 < mine) + (u32)(y1 < mine) + (u32)(cnt > 2 && y2 < mine) + (u32)(cnt > 3 && y3 < mine);
+                    eq = (u32)(y0 == mine) + (u32)(y1 == mine) + (u32)(cnt > 2 && y2 == mine) + (u32)(cnt > 3 && y3 == mine);
                 }
                 if (__any(cnt > 4)) {
                     for (u32 u = s + 4; __any(u < e); u++) {
