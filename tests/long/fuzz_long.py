@@ -45,6 +45,9 @@ for it in range(cases):
     if sigma == 256 and n >= 256 and rng.random() < 0.7:
         t[rng.permutation(n)[:256]] = np.arange(256)
     tb = t.astype(np.uint8).tobytes()
+    if os.environ.get("FUZZ_VERBOSE"):
+        print("case %d: n %d sigma %d" % (it, n, sigma), flush=True)
+        np.save("gpurun_out/fuzz_last_%d.npy" % seed, t.astype(np.uint8))
     try:
         sa = ctx.suffix_array(tb)
         assert sa.tolist() == O.suffix_array(tb).tolist(), "suffix array"

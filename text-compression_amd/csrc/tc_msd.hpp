@@ -1338,7 +1338,10 @@ __global__ __launch_bounds__(256, 6) void msd_finish_ko_kernel(MsdFinishArgs a, 
             if (i < tot) {
                 const u32 aw = s_aw[khi[k] & 255u];                    // field 3: key bits 39..32
                 const u32 c = s_c[klo[k] >> 24];                       // field 4: 31..24
-                const u32 inner = ((aw & 0xffffu) + (__umul24(aw >> 16, c) >> 16)) >> 6;   // < MSDK_BPC: a + w <= 65535
+                // (HIP declares __umul24 as returning int: without the cast the shift is arithmetic, and a share above
+                // one half times a cumulative share above one half came back negative -- the bin left the table)
+                u32 inner = ((aw & 0xffffu) + ((u32)__umul24(aw >> 16, c) >> 16)) >> 6;   // < MSDK_BPC: a + w <= 65535
+                inner = inner < MSDK_BPC ? inner : MSDK_BPC - 1u;                          // (whatever the table holds)
                 const u32 child = (khi[k] >> 8) & 255u;
                 const u32 bin = ((u32)(child >= l1) + (u32)(child >= l2)) * MSDK_BPC + inner;
                 bp[k] = bin | ((klo[k] & 255u) << 12) | (atomicAdd(&s_off[bin], 1u) << 20);
