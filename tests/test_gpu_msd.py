@@ -3,6 +3,8 @@
 (TC_SA_MSD_MIN_LOG2 lowers the length from which it is chosen).  Whatever the path, the result is
 the reference's order of the n+1 suffixes (createSuffixArray, BWT/Internal.hs:110-134) -- bit-exact
 against the oracle; `tc_stats.msd_path` tells which way round 0 went."""
+import os
+
 import numpy as np
 import pytest
 
