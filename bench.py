@@ -446,6 +446,7 @@ def main():
             "gather": gathered,
             "workspace_placement": placement,
             "stages_ms": {"suffix_sort+bwt": round(st.ms_sa, 3), "mtf": round(st.ms_mtf, 3), "rle": round(st.ms_rle, 3),
+                          "mtf_rle_one_kernel": bool(st.ms_rle < 0.05 and st.ms_mtf > 0.2),   # (sigma <= 8: "mtf" is then both stages)
                           "rounds": int(st.rounds), "m": [int(st.m[i]) for i in range(st.rounds)],
                           "passes": [int(st.passes[i]) for i in range(st.rounds)], "runs": int(st.runs),
                           "ticket_fallbacks": int(st.ticket_fallbacks)},
