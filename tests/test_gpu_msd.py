@@ -178,8 +178,9 @@ def test_msd_keyonly_finish_with_a_digit_above_half_the_text(ctx, monkeypatch):
     """a binary text, 60 % of it one run: one field value holds more than half of the level-1 digit counts, so the
     equal-mass bin map of the key-only finish kernel multiplies a share above 1/2 by cumulative shares above 1/2 --
     taken as a signed product (HIP's __umul24 returns int) the bin left the table and the kernel never came back.
-    The input is the soak case that showed it (tests/long/fuzz_long.py 80 102 200000, case 50)."""
+    The input is the soak case that showed it (tests/long/fuzz_long.py 80 102 200000, case 50).  (The run also makes
+    level-3 buckets above the finish chunk, so the attempt ends with the LSD way: msd_path 0 -- after the kernel ran.)"""
     monkeypatch.setenv("TC_SA_MSD", "2")
     monkeypatch.setenv("TC_SA_MSD_MIN_LOG2", "10")
     t = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "binary_long_run_128k.npz"))["text"]
-    _check(ctx, t, True)
+    _check(ctx, t, False)
