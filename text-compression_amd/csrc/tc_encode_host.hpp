@@ -1234,8 +1234,6 @@ static bool mtf_rle_device(tc_ctx *ctx, Arena &A, BwtAcc acc, u64 N, const u32 *
     a.ticket = reinterpret_cast<u32 *>(status + 2 * (size_t)tiles);
     a.scalars = ctx->d_scalars; a.err = ctx->d_err; a.ntiles = tiles;
     a.wide = ((((uintptr_t)out->run_count) | ((uintptr_t)out->run_value)) & 15) == 0 ? 1u : 0u;
-    a.diag = (u32)env_int("TC_MTFRLE_DIAG", 0);
-    a.stagger = (u32)env_int("TC_MTFRLE_STAGGER", 0);
     mtf_rle_kernel<<<tiles, MTF_NT, 0, s>>>(a);
     TC_LAUNCH_CHECK(ctx);
     u64 *d_final = status + 2 * (size_t)tiles + 2;

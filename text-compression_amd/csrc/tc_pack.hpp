@@ -693,8 +693,6 @@ struct MtfRleArgs {
     u32 *err;
     u32 ntiles;
     u32 wide;
-    u32 diag;        // TC_MTFRLE_DIAG (measurement only): 1 no run stores, 2 no MTF pass, 4 no block scan / replay
-    u32 stagger;     // the first blocks of a CU start apart: mode | sleeps << 8
 };
 
 __global__ __launch_bounds__(MTF_NT) void mtf_rle_kernel(MtfRleArgs a) {
@@ -712,11 +710,6 @@ __global__ __launch_bounds__(MTF_NT) void mtf_rle_kernel(MtfRleArgs a) {
     for (int i = tid; i < 257; i += MTF_NT) {
         s_lut[i] = a.lut.v[i];
         s_lut11[i] = (u8)((a.lut.v[i] & 7u) * 0x11u);
-    }
-    if (a.stagger && blockIdx.x < 1024u) {
-        const u32 mode = a.stagger & 255u, unit = a.stagger >> 8;
-        const u32 k = mode == 1 ? (blockIdx.x >> 8) & 3u : (mode == 2 ? blockIdx.x & 3u : (mode == 3 ? (blockIdx.x >> 3) & 3u : (blockIdx.x * 2654435761u) >> 30));
-        for (u32 i = 0; i < k * unit; i++) __builtin_amdgcn_s_sleep(127);
     }
     if (tid == 0) s_tile = atomicAdd(a.ticket, 1u);
     __syncthreads();
@@ -754,16 +747,14 @@ __global__ __launch_bounds__(MTF_NT) void mtf_rle_kernel(MtfRleArgs a) {
     u32 evc = 0, k4 = 0;
     {
         u32 lst = (u32)NIB_IDENT, seen = 0;
-        if (a.diag & 2u) seen = 1;
-        else if (edge) nib8_chunk_ranks<true>(cw, lst, seen, evc, evp, k4);
+        if (edge) nib8_chunk_ranks<true>(cw, lst, seen, evc, evp, k4);
         else nib8_chunk_ranks<false>(cw, lst, seen, evc, evp, k4);
         mine.perm = (NIB_IDENT & 0xFFFFFFFF00000000ull) | (u64)lst;
         mine.mask = seen;
     }
     MR_T(2);
     NibSumm agg{NIB_IDENT, 0u};
-    const NibSumm exc = (a.diag & 4u) ? mine : nib_block_excl(mine, s_w, &agg);
-    if (a.diag & 4u) __syncthreads();
+    const NibSumm exc = nib_block_excl(mine, s_w, &agg);
     {
         u64 list = nib_combine(NibSumm{s_in, 0u}, exc).perm;
         for (u32 e4 = 0; e4 < k4; e4 += 4) {
@@ -920,7 +911,6 @@ __global__ __launch_bounds__(MTF_NT) void mtf_rle_kernel(MtfRleArgs a) {
         const u32 zx = tx ^ 0xF0F0F0F0u, zy = ty ^ 0xF0F0F0F0u;
         const bool any15 = (((zx - 0x01010101u) & ~zx & 0x80808080u) | ((zy - 0x01010101u) & ~zy & 0x80808080u)) != 0;
         const bool plain = a.wide && !any15 && lo >= sh && lo + 8u <= sh + truns && lo + 8u <= lim;
-        if ((a.diag & 1u) && cwd.x != 0x12345678u) continue;
         if (plain) {
             uint4 *pc = reinterpret_cast<uint4 *>(a.counts + gbase + lo);
             pc[0] = make_uint4((cwd.x >> 4) & 15u, (cwd.x >> 12) & 15u, (cwd.x >> 20) & 15u, cwd.x >> 28);
