@@ -754,14 +754,14 @@ __global__ __launch_bounds__(MTF_NT) void mtf_rle_kernel(MtfRleArgs a) {
     }
     MR_T(2);
     NibSumm agg{NIB_IDENT, 0u};
-    const NibSumm exc = nib_block_excl(mine, s_w, &agg);
+    const NibSumm exc = nib_block_excl<true>(mine, s_w, &agg);
     {
-        u64 list = nib_combine(NibSumm{s_in, 0u}, exc).perm;
+        u32 list = (u32)nib8_combine(NibSumm{s_in, 0u}, exc).perm;   // (sigma <= 8: every list lives in 32 bits)
         for (u32 e4 = 0; e4 < k4; e4 += 4) {
             const u32 c = (evc >> e4) & 15u;
             const u32 pp = (u32)(evp >> (2 * e4)) & 255u;
-            const u32 pos = nib_find(list, c);
-            list = nib_front(list, pos, c);
+            const u32 pos = nib8_find(list, c);
+            list = nib8_front(list, pos, c);
             const u32 shf = 4u * (pp & 7u);
             cw[pp >> 3] = (cw[pp >> 3] & ~(15u << shf)) | (pos << shf);
         }
@@ -769,8 +769,8 @@ __global__ __launch_bounds__(MTF_NT) void mtf_rle_kernel(MtfRleArgs a) {
     if (tid == 0) {   // the rank the next tile's first symbol will get: the successor of this tile's last rank
         u32 nx = 0x100u;
         if (base + MTF_TILE < N) {
-            const u64 outl = nib_combine(NibSumm{s_in, 0u}, agg).perm;
-            nx = nib_find(outl, (u32)s_lut[nsym]);
+            const u32 outl = (u32)nib8_combine(NibSumm{s_in, 0u}, agg).perm;
+            nx = nib8_find(outl, (u32)s_lut[nsym]);
         }
         s_next = nx;
     }
