@@ -32,7 +32,8 @@ BUDGETS = {
     "tied_probe_kernelILi3EE": (128, 0, 3),               # (LDS holds 3 workgroups per CU; the next tile's text sits in 20 registers)
     "msd_finish_ko_kernelILi3EE": (80, 0, 6),              # round 3: equal-mass bins, prefetched keys.  NO scratch: a build
                                                            # of it that spilled (12 bytes) gave wrong tied sets on the GPU
-    "14mtf_rle_kernel10MtfRleArgs": (96, 0, 4),            # round 3: MTF and RLE of a small-alphabet record in one kernel
+    "mtf_rle_kernelILb0EE": (96, 0, 4),                    # round 3: MTF and RLE of a small-alphabet record in one kernel (run arrays)
+    "mtf_rle_kernelILb1EE": (128, 0, 4),                   # ... writing the container's nibble stream (LDS holds 4 workgroups per CU)
 }
 
 

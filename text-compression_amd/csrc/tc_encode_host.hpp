@@ -1234,7 +1234,7 @@ static bool mtf_rle_device(tc_ctx *ctx, Arena &A, BwtAcc acc, u64 N, const u32 *
     a.ticket = reinterpret_cast<u32 *>(status + 2 * (size_t)tiles);
     a.scalars = ctx->d_scalars; a.err = ctx->d_err; a.ntiles = tiles;
     a.wide = ((((uintptr_t)out->run_count) | ((uintptr_t)out->run_value)) & 15) == 0 ? 1u : 0u;
-    mtf_rle_kernel<<<tiles, MTF_NT, 0, s>>>(a);
+    mtf_rle_kernel<false><<<tiles, MTF_NT, 0, s>>>(a);
     TC_LAUNCH_CHECK(ctx);
     u64 *d_final = status + 2 * (size_t)tiles + 2;
     mtf_nib_final_kernel<BwtAcc><<<1, 64, 0, s>>>(acc, N, a.lut, al.sigma, d_final, a.flag);

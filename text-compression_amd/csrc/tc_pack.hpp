@@ -693,8 +693,23 @@ struct MtfRleArgs {
     u32 *err;
     u32 ntiles;
     u32 wide;
+    // NIB = true (the container of a record over <= 6 symbols): the runs leave as the nibble stream of rle_nib_kernel
+    u8 *out;         // 16-byte aligned, ZERO for cap_units * 16 bytes
+    u64 cap_units;
+    u32 *esc;
+    u64 esc_cap;
+    u64 *totals;     // [0] runs (atomicAdd), [1] nibbles, [2] escapes (written by the last tile)
 };
 
+// run-end bits of eight positions, one per nibble (bit 4 i + 3), as eight adjacent bits
+__device__ __forceinline__ u32 nib_bits8(u32 e) {
+    u32 x = (e >> 3) & 0x11111111u;
+    x = (x | (x >> 3)) & 0x03030303u;
+    x = (x | (x >> 6)) & 0x000F000Fu;
+    return (x | (x >> 12)) & 0xFFu;
+}
+
+template <bool NIB>
 __global__ __launch_bounds__(MTF_NT) void mtf_rle_kernel(MtfRleArgs a) {
     constexpr int NW = MTF_NT / 64, SUBS = MTF_TILE / (MTF_NT * 16), NSEG = SUBS * NW;
     static_assert(NSEG <= 64 && MTF_NT * MTF_STRIDE >= MTF_TILE + 16, "segment scan by one wave; the code image doubles as run staging");
@@ -822,6 +837,136 @@ __global__ __launch_bounds__(MTF_NT) void mtf_rle_kernel(MtfRleArgs a) {
     }
     __syncthreads();
     MR_T(4);
+    if constexpr (NIB) {
+        // ---- the nibble stream (rle_nib_kernel's phases 2-4 on this tile's ranks; the image takes the place of the ranks)
+        u64 *img = reinterpret_cast<u64 *>(s_code);
+        static_assert(MTF_NT * MTF_STRIDE >= (MTF_TILE / 16 + 4) * 8, "a tile emits at most one nibble per position");
+        for (int i = tid; i < MTF_TILE / 16 + 4; i += MTF_NT) img[i] = 0;   // (every thread has its ranks in registers)
+        if (w == 0) {
+            const u32 v = lane < NSEG ? s_last[lane] : 0u;
+            const u32 inc = seg_incl_scan<OpMax>(v);
+            const u32 aggl = __shfl(inc, NSEG - 1, 64);
+            u32 ex = __shfl_up(inc, 1, 64);
+            if (lane == 0) ex = 0;
+            const u32 tin = (u32)lb_exclusive_last(a.status_a, tile, aggl, a.err);
+            if (lane < NSEG) s_carry[lane] = ex > tin ? ex : tin;
+        }
+        __syncthreads();
+        u32 E16[SUBS], prev1[SUBS], cnt[SUBS], inc[SUBS];
+        u32 runs_mine = 0;
+#pragma unroll
+        for (int s = 0; s < SUBS; s++) {
+            const u32 p0 = (u32)(base + (u64)s * (MTF_NT * 16) + (u64)tid * 16);
+            const u32 pe = ((hasmask >> s) & 1u) ? pv[s] : s_carry[s * NW + w];
+            prev1[s] = pe;
+            E16[s] = nib_bits8(E0[s]) | (nib_bits8(E1[s]) << 8);
+            // the last end before the group is position pe - 1 (pe == 0: the virtual end before position 0)
+            const u32 back = p0 + 1u - pe;                       // 1: directly before the group, 2, 3, 4 ...
+            const u32 vb = (back - 1u < 4u) ? 1u << (4u - back) : 0u;
+            const u32 X = (E16[s] << 4) | vb;
+            const u32 g2 = X & ~(X << 1);
+            const u32 g3 = g2 & ~(X << 2);
+            const u32 g5 = g3 & ~(X << 3) & ~(X << 4);
+            const u32 runs = (u32)__popc(E16[s]);
+            runs_mine += runs;
+            cnt[s] = (runs + (u32)__popc((g3 >> 4) & 0xffffu)) | ((u32)__popc((g5 >> 4) & 0xffffu) << 16);
+            inc[s] = wave_incl_sum(cnt[s]);
+            if (lane == 63) s_sum[s * NW + w] = inc[s];
+        }
+        runs_mine = wave_sum(runs_mine);
+        if (lane == 0) s_wruns[w] = runs_mine;
+        __syncthreads();
+        u32 excl[SUBS], tile_cnt;
+        {
+            const u32 v = lane < NSEG ? s_sum[lane] : 0u;
+            const u32 sc = seg_incl_scan<OpSum>(v);
+            tile_cnt = __shfl(sc, NSEG - 1, 64);
+#pragma unroll
+            for (int s = 0; s < SUBS; s++) {
+                const int g = s * NW + w;
+                const u32 before = g ? __shfl(sc, g - 1, 64) : 0u;
+                excl[s] = before + inc[s] - cnt[s];
+            }
+        }
+        const u32 tn = tile_cnt & 0xffffu, te = tile_cnt >> 16;
+        if (w == 1) {
+            const u64 e = lb_exclusive<OpSum>(a.status_b, tile, NIB_LB(tn, te), a.err);
+            if (lane == 0) {
+                s_pref = e;
+                if (tile + 1 == a.ntiles) {
+                    a.totals[1] = (e >> NIB_LB_SHIFT) + tn;
+                    a.totals[2] = NIB_LB_ESC(e) + te;
+                }
+            }
+        } else if (tid == 0) {
+            u32 r = 0;
+#pragma unroll
+            for (int i = 0; i < NW; i++) r += s_wruns[i];
+            if (r) atomicAdd((unsigned long long *)&a.totals[0], (unsigned long long)r);
+        }
+        __syncthreads();
+        const u64 q0 = s_pref >> NIB_LB_SHIFT, e0 = NIB_LB_ESC(s_pref);
+        const u32 a0 = (u32)(q0 & 31u);
+#pragma unroll
+        for (int s = 0; s < SUBS; s++) {
+            const u32 p0 = (u32)(base + (u64)s * (MTF_NT * 16) + (u64)tid * 16);
+            u32 prev = prev1[s];
+            u64 L = 0;
+            u32 H = 0, len = 0;     // the group's string: at most 17 nibbles
+#pragma unroll
+            for (int d = 0; d < 4; d++) {
+                u32 g = 0, sh = 0;  // the nibbles of four positions: at most five
+#pragma unroll
+                for (int k = 0; k < 4; k++) {
+                    const int i = 4 * d + k;
+                    const bool end = (E16[s] >> i) & 1u;
+                    const u32 pos1 = p0 + (u32)i + 1u;
+                    const u32 c1 = pos1 - prev - 1u;                      // run length - 1
+                    const u32 v = ((i < 8 ? n0[s] : n1[s]) >> (4 * (i & 7))) & 15u;
+                    const u32 first = v + ((c1 - 1u < 3u) ? 6u : 0u);     // lengths 2, 3, 4: value + 6
+                    const u32 second = (c1 < 4u ? c1 : 4u) + 10u;         // 3 -> 12, 4 -> 13, >= 5 -> 14
+                    const bool two = c1 >= 2u;
+                    const u32 pair = first | (two ? second << 4 : 0u);
+                    if (end) {
+                        g |= pair << sh;
+                        sh += two ? 8u : 4u;
+                        prev = pos1;
+                    }
+                }
+                const u32 bsh = len * 4u;
+                if (len < 16u) {
+                    L |= (u64)g << bsh;
+                    if (bsh > 32u) H |= g >> (64u - bsh);
+                } else {
+                    H |= g << (bsh - 64u);
+                }
+                len += sh >> 2;
+            }
+            const u32 off = a0 + (excl[s] & 0xffffu);
+            const u32 wd = off >> 4, bs = (off & 15u) * 4u;
+            const u64 w0 = L << bs;
+            const u64 w1 = (bs ? L >> (64u - bs) : 0ull) | ((u64)H << bs);
+            if (w0) atomicOr((unsigned long long *)&img[wd], (unsigned long long)w0);
+            if (w1) atomicOr((unsigned long long *)&img[wd + 1], (unsigned long long)w1);
+            if (cnt[s] >> 16) {   // rare: lengths >= 5 go to the escape list, in run order
+                u64 e = e0 + (excl[s] >> 16);
+                u32 pr = prev1[s], em = E16[s];
+                while (em) {
+                    const u32 i = (u32)__builtin_ctz(em);
+                    em &= em - 1u;
+                    const u32 c = p0 + i + 1u - pr;
+                    pr = p0 + i + 1u;
+                    if (c >= 5u) {
+                        if (e < a.esc_cap) a.esc[e] = c;
+                        e++;
+                    }
+                }
+            }
+        }
+        __syncthreads();
+        nib_image_out<MTF_NT>(img, q0, tn, tile + 1 == a.ntiles, a.out, a.cap_units);
+        return;
+    }
     if (w == 0) {
         const u32 v = lane < NSEG ? s_last[lane] : 0u;
         const u32 inc = seg_incl_scan<OpMax>(v);

@@ -1028,15 +1028,27 @@ struct ContainerHeader {
 static_assert(sizeof(ContainerHeader) <= TC_CONTAINER_HEADER, "container header layout");
 static const char kContainerMagic[8] = {'T', 'C', 'B', 'L', 'K', '0', '1', 0};
 
+// the sum a thread of a grid of 256-thread workgroups contributes: word i weighs in by a mix of (word, i); four loads
+// in flight per thread (one per loop turn left the memory latency exposed)
+__device__ __forceinline__ u64 checksum64_term(u32 word, u64 i) {
+    u64 z = ((u64)word << 32 | (u32)i) + (i >> 32) * 0x9E3779B97F4A7C15ull;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    return z ^ (z >> 31);
+}
+__device__ __forceinline__ u64 checksum64_partial(const u32 *__restrict__ w, u64 nwords) {
+    const u64 stride = (u64)gridDim.x * 256;
+    u64 i = (u64)blockIdx.x * 256 + threadIdx.x, acc = 0;
+    for (; i + 3 * stride < nwords; i += 4 * stride) {
+        const u32 a = w[i], b = w[i + stride], c = w[i + 2 * stride], d = w[i + 3 * stride];
+        acc += checksum64_term(a, i) + checksum64_term(b, i + stride) + checksum64_term(c, i + 2 * stride) + checksum64_term(d, i + 3 * stride);
+    }
+    for (; i < nwords; i += stride) acc += checksum64_term(w[i], i);
+    return acc;
+}
 // position-dependent 64-bit checksum of a byte range (16-byte aligned, length a multiple of 4)
 __global__ __launch_bounds__(256) void checksum64_kernel(const u32 *__restrict__ w, u64 nwords, u64 *out) {
-    u64 acc = 0;
-    for (u64 i = (u64)blockIdx.x * 256 + threadIdx.x; i < nwords; i += (u64)gridDim.x * 256) {
-        u64 z = ((u64)w[i] << 32 | (u32)i) + (i >> 32) * 0x9E3779B97F4A7C15ull;
-        z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
-        z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
-        acc += z ^ (z >> 31);
-    }
+    u64 acc = checksum64_partial(w, nwords);
 #pragma unroll
     for (int d = 32; d >= 1; d >>= 1) acc += __shfl_xor(acc, d, 64);
     if (lane_id() == 0 && acc) atomicAdd((unsigned long long *)out, (unsigned long long)acc);
@@ -1144,13 +1156,7 @@ __global__ __launch_bounds__(256) void checksum64_dyn_kernel(const u32 *__restri
                                                              u64 cap_bytes, u64 *out) {
     u64 nwords = 4 * ((totals[1] + 31) >> 5) + totals[2];
     if (nwords > cap_bytes / 4) nwords = cap_bytes / 4;
-    u64 acc = 0;
-    for (u64 i = (u64)blockIdx.x * 256 + threadIdx.x; i < nwords; i += (u64)gridDim.x * 256) {
-        u64 z = ((u64)w[i] << 32 | (u32)i) + (i >> 32) * 0x9E3779B97F4A7C15ull;
-        z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
-        z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
-        acc += z ^ (z >> 31);
-    }
+    u64 acc = checksum64_partial(w, nwords);
 #pragma unroll
     for (int d = 32; d >= 1; d >>= 1) acc += __shfl_xor(acc, d, 64);
     if (lane_id() == 0 && acc) atomicAdd((unsigned long long *)out, (unsigned long long)acc);
@@ -1189,6 +1195,7 @@ static void encode_container_device(tc_ctx *ctx, const u8 *d_text, u64 n, u8 *d_
     u32 sigma = 0;
     i16 final_list[TC_MAX_SIGMA];
     hipStream_t s = ctx->stream;
+    static_assert(RN_TILE == MTF_TILE, "one tile count for the nibble-stream kernels");
     const u32 ntiles = tc_cdiv(N, RN_TILE);
     const u64 esc_cap = N / 5 + 16;
     bool fused = false;
@@ -1211,9 +1218,77 @@ static void encode_container_device(tc_ctx *ctx, const u8 *d_text, u64 n, u8 *d_
         }
         BwtAcc acc{d_L, (i64)primary};
         bool idx8 = false;
+        // a record over <= 6 symbols: MTF, RLE and the wire format in ONE kernel (tc_pack.hpp, mtf_rle_kernel<true>);
+        // its scratch first (the dry run does not know sigma yet)
+        u64 *fstatus = A.get<u64>(2 * (size_t)ntiles + 32);
+        u32 *fesc = A.get<u32>(esc_cap);
+        auto write_header = [&]() {   // what the host knows of the header; the seal kernel fills in the rest
+            ContainerHeader h;
+            memset(&h, 0, sizeof h);
+            memcpy(h.magic, kContainerMagic, 8);
+            h.n = n; h.primary = primary; h.sigma = sigma; h.format = (u32)pack_format(sigma);
+            for (u32 i = 0; i < sigma; i++) h.final_list[i] = final_list[i];
+            memset(ctx->h_hdr, 0, TC_CONTAINER_HEADER);
+            memcpy(ctx->h_hdr, &h, sizeof h);
+            tc_h2d(ctx, d_out, ctx->h_hdr, TC_CONTAINER_HEADER);
+        };
+        auto seal = [&](u64 *totals, u32 *esc_list) {
+            u8 *body = d_out + TC_CONTAINER_HEADER;
+            const u64 body_cap = cap - TC_CONTAINER_HEADER;
+            u64 *sum = totals + 4, *result = totals + 5;
+            nib_escapes_kernel<<<64, 256, 0, s>>>(totals, esc_list, body, body_cap, esc_cap);
+            TC_LAUNCH_CHECK(ctx);
+            checksum64_dyn_kernel<<<4096, 256, 0, s>>>(reinterpret_cast<const u32 *>(body), totals, body_cap, sum);
+            TC_LAUNCH_CHECK(ctx);
+            container_seal_kernel<<<1, 1, 0, s>>>(d_out, totals, sum, result);
+            TC_LAUNCH_CHECK(ctx);
+            TC_HIP(ctx, hipEventRecord(ctx->ev[3], s));
+            tc_d2h(ctx, &ctx->h_scalars[20], result, 3 * sizeof(u64));
+        };
+        bool one_kernel = false;
+        if (!dry && env_int("TC_MTF_RLE", 1) != 0 && env_int("TC_MTF_FORCE_GENERAL", 0) == 0 && N + 64 < (1ull << 32)) {
+            Alphabet al;
+            al.build(counts257);
+            if (al.sigma <= PK_NIB_SIGMA) {
+                u8 *body = d_out + TC_CONTAINER_HEADER;
+                const u64 body_cap = cap - TC_CONTAINER_HEADER;
+                const u64 most = ((N + 31) / 32 + 1) * 16;       // at most one nibble per symbol
+                tc_memset_async(ctx, fstatus, 0, (2 * (size_t)ntiles + 32) * sizeof(u64));
+                tc_memset_async(ctx, body, 0, most < (body_cap & ~15ull) ? most : (body_cap & ~15ull));
+                MtfRleArgs a;
+                memset(&a, 0, sizeof a);
+                for (int v = 0; v < 257; v++) a.lut.v[v] = (u8)al.code_of_sym[v];
+                a.acc = acc; a.N = N; a.sigma = al.sigma;
+                a.status_a = fstatus; a.status_b = fstatus + ntiles;
+                a.ticket = reinterpret_cast<u32 *>(fstatus + 2 * (size_t)ntiles);
+                a.flag = reinterpret_cast<u32 *>(fstatus + 2 * (size_t)ntiles + 1);
+                a.totals = fstatus + 2 * (size_t)ntiles + 8;
+                a.scalars = ctx->d_scalars; a.err = ctx->d_err; a.ntiles = ntiles;
+                a.out = body; a.cap_units = body_cap / 16; a.esc = fesc; a.esc_cap = esc_cap;
+                mtf_rle_kernel<true><<<ntiles, MTF_NT, 0, s>>>(a);
+                TC_LAUNCH_CHECK(ctx);
+                u64 *d_final = fstatus + 2 * (size_t)ntiles + 2;
+                mtf_nib_final_kernel<BwtAcc><<<1, 64, 0, s>>>(acc, N, a.lut, al.sigma, d_final, a.flag);
+                TC_LAUNCH_CHECK(ctx);
+                tc_d2h(ctx, &ctx->h_scalars[15], a.flag, sizeof(u32));
+                tc_d2h(ctx, &ctx->h_scalars[8], d_final, sizeof(u64));
+                TC_HIP(ctx, hipStreamSynchronize(s));
+                if ((u32)ctx->h_scalars[15] == 0) {
+                    const u64 perm = ctx->h_scalars[8];
+                    sigma = al.sigma;
+                    for (u32 i = 0; i < sigma; i++) final_list[i] = al.sym_of_code[(perm >> (4 * i)) & 15];
+                    TC_HIP(ctx, hipEventRecord(ctx->ev[2], s));
+                    write_header();
+                    seal(a.totals, fesc);
+                    one_kernel = true;
+                    fused = true;
+                }
+            }
+        }
+        if (!one_kernel)
         mtf_encode_device<BwtAcc>(ctx, A, acc, N, dry ? nullptr : counts257, d_idx, final_list, &sigma, dry,
                                   reinterpret_cast<u8 *>(d_idx), &idx8);
-        if (!dry) TC_HIP(ctx, hipEventRecord(ctx->ev[2], s));
+        if (!dry && !one_kernel) TC_HIP(ctx, hipEventRecord(ctx->ev[2], s));
         // scratch of both ways (the dry run does not know sigma yet)
         status = A.get<u64>(2 * (size_t)ntiles + 32);
         u32 *esc = A.get<u32>(esc_cap);
@@ -1226,6 +1301,10 @@ static void encode_container_device(tc_ctx *ctx, const u8 *d_text, u64 n, u8 *d_
             rle_encode_device<U16Acc, u16>(ctx, A, iacc, N, r_cnt, r_val, N + 2, &t, true);
             pack_base = A.off;
             (void)A.get<u8>(block_pack_scratch(N + 2));
+            if (A.off < end_sa) A.off = end_sa;
+            return;
+        }
+        if (one_kernel) {
             if (A.off < end_sa) A.off = end_sa;
             return;
         }
