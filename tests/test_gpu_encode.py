@@ -538,3 +538,35 @@ def test_place_workspace_keeps_results(ctx):
     b2 = ctx.encode(t)                                   # the context goes on working on the kept block
     assert b2["primary"] == eprim and np.array_equal(b2["run_count"], ec)
     assert ctx.suffix_array(t.tobytes()).tolist() == O.suffix_array(t.tobytes()).tolist()
+
+
+def test_one_kernel_mtf_rle_and_its_fallback(ctx, monkeypatch):
+    """sigma <= 8: MTF and RLE (and, for the container of sigma <= 6, the wire format) are one kernel whose tiles
+    recover their incoming list by the backward scan; a last column where two codes are met only near the start
+    leaves that scan ambiguous far from it, the kernel raises its flag and the encode runs the separate stages.
+    Both ways, block and container, against the oracle and against each other (TC_MTF_RLE=0: never the one kernel)."""
+    import torch
+    rng = np.random.default_rng(77)
+    plain = bytes(rng.choice(list(b"ACGTN"), 300000).astype(np.uint8))
+    # 'G' and 'T' once each, at the front: their places in the last column are far from most tiles
+    rare = b"GT" + bytes(rng.choice(list(b"AC"), 400000).astype(np.uint8))
+    runs = b"A" * 70000 + bytes(rng.choice(list(b"AC"), 50000).astype(np.uint8)) + b"C" * 70001
+    for t in (plain, rare, runs):
+        L = O.bwt_encode_arr(t)
+        eidx, efl = O.mtf_encode_arr(L)
+        ec, ev = O.rle_encode_u32_arr(eidx)
+        blobs = []
+        for sel in ("1", "0"):
+            monkeypatch.setenv("TC_MTF_RLE", sel)
+            blk = ctx.encode(t)
+            assert blk["final_list"].tolist() == efl.tolist(), sel
+            assert blk["run_count"].tolist() == ec.tolist() and blk["run_value"].tolist() == ev.tolist(), sel
+            n = len(t)
+            d_t = torch.from_numpy(np.frombuffer(t, np.uint8).copy()).cuda()
+            bound = int(ctx.lib.tc_container_bound(n + 2, 257))
+            d_o = torch.full((bound + 16,), 0x5A, dtype=torch.uint8, device="cuda")
+            torch.cuda.synchronize()
+            used = ctx.encode_container_dev(d_t.data_ptr(), n, d_o.data_ptr(), bound)
+            blobs.append(d_o[:used].cpu().numpy().tobytes())
+            assert ctx.decode_container(blobs[-1]) == t, sel
+        assert blobs[0] == blobs[1] == ctx.encode_container(t)
