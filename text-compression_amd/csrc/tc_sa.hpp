@@ -336,11 +336,17 @@ __global__ __launch_bounds__(GRP_NT, 4) void group_kernel(GroupArgs a) {
         carry = a.keys[base - 1] & KMASK;
         has_prev = true;
     }
+    u64 raws[GRP_ITEMS];   // (all of a lane's keys first: one load per turn of the loop below was eight latencies in a row)
+#pragma unroll
+    for (int k = 0; k < GRP_ITEMS; k++) {
+        const u64 j = base + k * 64 + l;
+        raws[k] = j < count ? a.keys[j] : 0;
+    }
 #pragma unroll
     for (int k = 0; k < GRP_ITEMS; k++) {
         u64 j = base + k * 64 + l;
         bool in = j < count;
-        u64 raw = in ? a.keys[j] : 0;
+        u64 raw = raws[k];
         u64 key = raw & KMASK;
         if (INIT) lowb[k >> 2] |= (u32)(raw & 0xff) << (8 * (k & 3));
         u64 up = __shfl_up(key, 1, 64);
@@ -404,6 +410,15 @@ __global__ __launch_bounds__(GRP_NT, 4) void group_kernel(GroupArgs a) {
     u32 cur_cnt = (u32)s_pref[1] + psum;
 
     // ---- phase 2: ranks, outputs, compaction -------------------------------------
+    u32 k0s[INIT ? 1 : GRP_ITEMS], slots[INIT ? 1 : GRP_ITEMS];
+    if (!INIT) {
+#pragma unroll
+        for (int k = 0; k < GRP_ITEMS; k++) {
+            const u64 j = base + (u64)k * 64 + l;
+            k0s[k] = j < count ? a.vals[j] : 0u;
+            slots[k] = j < count ? a.in_slot[j] : 0u;
+        }
+    }
 #pragma unroll
     for (int k = 0; k < GRP_ITEMS; k++) {
         const u64 jb = base + (u64)k * 64;
@@ -413,8 +428,8 @@ __global__ __launch_bounds__(GRP_NT, 4) void group_kernel(GroupArgs a) {
         const bool act = (ab[k] >> l) & 1ull;
         u32 k0 = 0, slot = 0;
         if (!INIT && in) {
-            k0 = a.vals[j];
-            slot = a.in_slot[j];
+            k0 = k0s[k];
+            slot = slots[k];
         }
         // group start for this lane: last head at or before it (every lane executes
         // the shuffles; lanes without a head in range take the running scalar)
@@ -546,11 +561,18 @@ __global__ __launch_bounds__(RSCAT_NT) void rank_scatter_kernel(const u64 *__res
                                                                  const u32 *__restrict__ cursor, u32 *__restrict__ isa) {
     const u64 base = (u64)blockIdx.x * (RSCAT_NT * RSCAT_ITEMS);
     u64 x[RSCAT_ITEMS];
+    u32 cur[RSCAT_ITEMS];
     bool ok[RSCAT_ITEMS];
+    // (the fill marks first, then the pairs: as one loop it was a mark load, a wait, a pair load, a wait -- eight times)
 #pragma unroll
     for (int k = 0; k < RSCAT_ITEMS; k++) {
         const u64 p = base + (u64)k * RSCAT_NT + threadIdx.x;
-        ok[k] = p < nslots && (u32)p < cursor[p >> shift];
+        cur[k] = p < nslots ? cursor[p >> shift] : 0u;
+    }
+#pragma unroll
+    for (int k = 0; k < RSCAT_ITEMS; k++) {
+        const u64 p = base + (u64)k * RSCAT_NT + threadIdx.x;
+        ok[k] = p < nslots && (u32)p < cur[k];
         x[k] = ok[k] ? part[p] : 0ull;
     }
 #pragma unroll
