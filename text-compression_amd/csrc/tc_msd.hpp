@@ -1239,16 +1239,31 @@ __global__ __launch_bounds__(256, 6) void msd_finish_ko_kernel(MsdFinishArgs a, 
     __shared__ u32 s_low[TILE + 4];                                    // key bits 39..8, in bin order
     __shared__ __attribute__((aligned(16))) u8 s_L[TILE + 8];          // preceding bytes, in final order, shifted by start & 3
     __shared__ u32 s_aw[256];                                          // a | w << 16
-    __shared__ u16 s_c[256], s_cc[256];
+    __shared__ u16 s_c[256];
+    __shared__ u32 s_live[256 + 4];                                    // the parent's non-empty children: child << 16 | min(pairs, 65535)
     __shared__ u32 s_scan[NT / 64 + 1];
     const u32 q = blockIdx.x;
     if (a.pcnt[q] == 0 || (a.counters[1] & 8u)) return;   // (bit 3: the level-3 counts did not add up)
     const u32 tid = threadIdx.x, l = tid & 63;
+    u32 nlive;
     {
         const u32 c = a.ccnt[(size_t)q * 256 + tid];
-        s_cc[tid] = (u16)(c > 65535u ? 65535u : c);                    // (> TILE is all that matters of a long one)
         s_aw[tid] = lut->a[tid] | (lut->w[tid] << 16);
         s_c[tid] = (u16)lut->c[tid];
+        // the non-empty children, in order, as one list: a chunk is then three consecutive entries (one LDS round
+        // trip instead of a walk over the counts, a dependent read per child)
+        const u64 m = __ballot(c != 0);
+        if (l == 0) s_scan[tid >> 6] = (u32)__popcll(m);
+        __syncthreads();
+        u32 before = 0, all = 0;
+        for (u32 w = 0; w < NT / 64; w++) {
+            const u32 x = s_scan[w];
+            before += w < (tid >> 6) ? x : 0u;
+            all += x;
+        }
+        nlive = all;
+        if (c) s_live[before + (u32)__popcll(m & lanemask_lt())] = (tid << 16) | (c > 65535u ? 65535u : c);   // (> TILE is all that matters of a long one)
+        if (tid < 4) s_live[all + tid] = (256u << 16) | 0xffffu;      // (ends the list: fits no chunk)
     }
     const u32 region = blockIdx.x % FIN_REGIONS;
     u32 *rctr = a.rcount + region * FIN_RSTRIDE;
@@ -1258,36 +1273,30 @@ __global__ __launch_bounds__(256, 6) void msd_finish_ko_kernel(MsdFinishArgs a, 
     // a chunk: up to CH non-empty children (c0 < l1 < l2; 256: none) of at most TILE pairs together; `ch` walks the
     // children, `run` the pairs before them.  Every thread walks the same counts (LDS broadcasts), the results scalar.
     struct Chunk { u32 c0, l1, l2, tot, off; };
-    u32 ch = 0, run = 0;
+    u32 lj = 0, run = 0;
     auto walk = [&](Chunk &k) -> bool {
         while (true) {
-            while (ch < 256 && s_cc[ch] == 0) ch++;
-            if (ch >= 256) return false;
-            if (s_cc[ch] <= TILE) break;
-            // a bucket no chunk can hold (repeats, poly-A): bit 2, the caller takes the LSD way
-            if (tid == 0) atomicOr(&a.counters[1], 4u);
-            run += a.ccnt[(size_t)q * 256 + ch];
-            ch++;
-        }
-        u32 c0 = ch, l1 = 256, l2 = 256, tot = s_cc[ch], nl = 1;
-        ch++;
-        while (ch < 256) {
-            const u32 c = s_cc[ch];
-            if (c) {
-                if (nl == (u32)CH || tot + c > TILE) break;
-                if (nl == 1) l1 = ch; else l2 = ch;
-                tot += c;
-                nl++;
+            if (lj >= nlive) return false;
+            const u32 e0 = s_live[lj], e1 = s_live[lj + 1], e2 = s_live[lj + 2];
+            const u32 n0 = e0 & 0xffffu, n1 = e1 & 0xffffu, n2 = e2 & 0xffffu;
+            if (n0 > TILE) {
+                // a bucket no chunk can hold (repeats, poly-A): bit 2, the caller takes the LSD way
+                if (tid == 0) atomicOr(&a.counters[1], 4u);
+                run += a.ccnt[(size_t)q * 256 + (e0 >> 16)];
+                lj++;
+                continue;
             }
-            ch++;
+            const bool t1 = n0 + n1 <= TILE, t2 = t1 && n0 + n1 + n2 <= TILE;
+            const u32 tot = n0 + (t1 ? n1 : 0u) + (t2 ? n2 : 0u);
+            k.c0 = (u32)__builtin_amdgcn_readfirstlane((int)(e0 >> 16));
+            k.l1 = (u32)__builtin_amdgcn_readfirstlane((int)(t1 ? e1 >> 16 : 256u));
+            k.l2 = (u32)__builtin_amdgcn_readfirstlane((int)(t2 ? e2 >> 16 : 256u));
+            k.tot = (u32)__builtin_amdgcn_readfirstlane((int)tot);
+            k.off = (u32)__builtin_amdgcn_readfirstlane((int)run);
+            run += tot;
+            lj += 1u + (u32)t1 + (u32)t2;
+            return true;
         }
-        k.c0 = (u32)__builtin_amdgcn_readfirstlane((int)c0);
-        k.l1 = (u32)__builtin_amdgcn_readfirstlane((int)l1);
-        k.l2 = (u32)__builtin_amdgcn_readfirstlane((int)l2);
-        k.tot = (u32)__builtin_amdgcn_readfirstlane((int)tot);
-        k.off = (u32)__builtin_amdgcn_readfirstlane((int)run);
-        run += tot;
-        return true;
     };
     // the keys of the NEXT chunk are loaded while this one is ranked and copied out (the barriers in between are
     // LDS-only, so nothing waits for them before their first use); a slot past the chunk re-reads its first key.
