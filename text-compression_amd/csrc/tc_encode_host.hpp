@@ -307,6 +307,7 @@ static void sa_run(tc_ctx *ctx, SaBuffers &b, const u8 *d_text, u64 n, u32 *d_sa
         const bool fuse = onehist && RDX_TILE == SA_TILE && env_int("TC_KEYGEN_FUSED", 1) != 0;
         st.keygen_fused = fuse ? 1u : 0u;
         RadixKeyGen kg;
+        kg.hash_ok = 0; kg.hsh = 0; kg.tlo = 0; kg.thi = 0;
         if (fuse) {
             kg.n_text = (u32)n; kg.B = cfg.B; kg.w = cfg.w; kg.s = cfg.s; kg.P = cfg.P;
             memcpy(kg.lut, cfg.lut, sizeof kg.lut);
@@ -455,6 +456,8 @@ static void sa_run(tc_ctx *ctx, SaBuffers &b, const u8 *d_text, u64 n, u32 *d_sa
                 RadixKeyGen kg;
                 kg.n_text = (u32)n; kg.B = cfg.B; kg.w = cfg.w; kg.s = cfg.s; kg.P = cfg.P;
                 memcpy(kg.lut, cfg.lut, sizeof kg.lut);
+                radix_keygen_hash(kg);
+                if (env_int("TC_KEYGEN_HASH", 1) == 0) kg.hash_ok = 0;
                 MsdTextDigit td;
                 td.text = d_text; td.n = (u32)n; td.B = cfg.B; td.s = cfg.s;
                 memcpy(td.lut, cfg.lut, sizeof td.lut);
@@ -643,6 +646,7 @@ static void sa_run(tc_ctx *ctx, SaBuffers &b, const u8 *d_text, u64 n, u32 *d_sa
                     tied_table_kernel<<<tc_cdiv(fm, 256), 256, 0, s>>>(b.act[0][1], b.act[0][3], b.act[0][2], fm, cfg.B, cfg.s, cfg.P, b.tp);
                     TC_LAUNCH_CHECK(ctx);
                     RadixKeyGen kgp;
+                    kgp.hash_ok = 0; kgp.hsh = 0; kgp.tlo = 0; kgp.thi = 0;
                     kgp.n_text = (u32)n; kgp.B = cfg.B; kgp.w = cfg.w; kgp.s = cfg.s; kgp.P = cfg.P;
                     memcpy(kgp.lut, cfg.lut, sizeof kgp.lut);
                     u32 pgrid = (u32)ctx->num_cus * 3;

@@ -650,6 +650,18 @@ __global__ __launch_bounds__(MSD_NT) void msd_partition_kernel(MsdLevel L, const
                 const u32 *rp = reinterpret_cast<const u32 *>(k_r + KG_PRE + 8 * grp);
                 const u32 x0 = rp[0], x1 = rp[1], x2 = rp[2];
                 u32 c[10];
+                if (kg.hash_ok) {   // (block-uniform) the codes of four bytes by one v_perm_b32 from a table in registers
+                    const u32 y0 = __builtin_amdgcn_perm(kg.thi, kg.tlo, (x0 >> kg.hsh) & 0x07070707u);
+                    const u32 y1 = __builtin_amdgcn_perm(kg.thi, kg.tlo, (x1 >> kg.hsh) & 0x07070707u);
+                    const u32 y2 = __builtin_amdgcn_perm(kg.thi, kg.tlo, (x2 >> kg.hsh) & 0x07070707u);
+#pragma unroll
+                    for (int j = 0; j < 4; j++) {
+                        c[j] = (y0 >> (8 * j)) & 255u;
+                        c[4 + j] = (y1 >> (8 * j)) & 255u;
+                    }
+                    c[8] = y2 & 255u;
+                    c[9] = (y2 >> 8) & 255u;
+                } else {
 #pragma unroll
                 for (int j = 0; j < 4; j++) {
                     c[j] = (u32)s_klut[(x0 >> (8 * j)) & 255u];
@@ -657,6 +669,7 @@ __global__ __launch_bounds__(MSD_NT) void msd_partition_kernel(MsdLevel L, const
                 }
                 c[8] = (u32)s_klut[x2 & 255u];
                 c[9] = (u32)s_klut[(x2 >> 8) & 255u];
+                }
                 u32 lo = 0, hi = 0;
 #pragma unroll
                 for (int j = 0; j < 8; j++) {

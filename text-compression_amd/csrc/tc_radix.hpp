@@ -59,7 +59,32 @@ struct RadixKeyGen {
     u32 n_text;   // text length; pairs sorted = n_text + 1
     u32 B, w, s, P;
     u16 lut[256];
+    // byte -> code without a table read, for alphabets of at most 8 bytes whose values differ in three adjacent bits
+    // (ACGTN: bits 1..3): code = byte ((byte >> hsh) & 7) of the 8-byte table (tlo, thi), four bytes per v_perm_b32
+    u32 hash_ok, hsh, tlo, thi;
 };
+// (host) fill the hash fields of a key generator from its lut
+static inline void radix_keygen_hash(RadixKeyGen &kg) {
+    kg.hash_ok = 0; kg.hsh = 0; kg.tlo = 0; kg.thi = 0;
+    int nb = 0, bytes[256];
+    for (int v = 0; v < 256; v++)
+        if (kg.lut[v]) bytes[nb++] = v;
+    if (nb == 0 || nb > 8) return;
+    for (u32 sh = 0; sh <= 5; sh++) {
+        u32 seen = 0;
+        bool ok = true;
+        for (int i = 0; i < nb && ok; i++) {
+            const u32 h = ((u32)bytes[i] >> sh) & 7u;
+            ok = !((seen >> h) & 1u) && kg.lut[bytes[i]] < 256;
+            seen |= 1u << h;
+        }
+        if (!ok) continue;
+        unsigned long long t = 0;
+        for (int i = 0; i < nb; i++) t |= (unsigned long long)(kg.lut[bytes[i]] & 0xffu) << (8 * (((u32)bytes[i] >> sh) & 7u));
+        kg.hash_ok = 1; kg.hsh = sh; kg.tlo = (u32)t; kg.thi = (u32)(t >> 32);
+        return;
+    }
+}
 
 struct RadixPlanDev {
     int npass;
