@@ -336,7 +336,7 @@ static void sa_run(tc_ctx *ctx, SaBuffers &b, const u8 *d_text, u64 n, u32 *d_sa
         if (start_in_va) { rb.vals = va; rb.vals_alt = b.v0; }
         else { rb.vals = b.v0; rb.vals_alt = va; }
         rb.hist = b.hist;
-        rb.status = b.rstatus;
+        rb.status = b.rstatus; rb.status_cap = radix_status_words(N);
         ctx->pev_used = 0;
         radix_sort_pairs(ctx, rb, (u32)N, plan, /*gen_idx=*/true, /*hist_ready=*/true, /*timed=*/true,
                          d_text, fuse ? &kg : nullptr,
@@ -723,7 +723,7 @@ static void sa_run(tc_ctx *ctx, SaBuffers &b, const u8 *d_text, u64 n, u32 *d_sa
                     ps.add_range(32, 32 + (int)slot_bits);
                     RadixBuffers rs;
                     rs.keys = b.sk[0]; rs.keys_alt = b.sk[1]; rs.vals = b.sv[0]; rs.vals_alt = b.sv[1];
-                    rs.hist = b.hist; rs.status = b.rstatus;
+                    rs.hist = b.hist; rs.status = b.rstatus; rs.status_cap = radix_status_words(N);
                     radix_sort_pairs(ctx, rs, mm, ps, false, false);
                     unpack_active_kernel<<<tc_cdiv(mm, 256), 256, 0, s>>>(rs.keys, mm, b.act[0][0], b.act[0][2]);
                     TC_LAUNCH_CHECK(ctx);
@@ -806,7 +806,7 @@ static void sa_run(tc_ctx *ctx, SaBuffers &b, const u8 *d_text, u64 n, u32 *d_sa
             pt.add_range(0, rbits);
             RadixBuffers rt;
             rt.keys = b.sk[0]; rt.keys_alt = b.sk[1]; rt.vals = b.sv[0]; rt.vals_alt = b.sv[1];
-            rt.hist = b.hist; rt.status = b.rstatus;
+            rt.hist = b.hist; rt.status = b.rstatus; rt.status_cap = radix_status_words(N);
             radix_sort_pairs(ctx, rt, mm, pt, true, false);
             // large tied sets: bitmap + popcount directory instead of a binary search per lookup,
             // and a directory into the sorted keys for the ranks of untied suffixes
@@ -882,7 +882,7 @@ static void sa_run(tc_ctx *ctx, SaBuffers &b, const u8 *d_text, u64 n, u32 *d_sa
         trace("round: keys (rank lookups)", mm);
         RadixBuffers r2;
         r2.keys = k2; r2.keys_alt = k2alt; r2.vals = kv; r2.vals_alt = kvalt;
-        r2.hist = b.hist; r2.status = b.rstatus;
+        r2.hist = b.hist; r2.status = b.rstatus; r2.status_cap = radix_status_words(N);
         radix_sort_pairs(ctx, r2, mm, p2, /*gen_idx=*/!vals_idx, /*hist_ready=*/fuse_hist);
         trace("round: radix passes", mm);
         GroupArgs gr = {};

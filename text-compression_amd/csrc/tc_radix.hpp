@@ -489,6 +489,8 @@ struct RadixBuffers {
     u32 *vals, *vals_alt;
     u32 *hist;    // [RDX_MAX_PASSES][256]
     u64 *status;  // [tiles*256 + 2]
+    size_t status_cap = 0;   // words behind `status` (0: unknown).  With room for every pass's status the sort zeroes
+                             // them all at once instead of once per pass (a small sort is mostly its launches)
 };
 static inline size_t radix_status_words(u64 n) {
     size_t t = tc_cdiv(n, RDX_TILE);

@@ -54,9 +54,14 @@ void radix_sort_pairs(tc_ctx *ctx, RadixBuffers &b, u32 n, const RadixPlan &plan
     TC_LAUNCH_CHECK(ctx);
     const u32 tiles = tc_cdiv(n, RDX_TILE);
     const size_t words = (size_t)tiles * RDX_BINS + 130;
+    // (a sort of a few thousand pairs is mostly launches: one zeroing for all its passes where the buffer has the room)
+    const bool once = n <= (1u << 20) && b.status_cap >= (size_t)plan.npass * words;
+    u64 *const status0 = b.status;
+    if (once) TC_HIP(ctx, hipMemsetAsync(status0, 0, (size_t)plan.npass * words * sizeof(u64), s));
     for (int p = 0; p < plan.npass; p++) {
+        if (once) b.status = status0 + (size_t)p * words;
         u32 *ticket = reinterpret_cast<u32 *>(b.status + (size_t)tiles * RDX_BINS);
-        TC_HIP(ctx, hipMemsetAsync(b.status, 0, words * sizeof(u64), s));
+        if (!once) TC_HIP(ctx, hipMemsetAsync(b.status, 0, words * sizeof(u64), s));
         const bool ev = timed && ctx->profile && ctx->pev_used < 16;
         if (ev) TC_HIP(ctx, hipEventRecord(ctx->pev[2 * ctx->pev_used], s));
         if (p == 0 && keygen)
@@ -75,4 +80,5 @@ void radix_sort_pairs(tc_ctx *ctx, RadixBuffers &b, u32 n, const RadixPlan &plan
         u64 *tk = b.keys; b.keys = b.keys_alt; b.keys_alt = tk;
         u32 *tv = b.vals; b.vals = b.vals_alt; b.vals_alt = tv;
     }
+    b.status = status0;
 }
