@@ -875,6 +875,8 @@ static void sa_run(tc_ctx *ctx, SaBuffers &b, const u8 *d_text, u64 n, u32 *d_sa
             // one lookup per thread for small sets (latency-bound); coarser when histograms are kept
             u32 kgrid = fuse_hist ? tc_cdiv(mm, 256 * 8) : tc_cdiv(mm, 256);
             if (fuse_hist && kgrid > 8192) kgrid = 8192;
+            // (a few thousand members looked up by counts inside unsorted buckets: the kernel takes a wave per member)
+            if (!fuse_hist && !vals_idx && !rl.isa && !rl.skeys && rl.tkeys && mm <= 65536u) kgrid = tc_cdiv(mm, 4);
             if (fuse_hist) key2_kernel<true><<<kgrid, 256, 0, s>>>(b.act[cur][1], b.act[cur][2], rl, mm, hh, k2, vals_idx ? kv : nullptr, pd2, b.hist);
             else key2_kernel<false><<<kgrid, 256, 0, s>>>(b.act[cur][1], b.act[cur][2], rl, mm, hh, k2, vals_idx ? kv : nullptr, pd2, b.hist);
         }

@@ -1301,6 +1301,9 @@ __device__ __forceinline__ int suffix_cmp(const u8 *text, u32 n, u64 x, u64 y, u
     return 0;
 }
 
+// WAVE: every lane of the wave asks for the SAME p (a few thousand lookups in all: one wave each); the count inside
+// the unsorted bucket is then taken 64 keys per step instead of 8 by one lane
+template <bool WAVE = false>
 __device__ __forceinline__ u32 rank_of(const RankLookup &r, const u16 *s_lut, u64 p) {
     if (p >= r.N) return 0u;
     if (r.isa) return r.isa[p];
@@ -1353,6 +1356,18 @@ __device__ __forceinline__ u32 rank_of(const RankLookup &r, const u16 *s_lut, u6
             // the MSD way holds ~550 keys, and a walk of dependent loads took 0.3 ms per round)
             u32 below = 0;
             u64 j = lo;
+            if (WAVE) {
+                const u32 l = lane_id();
+                for (;; j += 64) {
+                    const u64 jj = j + l;
+                    const u64 t = jj < r.N ? r.tkeys[jj] : ~0ull;
+                    const bool out = jj >= r.N || (t >> r.tshift) != tk;
+                    const u64 ob = __ballot(out);
+                    const u64 inside = ob ? ((1ull << __builtin_ctzll(ob)) - 1ull) : ~0ull;   // lanes before the bucket's end
+                    below += (u32)__popcll(__ballot(!out && (t & ~0xffull) < key) & inside);
+                    if (ob) return (u32)lo + below;
+                }
+            }
             for (; j + 8 <= r.N; j += 8) {
                 u64 t[8];
 #pragma unroll
@@ -1400,6 +1415,16 @@ __global__ __launch_bounds__(256) void key2_kernel(const u32 *__restrict__ idx,
     if (HIST)
         for (int i = threadIdx.x; i < plan.npass * RDX_BINS; i += 256) s_h[i] = 0;
     __syncthreads();
+    if (!HIST && !r.isa && !r.skeys && r.tkeys && vals_out == nullptr && m <= 65536u) {
+        // a few thousand members whose partners' ranks are counts inside unsorted buckets: one wave per member
+        const u32 wave = (blockIdx.x * 256 + threadIdx.x) >> 6, nwaves = gridDim.x * 4;
+        for (u32 k = wave; k < m; k += nwaves) {
+            const u32 i = idx[k];
+            const u32 rk = rank_of<true>(r, s_lut, (u64)i + h);
+            if (lane_id() == 0) keys[k] = ((u64)grp[k] << 32) | rk;
+        }
+        return;
+    }
     for (u64 k = (u64)blockIdx.x * 256 + threadIdx.x; k < m; k += (u64)gridDim.x * 256) {
         const u32 i = idx[k];
         const u64 key = ((u64)grp[k] << 32) | rank_of(r, s_lut, (u64)i + h);  // idx + h <= n for a tied suffix
@@ -1433,6 +1458,13 @@ __global__ void primary_kernel(RankLookup r, u64 *scalars) {
     __shared__ u16 s_lut[256];
     for (int i = threadIdx.x; i < 256; i += blockDim.x) s_lut[i] = r.lut[i];
     __syncthreads();
+    if (!r.isa && !r.skeys && r.tkeys) {   // (a count inside an unsorted bucket: by the whole wave)
+        if (threadIdx.x < 64) {
+            const u32 rk = rank_of<true>(r, s_lut, 0);
+            if (threadIdx.x == 0) scalars[0] = rk;
+        }
+        return;
+    }
     if (threadIdx.x == 0) scalars[0] = rank_of(r, s_lut, 0);
 }
 
