@@ -133,6 +133,36 @@ __global__ __launch_bounds__(1024) void msd_prep_kernel(const u32 *__restrict__ 
     const u32 per = (nparents + 1023) / 1024;
     const u32 lo = threadIdx.x * per;
     u32 sum = 0;
+    if (per == 64 && nparents == 65536u) {
+        // level 3: a thread's 64 parents by sixteen 16-byte loads issued together (a load per loop turn, twice, was 128
+        // latencies in a row: 130 us of a launch that does nothing else)
+        uint4 v[16];
+        const uint4 *pv = reinterpret_cast<const uint4 *>(pcnt + lo);
+#pragma unroll
+        for (int i = 0; i < 16; i++) v[i] = pv[i];
+        u32 t[64];
+#pragma unroll
+        for (int i = 0; i < 16; i++) {
+            t[4 * i] = (v[i].x + MSD_TILE - 1) / MSD_TILE; t[4 * i + 1] = (v[i].y + MSD_TILE - 1) / MSD_TILE;
+            t[4 * i + 2] = (v[i].z + MSD_TILE - 1) / MSD_TILE; t[4 * i + 3] = (v[i].w + MSD_TILE - 1) / MSD_TILE;
+        }
+#pragma unroll
+        for (int i = 0; i < 64; i++) sum += t[i];
+        u32 tot;
+        u32 run = block_excl_sum<1024>(sum, s_scan, &tot);
+        uint4 *ov = reinterpret_cast<uint4 *>(tpre + lo);
+#pragma unroll
+        for (int i = 0; i < 16; i++) {
+            uint4 o;
+            o.x = run; run += t[4 * i];
+            o.y = run; run += t[4 * i + 1];
+            o.z = run; run += t[4 * i + 2];
+            o.w = run; run += t[4 * i + 3];
+            ov[i] = o;
+        }
+        if (threadIdx.x == 0) tpre[nparents] = tot;
+        return;
+    }
     for (u32 i = 0; i < per; i++) {
         const u32 q = lo + i;
         if (q < nparents) sum += (pcnt[q] + MSD_TILE - 1) / MSD_TILE;
@@ -365,17 +395,23 @@ __global__ __launch_bounds__(256) void msd_scan_kernel(MsdLevel L, u32 G, u32 *m
     // (workgroups between bf and bl whose tile range is empty -- fewer tiles than workgroups -- own no
     // segment and wrote nothing)
     u32 tot = 0;
-    for (u32 b = bf; b <= bl; b++)
-        if (msd_tile_lo(T, b, G) < msd_tile_lo(T, b + 1, G)) tot += L.seg[((size_t)q + b) * 256 + d];
+    // (level 1 is ONE parent split over all G workgroups: a thread sums G counts.  The loads do not depend on each other --
+    // read unconditionally, eight in flight -- only the adds do)
+#pragma unroll 8
+    for (u32 b = bf; b <= bl; b++) {
+        const u32 v = L.seg[((size_t)q + b) * 256 + d];
+        tot += msd_tile_lo(T, b, G) < msd_tile_lo(T, b + 1, G) ? v : 0u;
+    }
     u32 all;
     const u32 excl = block_excl_sum<256>(tot, s_scan, &all);
     u32 run = L.pstart[q] + excl;
     L.cstart[c] = run;
     L.ccnt[c] = tot;
+#pragma unroll 8
     for (u32 b = bf; b <= bl; b++) {
-        if (msd_tile_lo(T, b, G) >= msd_tile_lo(T, b + 1, G)) continue;
         const size_t o = ((size_t)q + b) * 256 + d;
         const u32 v = L.seg[o];
+        if (msd_tile_lo(T, b, G) >= msd_tile_lo(T, b + 1, G)) continue;
         L.seg[o] = run;
         run += v;
     }
