@@ -622,15 +622,48 @@ __global__ __launch_bounds__(1024) void sample_dup_kernel(const u8 *__restrict__
     __syncthreads();
     u32 dups = 0;
     const u32 nf = ((u32)topbits + kg.w - 1) / kg.w;  // fields that reach into the top bits
-    for (u32 k = threadIdx.x; k < SAMP_N; k += 1024) {
+    // a thread's eight samples: their text first -- four (unaligned) 32-bit loads each, all 32 issued together -- then the
+    // keys (a byte load per symbol, each waited for, was ~100 latencies in a row: 120 us of a launch that does nothing else)
+    constexpr int SPT = SAMP_N / 1024;
+    const bool words = nf * kg.s <= 16;
+    u32 tw[SPT][4];
+    u64 qs[SPT];
+#pragma unroll
+    for (int j = 0; j < SPT; j++) {
+        const u32 k = threadIdx.x + 1024u * (u32)j;
         u64 z = (u64)(k + 1) * 0x9E3779B97F4A7C15ull;
         z = (z ^ (z >> 29)) * 0xBF58476D1CE4E5B9ull;
-        u64 q = (u64)(((z >> 32) * (u64)n) >> 32);
+        qs[j] = (u64)(((z >> 32) * (u64)n) >> 32);
+        const bool in = words && qs[j] + 16 <= n;
+#pragma unroll
+        for (int x = 0; x < 4; x++) {
+            u32 v = 0;
+            if (in) __builtin_memcpy(&v, text + qs[j] + 4 * x, 4);
+            tw[j][x] = v;
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < SPT; j++) {
+        u64 q = qs[j];
+        const bool in = words && q + 16 <= n;
         u64 key = 0;
         int sh = 64;
+        u32 pos = 0;
         for (u32 f = 0; f < nf; f++) {
             u32 g = 0;
-            for (u32 t = 0; t < kg.s; t++, q++) g = g * kg.B + (q < n ? (u32)s_lut[text[q]] : 0u);
+            for (u32 t = 0; t < kg.s; t++, q++, pos++) {
+                u32 c;
+                if (in) {
+                    u32 wsel = tw[j][0];   // (a select, not an indexed read: the words stay in registers)
+                    wsel = (pos >> 2) == 1 ? tw[j][1] : wsel;
+                    wsel = (pos >> 2) == 2 ? tw[j][2] : wsel;
+                    wsel = (pos >> 2) == 3 ? tw[j][3] : wsel;
+                    c = (u32)s_lut[(wsel >> (8 * (pos & 3))) & 255u];
+                } else {
+                    c = q < n ? (u32)s_lut[text[q]] : 0u;
+                }
+                g = g * kg.B + c;
+            }
             sh -= kg.w;
             key |= (u64)g << sh;
         }
