@@ -461,6 +461,7 @@ static void sa_run(tc_ctx *ctx, SaBuffers &b, const u8 *d_text, u64 n, u32 *d_sa
                 MsdTextDigit td;
                 td.text = d_text; td.n = (u32)n; td.B = cfg.B; td.s = cfg.s;
                 memcpy(td.lut, cfg.lut, sizeof td.lut);
+                td.hash_ok = kg.hash_ok; td.hsh = kg.hsh; td.tlo = kg.tlo; td.thi = kg.thi;
                 u32 G = b.msd_grid < (u32)ctx->num_cus * MSD_BPC ? b.msd_grid : (u32)ctx->num_cus * MSD_BPC;
                 if (ctx->reserved_cus > 0 && G > (u32)(ctx->num_cus - ctx->reserved_cus) * MSD_BPC)
                     G = (u32)(ctx->num_cus - ctx->reserved_cus) * MSD_BPC;   // (CUs left to the exchange: tc_comm_create)

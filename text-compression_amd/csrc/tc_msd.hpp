@@ -228,6 +228,7 @@ struct MsdTextDigit {
     u32 n;
     u32 B, s;
     u16 lut[256];
+    u32 hash_ok, hsh, tlo, thi;   // byte -> code by v_perm from a register table (RadixKeyGen, tc_radix.hpp)
 };
 
 // Workgroups are dealt round-robin over the 8 XCDs (blockIdx % 8; tc_dbg_dispatch_probe shows it), and the
@@ -304,8 +305,17 @@ __global__ __launch_bounds__(MSD_NT) void msd_count_kernel(MsdLevel L, const u64
                     const u32 wi = (r * MSD_NT + tid) * 4;
                     const u32 x[5] = {tw[wi], tw[wi + 1], tw[wi + 2], tw[wi + 3], tw[wi + 4]};
                     u32 cd[20];
+                    if (td.hash_ok) {   // (block-uniform) four codes by one v_perm_b32 instead of four LDS reads
+#pragma unroll
+                        for (int q = 0; q < 5; q++) {
+                            const u32 y = __builtin_amdgcn_perm(td.thi, td.tlo, (x[q] >> td.hsh) & 0x07070707u);
+#pragma unroll
+                            for (int j = 0; j < 4; j++) cd[4 * q + j] = (y >> (8 * j)) & 255u;
+                        }
+                    } else {
 #pragma unroll
                     for (int j = 0; j < 20; j++) cd[j] = s_lut[(x[j >> 2] >> (8 * (j & 3))) & 255u];
+                    }
 #pragma unroll
                     for (int k = 0; k < 16; k++) {
                         u32 g = 0;
