@@ -301,9 +301,12 @@ __global__ __launch_bounds__(MSD_NT) void msd_count_kernel(MsdLevel L, const u64
                 const u32 span = (u64)hi + 8 <= td.n ? hi - lo : td.n - 8 - lo;
                 const u32 nfull = span / (16 * MSD_NT);
                 const u32 *tw = reinterpret_cast<const u32 *>(td.text + lo);
-                for (u32 r = 0; r < nfull; r++) {
+                auto fetch = [&](u32 r, u32 *x) {
                     const u32 wi = (r * MSD_NT + tid) * 4;
-                    const u32 x[5] = {tw[wi], tw[wi + 1], tw[wi + 2], tw[wi + 3], tw[wi + 4]};
+#pragma unroll
+                    for (int q = 0; q < 5; q++) x[q] = tw[wi + q];
+                };
+                auto tally = [&](const u32 *x) {
                     u32 cd[20];
                     if (td.hash_ok) {   // (block-uniform) four codes by one v_perm_b32 instead of four LDS reads
 #pragma unroll
@@ -314,7 +317,7 @@ __global__ __launch_bounds__(MSD_NT) void msd_count_kernel(MsdLevel L, const u64
                         }
                     } else {
 #pragma unroll
-                    for (int j = 0; j < 20; j++) cd[j] = s_lut[(x[j >> 2] >> (8 * (j & 3))) & 255u];
+                        for (int j = 0; j < 20; j++) cd[j] = s_lut[(x[j >> 2] >> (8 * (j & 3))) & 255u];
                     }
 #pragma unroll
                     for (int k = 0; k < 16; k++) {
@@ -324,6 +327,19 @@ __global__ __launch_bounds__(MSD_NT) void msd_count_kernel(MsdLevel L, const u64
                             if (j < (int)td.s) g = g * td.B + cd[k + j];
                         atomicAdd(&s_cnt[g], 1u);
                     }
+                };
+                // four rounds' loads in flight per thread (one round -- 20 bytes a lane -- left the pass at 2.1 TB/s:
+                // one workgroup per CU, bound by the bytes in flight)
+                u32 r = 0;
+                for (; r + 4 <= nfull; r += 4) {
+                    u32 xa[5], xb[5], xc[5], xd[5];
+                    fetch(r, xa); fetch(r + 1, xb); fetch(r + 2, xc); fetch(r + 3, xd);
+                    tally(xa); tally(xb); tally(xc); tally(xd);
+                }
+                for (; r < nfull; r++) {
+                    u32 x[5];
+                    fetch(r, x);
+                    tally(x);
                 }
                 p = lo + nfull * 16 * MSD_NT;
             }
