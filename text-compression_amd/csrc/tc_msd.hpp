@@ -352,11 +352,18 @@ __global__ __launch_bounds__(MSD_NT) void msd_count_kernel(MsdLevel L, const u64
         } else {
             auto add = [&](u64 k) {
                 const u32 dd = (u32)(k >> (L.shift - 8)) & 0xffffu;   // digit, next digit
-                atomicAdd(&s_cnt[dd >> 8], 1u);
                 if (JOINT) {
+                    // (ONE atomic per key: the digit's own count is the sum of its row of the joint table, taken when
+                    // the table is flushed at the segment's end; a digit without a row -- it holds the end marker: one
+                    // of the text's last suffixes -- is counted directly)
                     const u32 r = s_row[dd >> 8];
                     if (r != 0xffu) atomicAdd(&s_joint[(r << 8) | (dd & 255u)], 1u);
-                    else atomicAdd(&joint_out[((size_t)sq * 256 + (dd >> 8)) * 256 + (dd & 255u)], 1u);
+                    else {
+                        atomicAdd(&s_cnt[dd >> 8], 1u);
+                        atomicAdd(&joint_out[((size_t)sq * 256 + (dd >> 8)) * 256 + (dd & 255u)], 1u);
+                    }
+                } else {
+                    atomicAdd(&s_cnt[dd >> 8], 1u);
                 }
             };
             u32 p = lo + tid;
@@ -367,18 +374,20 @@ __global__ __launch_bounds__(MSD_NT) void msd_count_kernel(MsdLevel L, const u64
             for (; p < hi; p += MSD_NT) add(keys[p]);
         }
         __syncthreads();
-        if (tid < 256) {
-            L.seg[((size_t)sq + b) * 256 + tid] = s_cnt[tid];
-            s_cnt[tid] = 0;
-        }
         if (JOINT) {
             for (u32 w = tid; w < 32768; w += MSD_NT) {
                 const u32 v = s_joint[w];
                 if (v) {
                     atomicAdd(&joint_out[((size_t)sq * 256 + jr.dig[w >> 8]) * 256 + (w & 255u)], v);
+                    atomicAdd(&s_cnt[jr.dig[w >> 8]], v);   // (the row's sum: the digit's count in this segment)
                     s_joint[w] = 0;
                 }
             }
+            __syncthreads();
+        }
+        if (tid < 256) {
+            L.seg[((size_t)sq + b) * 256 + tid] = s_cnt[tid];
+            s_cnt[tid] = 0;
         }
         // (the next round's barrier orders these resets before the next atomics)
     }
