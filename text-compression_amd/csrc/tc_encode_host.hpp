@@ -545,6 +545,11 @@ static void sa_run(tc_ctx *ctx, SaBuffers &b, const u8 *d_text, u64 n, u32 *d_sa
                 mf.whole_list = b.msd_seg[MSD_LEVELS - 1];
                 mf.whole_cap = 1u << 20;
                 mf.out_khi = b.v0;   // (key-only: the value buffers are free; region layout as out_idx)
+                // (equal-mass bins from the level-1 digit counts: tc_msd.hpp; TC_MSD_FINISH_LUT=0: the generic instances bin by key bits)
+                MsdFinishLut *flut = reinterpret_cast<MsdFinishLut *>(b.msd_seg[MSD_LEVELS - 1] + 2 * (size_t)mf.whole_cap);
+                msd_finish_lut_kernel<<<1, 256, 0, s>>>(b.msd_pcnt[1], flut);
+                TC_LAUNCH_CHECK(ctx);
+                mf.lut = env_int("TC_MSD_FINISH_LUT", 1) != 0 ? flut : nullptr;
                 if (msd_big && keyonly) {
                     msd_finish_kernel<MSDF_BIG_NT, MSDF_BIG_ITEMS, 1, 5, true, false><<<np / 256, MSDF_BIG_NT, 0, s>>>(mf);
                     // (no msd_whole_kernel: listed buckets raise bit 1 of the flags, which ends the key-only attempt below)
@@ -553,10 +558,6 @@ static void sa_run(tc_ctx *ctx, SaBuffers &b, const u8 *d_text, u64 n, u32 *d_sa
                     TC_LAUNCH_CHECK(ctx);
                     msd_whole_kernel<<<1024, MSDW_NT, 0, s>>>(mf);
                 } else if (keyonly && env_int("TC_MSD_FINISH_KO", 1) != 0) {
-                    // (equal-mass bins from the level-1 digit counts: tc_msd.hpp, msd_finish_ko_kernel)
-                    MsdFinishLut *flut = reinterpret_cast<MsdFinishLut *>(b.msd_seg[MSD_LEVELS - 1] + 2 * (size_t)mf.whole_cap);
-                    msd_finish_lut_kernel<<<1, 256, 0, s>>>(b.msd_pcnt[1], flut);
-                    TC_LAUNCH_CHECK(ctx);
                     msd_finish_ko_kernel<3><<<np / 256, 256, 0, s>>>(mf, flut);
 #ifdef MSDK_PROFILE
                     {

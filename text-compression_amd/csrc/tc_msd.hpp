@@ -1008,6 +1008,36 @@ __global__ __launch_bounds__(MSD_NT) void msd_partition_kernel(MsdLevel L, const
 }
 
 // ---- finish: every level-3 bucket ordered by its remaining key bits ----------------------------------
+// (the equal-mass bin map of the finish kernels: see msd_finish_ko_kernel below)
+struct MsdFinishLut {
+    u32 a[256];      // cumulative share of the values below, in 1/64 bins (0 .. MSDK_BPC * 64)
+    u32 w[256];      // a[v + 1] - a[v]
+    u32 c[256];      // cumulative share in 1/65536 (<= 65535)
+};
+#define MSDK_BPC 1024
+__global__ __launch_bounds__(256) void msd_finish_lut_kernel(const u32 *__restrict__ cnt, MsdFinishLut *out) {
+    __shared__ u64 s_x[257];
+    __shared__ u64 s_tot;
+    const u32 t = threadIdx.x;
+    s_x[t] = cnt[t];
+    __syncthreads();
+    if (t == 0) {
+        u64 run = 0;
+        for (int i = 0; i < 256; i++) { const u64 c = s_x[i]; s_x[i] = run; run += c; }
+        s_x[256] = run;
+        s_tot = run ? run : 1;
+    }
+    __syncthreads();
+    const u64 tot = s_tot;
+    // (65535, not 65536: a and w share a 32-bit word in the finish kernel, and the bin inside the child stays < MSDK_BPC)
+    const u32 lo = (u32)(s_x[t] * (u64)(MSDK_BPC * 64 - 1) / tot), hi = t == 255 ? (u32)(MSDK_BPC * 64 - 1) : (u32)(s_x[t + 1] * (u64)(MSDK_BPC * 64 - 1) / tot);
+    out->a[t] = lo;
+    out->w[t] = hi - lo;
+    const u64 c16 = s_x[t] * 65536ull / tot;
+    out->c[t] = c16 > 65535 ? 65535u : (u32)c16;
+}
+
+
 struct MsdFinishArgs {
     const u64 *keys;
     const u32 *vals;
@@ -1025,6 +1055,7 @@ struct MsdFinishArgs {
     u32 *whole_list;     // SORTEDKEYS: (start, length) of the over-long buckets
     u32 whole_cap;
     u32 *out_khi;        // VALS = false: key bits 40..63 of every tied member (out_idx then holds bits 8..39)
+    const MsdFinishLut *lut;   // bins = equal-mass intervals of (field 3, field 4) instead of key bits (null: key bits)
 };
 
 // Over-long buckets of the SORTEDKEYS instance (repeats, poly-A: no chunk holds them): msd_finish_kernel only
@@ -1107,7 +1138,27 @@ __global__ __launch_bounds__(MSDF_NT) void msd_finish_kernel(MsdFinishArgs a) {
     const u32 region = blockIdx.x % FIN_REGIONS;
     u32 *rctr = a.rcount + region * FIN_RSTRIDE;
     const u32 rbase = region * a.rcap;
-    auto bin_of = [](u64 key, u32 c0) { return ((u32)(key >> (32 - MSDF_XB)) & ((0x10000u << MSDF_XB) - 1u)) - c0 * BINS_PER_CHILD; };
+    // bins by key BITS use a fraction of a child's bins only (a field is s symbols in base B inside 8 bits: 4-letter DNA has
+    // 64 live values of 256), so a bin holds several keys and the ranking loop below runs as long as the wave's longest
+    // bin; with the table of msd_finish_lut_kernel a bin is an equal-mass interval of (field 3, field 4) -- any monotone
+    // map is correct, the ranking compares all of bits 39..8 -- and holds ~0.5 keys
+    __shared__ u32 s_aw[256];
+    __shared__ u16 s_cq[256];
+    const bool use_lut = a.lut != nullptr;
+    if (use_lut)
+        for (u32 i = tid; i < 256; i += MSDF_NT) {
+            s_aw[i] = a.lut->a[i] | (a.lut->w[i] << 16);
+            s_cq[i] = (u16)a.lut->c[i];
+        }
+    auto bin_of = [&](u64 key, u32 c0) -> u32 {
+        if (use_lut) {
+            const u32 aw = s_aw[(u32)(key >> 32) & 255u];
+            const u32 c = s_cq[(u32)(key >> 24) & 255u];
+            const u32 inner = ((aw & 0xffffu) + ((u32)__umul24(aw >> 16, c) >> 16)) >> (8 - MSDF_XB);   // < BINS_PER_CHILD: a + w <= 65535
+            return (((u32)(key >> 40) & 255u) - c0) * BINS_PER_CHILD + inner;
+        }
+        return ((u32)(key >> (32 - MSDF_XB)) & ((0x10000u << MSDF_XB) - 1u)) - c0 * BINS_PER_CHILD;
+    };
     auto off_at = [&](u32 bin) { return (s_off[bin >> 1] >> (16 * (bin & 1))) & 0xffffu; };
     u32 ch = 0;
     while (true) {
@@ -1283,35 +1334,6 @@ __global__ __launch_bounds__(MSDF_NT) void msd_finish_kernel(MsdFinishArgs a) {
 //  * 32-bit bins and offsets (one ds_read2 gives a bin's start and end), the chunk walk done by every thread from LDS
 //    (no single-thread section), key halves in registers throughout.
 // Same results as the generic instance (final places, last column, the tied set by (slot, key, group)).
-struct MsdFinishLut {
-    u32 a[256];      // cumulative share of the values below, in 1/64 bins (0 .. MSDK_BPC * 64)
-    u32 w[256];      // a[v + 1] - a[v]
-    u32 c[256];      // cumulative share in 1/65536 (<= 65535)
-};
-#define MSDK_BPC 1024
-__global__ __launch_bounds__(256) void msd_finish_lut_kernel(const u32 *__restrict__ cnt, MsdFinishLut *out) {
-    __shared__ u64 s_x[257];
-    __shared__ u64 s_tot;
-    const u32 t = threadIdx.x;
-    s_x[t] = cnt[t];
-    __syncthreads();
-    if (t == 0) {
-        u64 run = 0;
-        for (int i = 0; i < 256; i++) { const u64 c = s_x[i]; s_x[i] = run; run += c; }
-        s_x[256] = run;
-        s_tot = run ? run : 1;
-    }
-    __syncthreads();
-    const u64 tot = s_tot;
-    // (65535, not 65536: a and w share a 32-bit word in the finish kernel, and the bin inside the child stays < MSDK_BPC)
-    const u32 lo = (u32)(s_x[t] * (u64)(MSDK_BPC * 64 - 1) / tot), hi = t == 255 ? (u32)(MSDK_BPC * 64 - 1) : (u32)(s_x[t + 1] * (u64)(MSDK_BPC * 64 - 1) / tot);
-    out->a[t] = lo;
-    out->w[t] = hi - lo;
-    const u64 c16 = s_x[t] * 65536ull / tot;
-    out->c[t] = c16 > 65535 ? 65535u : (u32)c16;
-}
-
-
 template <int CH>
 __global__ __launch_bounds__(256, 6) void msd_finish_ko_kernel(MsdFinishArgs a, const MsdFinishLut *__restrict__ lut) {
     constexpr u32 NT = 256, ITEMS = 8, TILE = NT * ITEMS, MAXBINS = CH * MSDK_BPC;
