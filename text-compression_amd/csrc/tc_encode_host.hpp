@@ -13,6 +13,7 @@
 #include "tc_pack.hpp"
 #include "tc_sa.hpp"
 #include "tc_msd.hpp"
+#include "tc_seg.hpp"
 
 // ---------------------------------------------------------------- small helpers
 static inline void tc_memset_async(tc_ctx *ctx, void *p, int v, size_t bytes) {
@@ -82,6 +83,7 @@ struct SaBuffers {
     u32 *msd_joint;   // [256^3] child counts of the level-3 parents, gathered by the level-2 counting pass
     u32 msd_grid;
     TiedTable tp;     // key-only levels: hash table of the tied keys (tc_sa.hpp)
+    SegBuffers seg;   // segmented sort of the doubling rounds (tc_seg.hpp)
 };
 
 // the MSD round 0 pays from this many suffixes on (level-3 buckets of >= ~64 members on DNA)
@@ -113,6 +115,21 @@ static size_t sa_carve(Arena &A, u64 N, SaBuffers &b, bool own_v1) {
     b.rstatus = A.get<u64>(radix_status_words(N));
     b.gstatus = A.get<u64>(2 * (size_t)tc_cdiv(N, GRP_TILE) + 4);
     b.counts = A.get<u32>(260);
+    {
+        SegBuffers &g = b.seg;
+        g.cap_runs = (size_t)(N / SEG_CAP + 2);
+        g.cap_tiles = (size_t)(N / SEG_PT + 2) + g.cap_runs;
+        g.segbits = A.get<u64>(seg_bit_words(N));
+        g.ybits = A.get<u64>(seg_bit_words(N));
+        for (int q = 0; q < 2; q++) {
+            g.lstart[q] = A.get<u32>(g.cap_runs);
+            g.lsize[q] = A.get<u32>(g.cap_runs);
+            g.ltbase[q] = A.get<u32>(g.cap_runs);
+        }
+        g.tile_seg = A.get<u32>(g.cap_tiles);
+        g.hist = A.get<u32>(g.cap_runs * 256);
+        g.counters = A.get<u32>(64);
+    }
     for (int l = 0; l <= MSD_LEVELS; l++) b.msd_pstart[l] = b.msd_pcnt[l] = nullptr;
     if (msd_wanted(N)) {
         b.msd_grid = 256 * MSD_BPC;   // fixed for the carve; the launch uses min(this, CUs x workgroups per CU)
@@ -132,6 +149,48 @@ static size_t sa_carve(Arena &A, u64 N, SaBuffers &b, bool own_v1) {
         b.tp.bloom = A.get<u32>(((size_t)1 << TP_BLOOM_LOG2) / 32);
     }
     return A.off;
+}
+
+// The sort of one doubling round (tc_seg.hpp): keys (grp << 32 | rank, grp non-decreasing) and values, m members, ranks
+// below 2^rbits.  The result is in (kx, vx); (ky, vy) is scratch of the same size.  One host synchronisation per
+// partition level that has long runs (none: one, for the count of long runs).
+static void seg_sort_pairs(tc_ctx *ctx, SegBuffers &g, u64 *kx, u32 *vx, u64 *ky, u32 *vy, u32 m, int rbits) {
+    hipStream_t s = ctx->stream;
+    const u32 nwords = (u32)seg_bit_words(m);
+    TC_HIP(ctx, hipMemsetAsync(g.ybits, 0, (size_t)nwords * sizeof(u64), s));
+    TC_HIP(ctx, hipMemsetAsync(g.counters, 0, 8 * sizeof(u32), s));
+    u32 igrid = tc_cdiv((u64)nwords * 64, 256);
+    if (igrid > 16384) igrid = 16384;
+    seg_init_kernel<<<igrid, 256, 0, s>>>(kx, m, g.segbits, nwords, g.lstart[0], g.lsize[0], g.ltbase[0], g.counters, (u32)g.cap_runs);
+    TC_LAUNCH_CHECK(ctx);
+    const int nlev = rbits > 8 ? (rbits + 7) / 8 : 1;
+    int cur = 0;
+    for (int L = 0; L < nlev; L++) {
+        TC_HIP(ctx, hipMemcpyAsync(&ctx->h_scalars[24], g.counters + 2 * cur, 2 * sizeof(u32), hipMemcpyDeviceToHost, s));
+        TC_HIP(ctx, hipStreamSynchronize(s));
+        const u32 S = (u32)(ctx->h_scalars[24] & 0xffffffffu), T = (u32)(ctx->h_scalars[24] >> 32);
+        if (S == 0) break;
+        if (S > g.cap_runs || T > g.cap_tiles) TC_FAIL(ctx, TC_ERR_INTERNAL, "segmented sort: %u long runs / %u tiles exceed the tables", S, T);
+        const int shift = rbits - 8 * (L + 1) > 0 ? rbits - 8 * (L + 1) : 0;
+        const int nxt = cur ^ 1;
+        TC_HIP(ctx, hipMemsetAsync(g.hist, 0, (size_t)S * 256 * sizeof(u32), s));
+        TC_HIP(ctx, hipMemsetAsync(g.counters + 2 * nxt, 0, 2 * sizeof(u32), s));
+        u32 wgrid = tc_cdiv(S, 4);
+        if (wgrid > 8192) wgrid = 8192;
+        seg_tilemap_kernel<<<wgrid, 256, 0, s>>>(g.lsize[cur], g.ltbase[cur], S, g.tile_seg, (u32)g.cap_tiles);
+        TC_LAUNCH_CHECK(ctx);
+        seg_count_kernel<<<T, 256, 0, s>>>(kx, ky, g.lstart[cur], g.lsize[cur], g.ltbase[cur], g.tile_seg, g.counters + 2 * cur, shift, g.hist);
+        TC_LAUNCH_CHECK(ctx);
+        seg_scan_kernel<<<wgrid, 256, 0, s>>>(g.lstart[cur], g.lsize[cur], g.counters + 2 * cur, g.hist, g.segbits, L == nlev - 1 ? 1 : 0,
+                                              g.lstart[nxt], g.lsize[nxt], g.ltbase[nxt], g.counters + 2 * nxt, (u32)g.cap_runs);
+        TC_LAUNCH_CHECK(ctx);
+        seg_scatter_kernel<<<T, 256, 0, s>>>(kx, vx, ky, vy, g.lstart[cur], g.lsize[cur], g.ltbase[cur], g.tile_seg, g.counters + 2 * cur, shift,
+                                             g.hist, g.ybits);
+        TC_LAUNCH_CHECK(ctx);
+        cur = nxt;
+    }
+    seg_small_kernel<<<tc_cdiv(m, SEG_SPAN), SEG_NT, 0, s>>>(kx, vx, ky, vy, m, g.segbits, g.ybits);
+    TC_LAUNCH_CHECK(ctx);
 }
 
 static void sa_choose_config(tc_ctx *ctx, const u32 *counts, u64 n, SaConfig &c) {
@@ -870,7 +929,8 @@ static void sa_run(tc_ctx *ctx, SaBuffers &b, const u8 *d_text, u64 n, u32 *d_sa
         for (int p = 0; p < p2.npass; p++) { pd2.shift[p] = p2.shift[p]; pd2.mask[p] = p2.mask[p]; }
         // large rounds: digit histograms on the way; dense: the suffix starts are sorted along
         // (no gather through the active set afterwards)
-        const bool fuse_hist = mm >= (1u << 20);
+        const bool seg_round = env_int("TC_SA_SEG", 1) != 0 && mm >= (u32)env_int("TC_SA_SEG_MIN", 1 << 16);
+        const bool fuse_hist = mm >= (1u << 20) && !seg_round;
         const bool vals_idx = dense;
         if (fuse_hist) tc_memset_async(ctx, b.hist, 0, sizeof(u32) * RDX_MAX_PASSES * RDX_BINS);
         {
@@ -887,8 +947,18 @@ static void sa_run(tc_ctx *ctx, SaBuffers &b, const u8 *d_text, u64 n, u32 *d_sa
         RadixBuffers r2;
         r2.keys = k2; r2.keys_alt = k2alt; r2.vals = kv; r2.vals_alt = kvalt;
         r2.hist = b.hist; r2.status = b.rstatus; r2.status_cap = radix_status_words(N);
-        radix_sort_pairs(ctx, r2, mm, p2, /*gen_idx=*/!vals_idx, /*hist_ready=*/fuse_hist);
-        trace("round: radix passes", mm);
+        if (seg_round) {
+            // the members are in SA order, so every group is a run of equal top key halves: a sort inside the runs
+            // (tc_seg.hpp) instead of eight stable passes over the whole set
+            if (!vals_idx) {
+                seg_iota_kernel<<<tc_cdiv(mm, 256), 256, 0, s>>>(kv, mm);
+                TC_LAUNCH_CHECK(ctx);
+            }
+            seg_sort_pairs(ctx, b.seg, k2, kv, k2alt, kvalt, mm, rbits);
+        } else {
+            radix_sort_pairs(ctx, r2, mm, p2, /*gen_idx=*/!vals_idx, /*hist_ready=*/fuse_hist);
+        }
+        trace(seg_round ? "round: segmented sort" : "round: radix passes", mm);
         GroupArgs gr = {};
         gr.keys = r2.keys; gr.count = mm; gr.vals = r2.vals; gr.vals_are_idx = vals_idx ? 1 : 0;
         gr.in_slot = b.act[cur][0]; gr.in_idx = b.act[cur][1]; gr.in_tpos = b.act[cur][3];
@@ -901,7 +971,7 @@ static void sa_run(tc_ctx *ctx, SaBuffers &b, const u8 *d_text, u64 n, u32 *d_sa
         if (gr_pairs) gr.pairs = r2.keys_alt;
         run_group(false, gr, sa);
         if (gr_pairs) apply_pairs(r2.keys_alt, mm, r2.keys);
-        st.m[st.rounds] = m; st.key_bytes[st.rounds] = 8; st.passes[st.rounds] = (u32)p2.npass;
+        st.m[st.rounds] = m; st.key_bytes[st.rounds] = 8; st.passes[st.rounds] = seg_round ? 1u : (u32)p2.npass;
         st.h[st.rounds] = hh;
         st.rounds++;
         m = fetch_m();
