@@ -39,6 +39,7 @@ def parse():
     ap.add_argument("--n", "--record-bytes", dest="n", type=int, default=GIB, help="record size in bytes (default 1 GiB = BASELINE configs[2])")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-fm", action="store_true", help="skip the FM-index count leg (BASELINE configs[3])")
+    ap.add_argument("--no-classes", action="store_true", help="skip the input-classes leg (non-iid records at 2^28 bytes)")
     ap.add_argument("--cpu-sample", type=int, default=64 << 20, help="bytes of the workload timed on the CPU port")
     return ap.parse_args()
 
@@ -98,7 +99,7 @@ def self_launch(a):
            "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__),
            # (rebuilt from the parsed values: torchrun's own parser chokes on abbreviations such as --n)
            "--gpus", str(a.gpus), "--steps", str(a.steps), "--warmup", str(a.warmup), "--record-bytes", str(a.n),
-           "--cpu-sample", str(a.cpu_sample)] + (["--no-cpu-baseline"] if a.no_cpu_baseline else []) + (["--no-fm"] if a.no_fm else [])
+           "--cpu-sample", str(a.cpu_sample)] + (["--no-cpu-baseline"] if a.no_cpu_baseline else []) + (["--no-fm"] if a.no_fm else []) + (["--no-classes"] if a.no_classes else [])
     p = subprocess.run(cmd, env=env)
     sys.exit(p.returncode)
 
@@ -145,6 +146,50 @@ def container_leg(ctx, lib, torch, d_text, n, steps, ms_plain):
             "stages_ms": {"suffix_sort+bwt": round(st.ms_sa, 3), "mtf": round(st.ms_mtf, 3), "rle+wire_format+seal": round(st.ms_rle, 3)},
             "what": "tc_encode_container_dev: BWT -> MTF -> RLE written as the container's nibble stream by the RLE stage, "
                     "sealed on the device; bit-identical to tc_encode_dev + tc_block_to_container_dev (tests/test_gpu_container_fused.py)"}
+
+
+CLASSES = (("genome_like", 2, 0x6E0E), ("zipf_words", 3, 0x21BF), ("runs_p0.9", 4, 0x9A75), ("repeat_4KiB", 5, 0x4B1B))
+
+
+def classes_leg(ctx, lib, torch, n=1 << 28):
+    """Away from iid ACGTN, after the timed region: four records of 2^28 bytes from the device-side generators
+    (tc_generate_dev kinds 2 .. 5: repeat-rich DNA, Zipf-distributed words, runs, a 4 KiB block repeated), each
+    encoded twice by the same call as the headline (tc_encode_dev; best of the two), decoded, and compared with the
+    text on the device.  `rounds` / `m` are the prefix-doubling rounds and their tied sets (tc_stats)."""
+    from textcomp import Block
+    cap = n + 2
+    d_text = torch.empty(n, dtype=torch.uint8, device="cuda")
+    d_cnt = torch.empty(cap, dtype=torch.int32, device="cuda")
+    d_val = torch.empty(cap, dtype=torch.int16, device="cuda")
+    d_out = torch.empty(n, dtype=torch.uint8, device="cuda")
+    res = {"record_bytes": n}
+    for name, kind, seed in CLASSES:
+        try:
+            rc = lib.tc_generate_dev(ctx.handle, kind, seed, n, C.c_void_p(d_text.data_ptr()))
+            assert rc == 0, "generate rc=%d" % rc
+            torch.cuda.synchronize()
+            enc, dec = [], []
+            for _ in range(2):
+                blk = Block()
+                blk.nruns = cap
+                blk.run_count = d_cnt.data_ptr()
+                blk.run_value = d_val.data_ptr()
+                t0 = time.perf_counter()
+                rc = lib.tc_encode_dev(ctx.handle, C.c_void_p(d_text.data_ptr()), n, C.byref(blk))
+                enc.append(time.perf_counter() - t0)
+                assert rc == 0, "encode rc=%d: %s" % (rc, lib.tc_last_error(ctx.handle).decode())
+                st = ctx.stats()
+                t0 = time.perf_counter()
+                rc = lib.tc_decode_dev(ctx.handle, C.byref(blk), C.c_void_p(d_out.data_ptr()))
+                dec.append(time.perf_counter() - t0)
+                assert rc == 0, "decode rc=%d: %s" % (rc, lib.tc_last_error(ctx.handle).decode())
+            res[name] = {"kind": kind, "seed": seed, "encode_ms": round(min(enc) * 1e3, 2), "encode_MBps": round(n / min(enc) / 1e6, 1),
+                         "decode_ms": round(min(dec) * 1e3, 2), "rounds": int(st.rounds),
+                         "m": [int(st.m[i]) for i in range(min(int(st.rounds), 6))], "sigma": int(blk.sigma), "runs": int(blk.nruns),
+                         "round_trip_exact": bool(torch.equal(d_out, d_text))}
+        except Exception as e:   # noqa: BLE001
+            res[name] = {"error": "%s: %s" % (type(e).__name__, e)}
+    return res
 
 
 def fm_count_leg(ctx, lib, torch, no_cpu):
@@ -463,6 +508,11 @@ def main():
                 out["fm_count"] = fm_count_leg(ctx, lib, torch, a.no_cpu_baseline)
             except Exception as e:   # noqa: BLE001
                 out["fm_count"] = {"error": "%s: %s" % (type(e).__name__, e)}
+        if world == 1 and not a.no_classes and n == GIB:
+            try:
+                out["classes"] = classes_leg(ctx, lib, torch)
+            except Exception as e:   # noqa: BLE001
+                out["classes"] = {"error": "%s: %s" % (type(e).__name__, e)}
         if not a.no_cpu_baseline and world == 1:   # the CPU port is timed at N = 1 only
             try:
                 out["cpu_baseline"] = cpu_baseline(min(a.cpu_sample, n), seed)

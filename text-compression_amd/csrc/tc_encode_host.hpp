@@ -128,6 +128,7 @@ static size_t sa_carve(Arena &A, u64 N, SaBuffers &b, bool own_v1) {
         }
         g.tile_seg = A.get<u32>(g.cap_tiles);
         g.hist = A.get<u32>(g.cap_runs * 256);
+        g.mm = A.get<u32>(g.cap_runs * 2);
         g.counters = A.get<u32>(64);
     }
     for (int l = 0; l <= MSD_LEVELS; l++) b.msd_pstart[l] = b.msd_pcnt[l] = nullptr;
@@ -174,18 +175,20 @@ static void seg_sort_pairs(tc_ctx *ctx, SegBuffers &g, u64 *kx, u32 *vx, u64 *ky
         const int shift = rbits - 8 * (L + 1) > 0 ? rbits - 8 * (L + 1) : 0;
         const int nxt = cur ^ 1;
         TC_HIP(ctx, hipMemsetAsync(g.hist, 0, (size_t)S * 256 * sizeof(u32), s));
+        seg_mm_init_kernel<<<tc_cdiv(S, 256), 256, 0, s>>>(g.mm, S);
+        TC_LAUNCH_CHECK(ctx);
         TC_HIP(ctx, hipMemsetAsync(g.counters + 2 * nxt, 0, 2 * sizeof(u32), s));
         u32 wgrid = tc_cdiv(S, 4);
         if (wgrid > 8192) wgrid = 8192;
         seg_tilemap_kernel<<<wgrid, 256, 0, s>>>(g.lsize[cur], g.ltbase[cur], S, g.tile_seg, (u32)g.cap_tiles);
         TC_LAUNCH_CHECK(ctx);
-        seg_count_kernel<<<T, 256, 0, s>>>(kx, ky, g.lstart[cur], g.lsize[cur], g.ltbase[cur], g.tile_seg, g.counters + 2 * cur, shift, g.hist);
+        seg_count_kernel<<<T, 256, 0, s>>>(kx, ky, g.lstart[cur], g.lsize[cur], g.ltbase[cur], g.tile_seg, g.counters + 2 * cur, shift, g.hist, g.mm);
         TC_LAUNCH_CHECK(ctx);
-        seg_scan_kernel<<<wgrid, 256, 0, s>>>(g.lstart[cur], g.lsize[cur], g.counters + 2 * cur, g.hist, g.segbits, L == nlev - 1 ? 1 : 0,
+        seg_scan_kernel<<<wgrid, 256, 0, s>>>(g.lstart[cur], g.lsize[cur], g.counters + 2 * cur, g.hist, g.mm, g.segbits, L == nlev - 1 ? 1 : 0,
                                               g.lstart[nxt], g.lsize[nxt], g.ltbase[nxt], g.counters + 2 * nxt, (u32)g.cap_runs);
         TC_LAUNCH_CHECK(ctx);
         seg_scatter_kernel<<<T, 256, 0, s>>>(kx, vx, ky, vy, g.lstart[cur], g.lsize[cur], g.ltbase[cur], g.tile_seg, g.counters + 2 * cur, shift,
-                                             g.hist, g.ybits);
+                                             g.hist, g.mm, g.ybits);
         TC_LAUNCH_CHECK(ctx);
         cur = nxt;
     }

@@ -467,12 +467,15 @@ __global__ __launch_bounds__(GRP_NT, 4) void group_kernel(GroupArgs a) {
                 a.sa[slot] = i;
                 a.L[slot] = i ? a.text[i - 1] : (u8)0;
             }
+            // a member of its old group's first subgroup keeps its rank (the rank of a tied member is the slot of its
+            // group's head): nothing to store -- on text with long repeats that is almost every member, every round
+            const bool moved = g != reinterpret_cast<const u32 *>(a.keys)[2 * j + 1];
             u32 tp = 0;
-            if (a.pairs) a.pairs[j] = ((u64)i << 32) | g;
-            else if (a.isa) a.isa[i] = g;
+            if (a.pairs) a.pairs[j] = moved ? ((u64)i << 32) | g : ~0ull;
+            else if (a.isa) { if (moved) a.isa[i] = g; }
             else {
                 tp = a.in_tpos[k0];
-                a.t_rank[tp] = g;
+                if (moved) a.t_rank[tp] = g;
             }
             if (act) {
                 a.out_slot[o] = slot;
@@ -521,10 +524,12 @@ __global__ __launch_bounds__(RBIN_NT) void rank_bin_kernel(const u64 *__restrict
         const u32 p = k * RBIN_NT + tid;
         v[k] = p < valid ? in[base + p] : 0ull;
     }
+    // (a pair of all ones: a member whose rank did not change -- group_kernel<REFINE> -- is dropped here)
 #pragma unroll
     for (int k = 0; k < RBIN_ITEMS; k++) {
         const u32 p = k * RBIN_NT + tid;
-        if (p < valid) r[k] = atomicAdd(&s_cnt[(u32)(v[k] >> 32) >> shift], 1u);
+        if (p >= valid) v[k] = ~0ull;
+        if (v[k] != ~0ull) r[k] = atomicAdd(&s_cnt[(u32)(v[k] >> 32) >> shift], 1u);
     }
     __syncthreads();
     const u32 c = tid < 256 ? s_cnt[tid] : 0u;
@@ -538,13 +543,13 @@ __global__ __launch_bounds__(RBIN_NT) void rank_bin_kernel(const u64 *__restrict
 #pragma unroll
     for (int k = 0; k < RBIN_ITEMS; k++) {
         const u32 p = k * RBIN_NT + tid;
-        if (p < valid) s_stage[s_lb[(u32)(v[k] >> 32) >> shift] + r[k]] = v[k];
+        if (v[k] != ~0ull) s_stage[s_lb[(u32)(v[k] >> 32) >> shift] + r[k]] = v[k];
     }
     __syncthreads();
 #pragma unroll
     for (int k = 0; k < RBIN_ITEMS; k++) {
         const u32 p = k * RBIN_NT + tid;
-        if (p < valid) {
+        if (p < tot) {
             const u64 x = s_stage[p];
             const u32 d = (u32)(x >> 32) >> shift;
             const u64 g = (u64)s_gb[d] + (p - s_lb[d]);

@@ -35,6 +35,7 @@ struct SegBuffers {
     u32 *ltbase[2];    // first tile of the run
     u32 *tile_seg;     // tile -> run
     u32 *hist;         // [runs][256] digit counts, then cursors
+    u32 *mm;           // [runs][2] smallest / largest rank of a run (equal: nothing to sort, the run is left alone)
     u32 *counters;     // [0..1] runs / tiles of level A, [2..3] of level B
     size_t cap_runs, cap_tiles;
 };
@@ -93,8 +94,10 @@ __global__ __launch_bounds__(256) void seg_tilemap_kernel(const u32 *__restrict_
 __global__ __launch_bounds__(256) void seg_count_kernel(const u64 *__restrict__ kx, const u64 *__restrict__ ky,
                                                         const u32 *__restrict__ lstart, const u32 *__restrict__ lsize,
                                                         const u32 *__restrict__ ltbase, const u32 *__restrict__ tile_seg,
-                                                        const u32 *__restrict__ counters, int shift, u32 *__restrict__ hist) {
+                                                        const u32 *__restrict__ counters, int shift, u32 *__restrict__ hist,
+                                                        u32 *__restrict__ mm) {
     __shared__ u32 s_h[256];
+    __shared__ u32 s_mm[2];
     const u32 tile = blockIdx.x;
     if (tile >= counters[1]) return;
     const u32 s = tile_seg[tile];
@@ -105,6 +108,7 @@ __global__ __launch_bounds__(256) void seg_count_kernel(const u64 *__restrict__ 
     const u32 cnt = size - off < SEG_PT ? size - off : SEG_PT;
     const u64 base = (u64)lstart[s] + off;
     s_h[threadIdx.x] = 0;
+    if (threadIdx.x == 0) { s_mm[0] = 0xffffffffu; s_mm[1] = 0u; }
     __syncthreads();
     u64 v[SEG_PT / 256];
 #pragma unroll
@@ -117,21 +121,47 @@ __global__ __launch_bounds__(256) void seg_count_kernel(const u64 *__restrict__ 
         const u32 p = q * 256 + threadIdx.x;
         if (p < cnt) atomicAdd(&s_h[((u32)v[q] >> shift) & 255u], 1u);
     }
+    {
+        u32 lo = 0xffffffffu, hi = 0u;
+#pragma unroll
+        for (int q = 0; q < SEG_PT / 256; q++) {
+            const u32 p = q * 256 + threadIdx.x;
+            if (p < cnt) {
+                lo = lo < (u32)v[q] ? lo : (u32)v[q];
+                hi = hi > (u32)v[q] ? hi : (u32)v[q];
+            }
+        }
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) {
+            const u32 a = (u32)__shfl_xor((int)lo, d, 64), b = (u32)__shfl_xor((int)hi, d, 64);
+            lo = lo < a ? lo : a;
+            hi = hi > b ? hi : b;
+        }
+        if ((threadIdx.x & 63) == 0) {
+            atomicMin(&s_mm[0], lo);
+            atomicMax(&s_mm[1], hi);
+        }
+    }
     __syncthreads();
     const u32 c = s_h[threadIdx.x];
     if (c) atomicAdd(&hist[(size_t)s * 256 + threadIdx.x], c);
+    if (threadIdx.x == 0) {
+        atomicMin(&mm[2 * (size_t)s], s_mm[0]);
+        atomicMax(&mm[2 * (size_t)s + 1], s_mm[1]);
+    }
 }
 
 // per run (one wave): counts -> cursors; the children's heads into segbits; children still longer than the cap onto the
 // next level's list (not after the last level: its children hold equal ranks)
 __global__ __launch_bounds__(256) void seg_scan_kernel(const u32 *__restrict__ lstart, const u32 *__restrict__ lsize,
                                                        const u32 *__restrict__ counters, u32 *__restrict__ hist,
-                                                       u64 *__restrict__ segbits, int last_level,
+                                                       const u32 *__restrict__ mm, u64 *__restrict__ segbits, int last_level,
                                                        u32 *__restrict__ nstart, u32 *__restrict__ nsize,
                                                        u32 *__restrict__ ntbase, u32 *__restrict__ ncounters, u32 cap_runs) {
     const u32 nruns = counters[0] < cap_runs ? counters[0] : cap_runs;
     const u32 nwaves = gridDim.x * 4, l = threadIdx.x & 63;
     for (u32 s = blockIdx.x * 4 + (threadIdx.x >> 6); s < nruns; s += nwaves) {
+        if (mm[2 * (size_t)s] == mm[2 * (size_t)s + 1]) continue;   // equal ranks: the run stays as it is, where it is
         u32 *h = hist + (size_t)s * 256;
         const uint4 c = *reinterpret_cast<const uint4 *>(h + 4 * l);
         const u32 mine = c.x + c.y + c.z + c.w;
@@ -169,7 +199,7 @@ __global__ __launch_bounds__(256) void seg_scatter_kernel(u64 *__restrict__ kx, 
                                                           const u32 *__restrict__ lstart, const u32 *__restrict__ lsize,
                                                           const u32 *__restrict__ ltbase, const u32 *__restrict__ tile_seg,
                                                           const u32 *__restrict__ counters, int shift, u32 *__restrict__ cursor,
-                                                          u64 *__restrict__ ybits) {
+                                                          const u32 *__restrict__ mm, u64 *__restrict__ ybits) {
     __shared__ u64 s_k[SEG_PT];
     __shared__ u32 s_v[SEG_PT];
     __shared__ u32 s_cnt[256], s_lb[256], s_gb[256];
@@ -177,6 +207,7 @@ __global__ __launch_bounds__(256) void seg_scatter_kernel(u64 *__restrict__ kx, 
     const u32 tile = blockIdx.x, tid = threadIdx.x;
     if (tile >= counters[1]) return;
     const u32 s = tile_seg[tile];
+    if (mm[2 * (size_t)s] == mm[2 * (size_t)s + 1]) return;   // (equal ranks: see seg_scan_kernel)
     const u32 sz = lsize[s];
     const bool from_y = (sz >> 31) != 0;
     const u64 *ksrc = from_y ? ky : kx;
@@ -242,45 +273,83 @@ __global__ __launch_bounds__(256) void seg_scatter_kernel(u64 *__restrict__ kx, 
 }
 
 // ---- runs up to SEG_CAP members: sorted in LDS ------------------------------------------------------------
+// Three kinds of runs in a window: TINY (2 .. SEG_TINY members: every member counts the members of its run that
+// precede it -- a few LDS reads), MID (up to SEG_CAP: the mid members of the window are compacted into one array
+// and sorted by a bitonic network over (run head, rank, source slot) -- the head keeps every run in its own slots, so
+// the network needs no knowledge of the run boundaries; its size is the power of two that holds the mid members, so a
+// window pays for what it has), and the rest (singletons, long runs: equal ranks by now, slots of a neighbour's run),
+// which keep their places.
+#define SEG_TINY 15
 #define SEG_PADX(i) ((i) + ((i) >> 4))      // a thread's 16 consecutive keys start 17 * 8 bytes apart
-// compare-exchange steps of a bitonic network on the 16 keys a thread holds in layout LO: key q of thread t is element
-// ((t >> LO) << (LO + 4)) | (q << LO) | (t & ((1 << LO) - 1)); bits [LO, LO + 4) of the element index are the thread's own.
-// Steps for element-index bits bhi .. blo (both inside the layout's four), merge size 2^lk.
-template <int LO>
-__device__ __forceinline__ void seg_steps(u64 (&e)[16], const u32 tid, const int lk, const int bhi, const int blo) {
+// compare-exchange steps of the network on the 16 keys a thread holds in layout LO: key q of thread t is element
+// ((t >> LO) << (LO + 4)) | (q << LO) | (t & ((1 << LO) - 1)).  Steps for the element-index bits BHI .. BLO (inside the
+// layout's four), merge size 2^LK (compile time: the direction of a pair is a constant or one flag per thread).
+template <int LO, int LK, int BHI, int BLO>
+__device__ __forceinline__ void seg_steps(u64 (&e)[16], const u32 tid) {
     const u32 ibase = ((tid >> LO) << (LO + 4)) | (tid & ((1u << LO) - 1u));
+    const bool tdesc = (LK >= LO + 4 || LK < LO) ? ((ibase >> LK) & 1u) != 0u : false;   // (bit LK of the index is a thread bit)
 #pragma unroll
     for (int b = 3; b >= 0; b--) {
-        if (b + LO > bhi || b + LO < blo) continue;
+        if (b + LO > BHI || b + LO < BLO) continue;
         const int jq = 1 << b;
 #pragma unroll
         for (int q = 0; q < 16; q++) {
             if (q & jq) continue;
-            const u32 i = ibase | ((u32)q << LO);
-            const bool asc = lk >= 12 || ((i >> lk) & 1u) == 0u;
+            const bool qdesc = (LK >= LO && LK < LO + 4) ? ((q >> (LK - LO)) & 1) != 0 : false;   // (.. or one of the key's own)
             const u64 a = e[q], c = e[q | jq];
-            const bool sw = (a > c) == asc;
+            const bool sw = (a > c) != (tdesc || qdesc);
             e[q] = sw ? c : a;
             e[q | jq] = sw ? a : c;
         }
     }
 }
+// (Q: the keys of a thread that exist in this layout when the network covers fewer than 4096 elements)
 template <int LO>
-__device__ __forceinline__ void seg_lds_load(const u64 *s_key, u64 (&e)[16], const u32 tid) {
+__device__ __forceinline__ void seg_lds_load(const u64 *s_key, u64 (&e)[16], const u32 tid, const u32 Q = 16) {
     const u32 ibase = ((tid >> LO) << (LO + 4)) | (tid & ((1u << LO) - 1u));
 #pragma unroll
-    for (int q = 0; q < 16; q++) {
-        const u32 i = ibase | ((u32)q << LO);
-        e[q] = s_key[SEG_PADX(i)];
-    }
+    for (int q = 0; q < 16; q++)
+        if ((u32)q < Q) e[q] = s_key[SEG_PADX(ibase | ((u32)q << LO))];
 }
 template <int LO>
-__device__ __forceinline__ void seg_lds_store(u64 *s_key, const u64 (&e)[16], const u32 tid) {
+__device__ __forceinline__ void seg_lds_store(u64 *s_key, const u64 (&e)[16], const u32 tid, const u32 Q = 16) {
     const u32 ibase = ((tid >> LO) << (LO + 4)) | (tid & ((1u << LO) - 1u));
 #pragma unroll
-    for (int q = 0; q < 16; q++) {
-        const u32 i = ibase | ((u32)q << LO);
-        s_key[SEG_PADX(i)] = e[q];
+    for (int q = 0; q < 16; q++)
+        if ((u32)q < Q) s_key[SEG_PADX(ibase | ((u32)q << LO))] = e[q];
+}
+// one merge size of the network over the first 2^lw elements of s_key (lw >= 4, lw >= LK).  Which threads hold keys, and
+// how many, depends on the layout: layout 0: threads below 2^(lw - 4), 16 keys each; layout 4: threads whose upper four
+// bits are below 2^(lw - 8), 16 keys (lw < 8: the first 16 threads, 2^(lw - 4) keys); layout 8: every thread, 2^(lw - 8) keys.
+template <int LK>
+__device__ __forceinline__ void seg_merge(u64 *s_key, u64 (&e)[16], const u32 tid, const int lw) {
+    const bool on0 = tid < (1u << (lw - 4));
+    if constexpr (LK <= 4) {
+        if (on0) seg_steps<0, LK, LK - 1, 0>(e, tid);
+    } else {
+        if (on0) seg_lds_store<0>(s_key, e, tid);
+        __syncthreads();
+        if constexpr (LK > 8) {
+            const u32 Q8 = 1u << (lw - 8);
+            seg_lds_load<8>(s_key, e, tid, Q8);
+            seg_steps<8, LK, LK - 1, 8>(e, tid);
+            __syncthreads();
+            seg_lds_store<8>(s_key, e, tid, Q8);
+            __syncthreads();
+        }
+        const bool on4 = lw >= 8 ? (tid >> 4) < (1u << (lw - 8)) : tid < 16u;
+        const u32 Q4 = lw >= 8 ? 16u : 1u << (lw - 4);
+        if (on4) {
+            seg_lds_load<4>(s_key, e, tid, Q4);
+            seg_steps<4, LK, (LK - 1 < 7 ? LK - 1 : 7), 4>(e, tid);
+        }
+        __syncthreads();
+        if (on4) seg_lds_store<4>(s_key, e, tid, Q4);
+        __syncthreads();
+        if (on0) {
+            seg_lds_load<0>(s_key, e, tid);
+            seg_steps<0, LK, 3, 0>(e, tid);
+        }
     }
 }
 
@@ -292,13 +361,15 @@ __device__ __forceinline__ void seg_lds_store(u64 *s_key, const u64 (&e)[16], co
 __global__ __launch_bounds__(SEG_NT) void seg_small_kernel(u64 *__restrict__ kx, u32 *__restrict__ vx,
                                                            const u64 *__restrict__ ky, const u32 *__restrict__ vy, u32 m,
                                                            const u64 *__restrict__ segbits, const u64 *__restrict__ ybits) {
-    __shared__ u64 s_key[SEG_W + SEG_W / 16];
-    __shared__ u32 s_val[SEG_W];
-    __shared__ u64 s_bits[SEG_EXTW], s_yb[SEG_W / 64];
+    __shared__ u64 s_cmp[SEG_W + SEG_W / 16];    // the network's keys; at the end the staged output keys
+    __shared__ u32 s_rank[SEG_W], s_hi[SEG_W / 64], s_val[SEG_W];
+    __shared__ u16 s_att[SEG_W];                 // [11:0] head of the slot's run (window slot), [15:12] 0 nothing to do, 1 .. 14: tiny run of 2 .. 15, 15: mid
+    __shared__ u64 s_bits[SEG_EXTW], s_yb[SEG_W / 64], s_midw[SEG_W / 64];
     __shared__ i32 s_last[SEG_EXTW + 1], s_first[SEG_EXTW + 1];   // last head before word j / first head in words >= j (ext. slots)
-    __shared__ u32 s_pop[SEG_EXTW + 1];                           // heads of the image's words before word j
+    __shared__ u32 s_wpre[SEG_W / 64 + 1];
     __shared__ u16 s_wm[SEG_NT];
-    __shared__ u32 s_any;
+    __shared__ u32 s_any, s_tmax;
+    (void)s_hi;
     const u32 tid = threadIdx.x;
     const u64 t0 = (u64)blockIdx.x * SEG_SPAN;
     constexpr int LBW = SEG_CAP / 64;          // look-back words
@@ -311,54 +382,63 @@ __global__ __launch_bounds__(SEG_NT) void seg_small_kernel(u64 *__restrict__ kx,
         s_bits[tid] = b;
     }
     if (tid >= 128 && tid < 128 + SEG_W / 64) s_yb[tid - 128] = ybits[(t0 >> 6) + (tid - 128)];
-    if (tid == 0) s_any = 0;
+    if (tid == 0) { s_any = 0; s_tmax = 0; }
     __syncthreads();
     if (tid <= SEG_EXTW) {
         i32 last = -BIG, first = BIG;
-        u32 pop = 0;
+#pragma unroll
         for (int j = 0; j < SEG_EXTW; j++) {
             const u64 b = s_bits[j];
             if (j < (int)tid) {
                 if (b) last = j * 64 + 63 - __builtin_clzll(b);
-                if (j >= LBW) pop += (u32)__popcll(b);
             } else if (b && first == BIG) {
                 first = j * 64 + __builtin_ctzll(b);
             }
         }
         s_last[tid] = last;
         s_first[tid] = first;
-        s_pop[tid] = pop;
     }
     __syncthreads();
     // attributes of this thread's 16 consecutive slots
     const u32 p0 = tid * 16;
-    const int wi = LBW + (int)(tid >> 2), sub = (int)(tid & 3) * 16;
-    const u64 word = s_bits[wi];
-    const u32 yw = (u32)(s_yb[tid >> 2] >> sub) & 0xffffu;
-    u32 mine16 = 0, pass16 = 0, long16 = 0;
-    u32 ordv[16];
+    u32 mine16 = 0, pass16 = 0, mid16 = 0, tmax = 0;
+    {
+        const int wi = LBW + (int)(tid >> 2), sub = (int)(tid & 3) * 16;
+        const u64 word = s_bits[wi];
+        const u32 yw = (u32)(s_yb[tid >> 2] >> sub) & 0xffffu;
 #pragma unroll
-    for (int q = 0; q < 16; q++) {
-        const int b = sub + q;
-        const u64 le = word & ((2ull << b) - 1ull);
-        const u64 gt = b == 63 ? 0ull : word & ~((2ull << b) - 1ull);
-        const i32 hs = le ? wi * 64 + 63 - __builtin_clzll(le) : s_last[wi];
-        const i32 he = gt ? wi * 64 + __builtin_ctzll(gt) : s_first[wi + 1];
-        const bool valid = t0 + p0 + q < m;
-        const bool small = hs >= 0 && he < BIG && he - hs <= SEG_CAP;
-        const bool mine = valid && small && hs >= SEG_CAP && hs < SEG_CAP + SEG_SPAN;
-        const bool pass = valid && !small && p0 + q < SEG_SPAN && ((yw >> q) & 1u);
-        mine16 |= (mine ? 1u : 0u) << q;
-        pass16 |= (pass ? 1u : 0u) << q;
-        long16 |= (valid && !small ? 1u : 0u) << q;
-        ordv[q] = s_pop[wi] + (u32)__popcll(le);
+        for (int q = 0; q < 16; q++) {
+            const int b = sub + q;
+            const u64 le = word & ((2ull << b) - 1ull);
+            const u64 gt = b == 63 ? 0ull : word & ~((2ull << b) - 1ull);
+            const i32 hs = le ? wi * 64 + 63 - __builtin_clzll(le) : s_last[wi];
+            const i32 he = gt ? wi * 64 + __builtin_ctzll(gt) : s_first[wi + 1];
+            const bool valid = t0 + p0 + q < m;
+            const bool small = hs >= 0 && he < BIG && he - hs <= SEG_CAP;
+            const bool mine = valid && small && hs >= SEG_CAP && hs < SEG_CAP + SEG_SPAN;
+            const bool pass = valid && !small && p0 + q < SEG_SPAN && ((yw >> q) & 1u);
+            const u32 size = mine ? (u32)(he - hs) : 0u;
+            const u32 code = size < 2 ? 0u : (size <= SEG_TINY ? size - 1u : 15u);
+            s_att[p0 + q] = (u16)((mine ? (u32)(hs - SEG_CAP) : 0u) | (code << 12));
+            mine16 |= (mine ? 1u : 0u) << q;
+            pass16 |= (pass ? 1u : 0u) << q;
+            mid16 |= (code == 15u ? 1u : 0u) << q;
+            if (code >= 1u && code < 15u && size > tmax) tmax = size;
+        }
     }
+    s_wm[tid] = (u16)(mine16 | pass16);
     if (mine16) s_any = 1;
+    if (tmax) atomicMax(&s_tmax, tmax);
+    // mid members per 64-slot word (four threads a word) and their prefix: the compact index of a mid slot
+    {
+        u64 w4 = (u64)mid16 << ((tid & 3) * 16);
+        w4 |= __shfl_xor(w4, 1, 64);
+        w4 |= __shfl_xor(w4, 2, 64);
+        if ((tid & 3) == 0) s_midw[tid >> 2] = w4;
+    }
     __syncthreads();
     if (!s_any) {
         // nothing to sort: only slots of long runs to bring home
-        s_wm[tid] = (u16)pass16;
-        __syncthreads();
         for (u32 p = tid; p < SEG_SPAN; p += SEG_NT) {
             if ((s_wm[p >> 4] >> (p & 15)) & 1u) {
                 kx[t0 + p] = ky[t0 + p];
@@ -367,7 +447,14 @@ __global__ __launch_bounds__(SEG_NT) void seg_small_kernel(u64 *__restrict__ kx,
         }
         return;
     }
-    // image: keys and values, coalesced, each slot from the buffer that holds it
+    if (tid < 64) {
+        const u32 c = (u32)__popcll(s_midw[tid]);
+        const u32 inc = wave_incl_sum(c);
+        s_wpre[tid] = inc - c;
+        if (tid == 63) s_wpre[64] = inc;
+    }
+    // image: keys and values, coalesced, each slot from the buffer that holds it (the top key halves stay in registers)
+    u32 hi[SEG_ITEMS];
 #pragma unroll
     for (int q = 0; q < SEG_ITEMS; q++) {
         const u32 p = q * SEG_NT + tid;
@@ -379,65 +466,109 @@ __global__ __launch_bounds__(SEG_NT) void seg_small_kernel(u64 *__restrict__ kx,
             key = iny ? ky[k] : kx[k];
             val = iny ? vy[k] : vx[k];
         }
-        s_key[SEG_PADX(p)] = key;
+        hi[q] = (u32)(key >> 32);
+        s_rank[p] = (u32)key;
         s_val[p] = val;
     }
     __syncthreads();
-    u64 e[16];
-    u32 hi[16];
-    seg_lds_load<0>(s_key, e, tid);
+    const u32 nmid = s_wpre[64];
+    int lw = 4;                                   // the network covers 2^lw >= nmid elements
+    while ((1u << lw) < nmid) lw++;
+    // tiny runs: a member's place = head + the members of its run that sort before it; mid members: into the compact array
+    u32 tdest[SEG_ITEMS], trank[SEG_ITEMS], tval[SEG_ITEMS];
 #pragma unroll
-    for (int q = 0; q < 16; q++) {
-        hi[q] = (u32)(e[q] >> 32);
-        const u32 p = p0 + q;
-        const bool valid = t0 + p < m;
-        // (a long run holds equal ranks by now, so its slots keep their places and their keys; a slot of the neighbour
-        // window's run is neither read nor written here: it is pinned by its slot number)
-        const u32 rk = (((mine16 | long16) >> q) & 1u) ? (u32)e[q] : p;
-        e[q] = valid ? ((u64)ordv[q] << 44) | ((u64)rk << 12) | p : ~0ull;
-    }
-    // the network: merge sizes 2 .. 16 inside the thread, then with the three layouts
-    for (int lk = 1; lk <= 4; lk++) seg_steps<0>(e, tid, lk, lk - 1, 0);
-    for (int lk = 5; lk <= 12; lk++) {
-        __syncthreads();
-        seg_lds_store<0>(s_key, e, tid);
-        __syncthreads();
-        if (lk > 8) {
-            seg_lds_load<8>(s_key, e, tid);
-            seg_steps<8>(e, tid, lk, lk - 1, 8);
-            __syncthreads();
-            seg_lds_store<8>(s_key, e, tid);
-            __syncthreads();
+    for (int q = 0; q < SEG_ITEMS; q++) {
+        const u32 p = q * SEG_NT + tid;
+        const u32 att = s_att[p];
+        const u32 code = att >> 12, hsw = att & 4095u;
+        const u32 rk = s_rank[p];
+        tdest[q] = 0xffffffffu;
+        trank[q] = rk;
+        tval[q] = s_val[p];
+        if (code == 15u) {
+            const u32 c = s_wpre[p >> 6] + (u32)__popcll(s_midw[p >> 6] & ((1ull << (p & 63)) - 1ull));
+            s_cmp[SEG_PADX(c)] = ((u64)hsw << 44) | ((u64)rk << 12) | p;
         }
-        seg_lds_load<4>(s_key, e, tid);
-        seg_steps<4>(e, tid, lk, lk - 1 < 7 ? lk - 1 : 7, 4);
-        __syncthreads();
-        seg_lds_store<4>(s_key, e, tid);
-        __syncthreads();
-        seg_lds_load<0>(s_key, e, tid);
-        seg_steps<0>(e, tid, lk, 3, 0);
-    }
-    // slot p0 + q now holds the member e[q] & 4095 came from
-    u32 ov[16];
+        {
+            // (bounded by the longest tiny run among this wave's 64 slots; a wave without tiny members skips the walk)
+            const u32 size = (code >= 1u && code < 15u) ? code + 1u : 0u;
+            u32 wmax = size;
 #pragma unroll
-    for (int q = 0; q < 16; q++) ov[q] = s_val[(u32)e[q] & 4095u];
+            for (int dd = 32; dd >= 1; dd >>= 1) {
+                const u32 o = (u32)__shfl_xor((int)wmax, dd, 64);
+                wmax = wmax > o ? wmax : o;
+            }
+            u32 cnt = 0;
+            for (u32 d = 0; d < wmax; d++) {
+                const u32 j = hsw + d;
+                const u32 r = s_rank[j & (SEG_W - 1)];
+                cnt += (d < size && (r < rk || (r == rk && j < p))) ? 1u : 0u;
+            }
+            if (size) tdest[q] = hsw + cnt;
+        }
+    }
+    if (nmid) {
+        for (u32 c = nmid + tid; c < (1u << lw); c += SEG_NT) s_cmp[SEG_PADX(c)] = ~0ull;
+    }
     __syncthreads();
+    // tiny members to their places (all reads of the image are done)
 #pragma unroll
-    for (int q = 0; q < 16; q++) {
-        const u32 p = p0 + q;
-        s_key[SEG_PADX(p)] = ((u64)hi[q] << 32) | ((e[q] >> 12) & 0xffffffffull);
-        s_val[p] = ov[q];
+    for (int q = 0; q < SEG_ITEMS; q++) {
+        if (tdest[q] != 0xffffffffu) {
+            s_rank[tdest[q]] = trank[q];
+            s_val[tdest[q]] = tval[q];
+        }
     }
-    s_wm[tid] = (u16)(mine16 | pass16);
+    if (nmid) {   // (block-uniform)
+        const bool on = p0 < (1u << lw);
+        u64 e[16];
+        if (on) seg_lds_load<0>(s_cmp, e, tid);
+        seg_merge<1>(s_cmp, e, tid, lw);
+        seg_merge<2>(s_cmp, e, tid, lw);
+        seg_merge<3>(s_cmp, e, tid, lw);
+        seg_merge<4>(s_cmp, e, tid, lw);
+        if (lw >= 5) seg_merge<5>(s_cmp, e, tid, lw);
+        if (lw >= 6) seg_merge<6>(s_cmp, e, tid, lw);
+        if (lw >= 7) seg_merge<7>(s_cmp, e, tid, lw);
+        if (lw >= 8) seg_merge<8>(s_cmp, e, tid, lw);
+        if (lw >= 9) seg_merge<9>(s_cmp, e, tid, lw);
+        if (lw >= 10) seg_merge<10>(s_cmp, e, tid, lw);
+        if (lw >= 11) seg_merge<11>(s_cmp, e, tid, lw);
+        if (lw >= 12) seg_merge<12>(s_cmp, e, tid, lw);
+        // compact slot c = 16 tid + q holds the member that came from window slot e[q] & 4095; its place: the head of its
+        // run + its distance from the head's compact slot
+        u32 mv[16];
+#pragma unroll
+        for (int q = 0; q < 16; q++) mv[q] = (on && p0 + q < nmid) ? s_val[(u32)e[q] & 4095u] : 0u;
+        __syncthreads();
+        if (on) {
+#pragma unroll
+            for (int q = 0; q < 16; q++) {
+                const u32 c = p0 + q;
+                if (c < nmid) {
+                    const u32 hsw = (u32)(e[q] >> 44) & 4095u;
+                    const u32 ch = s_wpre[hsw >> 6] + (u32)__popcll(s_midw[hsw >> 6] & ((1ull << (hsw & 63)) - 1ull));
+                    const u32 dest = hsw + (c - ch);
+                    s_rank[dest] = (u32)(e[q] >> 12);
+                    s_val[dest] = mv[q];
+                }
+            }
+        }
+    }
     __syncthreads();
 #pragma unroll
     for (int q = 0; q < SEG_ITEMS; q++) {
         const u32 p = q * SEG_NT + tid;
         if ((s_wm[p >> 4] >> (p & 15)) & 1u) {
-            kx[t0 + p] = s_key[SEG_PADX(p)];
+            kx[t0 + p] = ((u64)hi[q] << 32) | s_rank[p];
             vx[t0 + p] = s_val[p];
         }
     }
+}
+
+__global__ __launch_bounds__(256) void seg_mm_init_kernel(u32 *__restrict__ mm, u32 nruns) {
+    const u32 s = blockIdx.x * 256 + threadIdx.x;
+    if (s < nruns) { mm[2 * (size_t)s] = 0xffffffffu; mm[2 * (size_t)s + 1] = 0u; }
 }
 
 __global__ __launch_bounds__(256) void seg_iota_kernel(u32 *__restrict__ v, u32 m) {

@@ -249,19 +249,87 @@ static void rle_host(tc_ctx *ctx, const void *src, size_t src_bytes, u64 N, i64 
 }
 
 
+__device__ __forceinline__ u64 gen_mix(u64 seed, u64 i) {   // splitmix64 of (seed, position): SURVEY.md 8(d)
+    u64 z = seed + (i + 1) * 0x9E3779B97F4A7C15ull;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    return z ^ (z >> 31);
+}
+__device__ __forceinline__ u32 gen_scaled(u64 z, u32 m) { return (u32)(((z >> 32) * (u64)m) >> 32); }   // uniform over 0 .. m - 1
+__device__ __forceinline__ u8 gen_acgt(u32 k) { return (u8)(0x54474341u >> (8 * (k & 3u))); }
+
+// Every byte is a function of (kind, seed, position) alone (integer arithmetic; no state carried along the text):
+//   0 iid ACGTN, 1 printable ASCII;  the classes away from iid text the bench reports (round 4):
+//   2 genome-like: iid ACGT; per 3000-byte cell one copy of a 300-bp family at a hashed offset, 15 % of its bases redrawn;
+//     per 20 000-byte cell a poly-A tract of 15 .. 59; per 100 000-byte cell 100 bytes of (CA)n
+//   4 runs: a new run starts at a position with probability 1/10, the run's letter is drawn at its start
+//   5 periodic: a 4096-byte iid ACGT block repeated
+// (3, Zipf words, needs the word boundaries: generate_words_kernel below)
 __global__ __launch_bounds__(256) void generate_kernel(int kind, u64 seed, u64 n, u8 *out) {
     for (u64 i = (u64)blockIdx.x * 256 + threadIdx.x; i < n; i += (u64)gridDim.x * 256) {
-        u64 z = seed + (i + 1) * 0x9E3779B97F4A7C15ull;
-        z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
-        z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
-        z = z ^ (z >> 31);
-        u32 hi = (u32)(z >> 32);
+        const u64 z = gen_mix(seed, i);
+        const u32 hi = (u32)(z >> 32);
+        u8 b;
         if (kind == 0) {
             u32 k = (u32)(((u64)hi * 5) >> 32);
-            out[i] = (u8)(0x4E54474341ull >> (8 * k));  // "ACGTN"
+            b = (u8)(0x4E54474341ull >> (8 * k));  // "ACGTN"
+        } else if (kind == 1) {
+            b = (u8)(0x20 + (u32)(((u64)hi * 95) >> 32));
+        } else if (kind == 2) {
+            b = gen_acgt(gen_scaled(z, 4));
+            const u64 c3 = i / 3000, o3 = i % 3000;
+            const u32 f0 = gen_scaled(gen_mix(seed + 2, c3), 2700);
+            if (o3 >= f0 && o3 < f0 + 300) {
+                const u64 x = gen_mix(seed + 3, i);
+                b = gen_scaled(x, 100) < 15 ? gen_acgt((u32)(x >> 8)) : gen_acgt(gen_scaled(gen_mix(seed + 1, o3 - f0), 4));
+            }
+            const u64 c2 = i / 20000, o2 = i % 20000;
+            const u32 a0 = gen_scaled(gen_mix(seed + 4, c2), 19900), al = 15 + gen_scaled(gen_mix(seed + 5, c2), 45);
+            if (o2 >= a0 && o2 < a0 + al) b = 65;
+            const u64 c1 = i / 100000, o1 = i % 100000;
+            const u32 m0 = gen_scaled(gen_mix(seed + 6, c1), 99800);
+            if (o1 >= m0 && o1 < m0 + 100) b = ((o1 - m0) & 1) ? 65 : 67;
+        } else if (kind == 4) {
+            u64 j = i;
+            for (int back = 0; back < 512 && j > 0 && gen_scaled(gen_mix(seed, j), 10) != 0; back++) j--;
+            b = gen_acgt((u32)(gen_mix(seed + 1, j) >> 40));
         } else {
-            out[i] = (u8)(0x20 + (u32)(((u64)hi * 95) >> 32));
+            b = gen_acgt(gen_scaled(gen_mix(seed, i & 4095), 4));
         }
+        out[i] = b;
+    }
+}
+// kind 3, natural-language-like: words drawn Zipf(1) from a 20 000-word vocabulary (2 .. 9 lower-case letters, a space behind
+// each).  One thread writes one 4096-byte cell, word after word from the cell's own counter stream (the last word of a cell
+// is cut at the cell's end), so a byte is still a function of (seed, position) alone.  cw: cumulative integer weights.
+#define GEN_VOCAB 20000
+__global__ __launch_bounds__(256) void generate_vocab_kernel(u64 seed, u64 *cw_scratch) {
+    // weights 2^40 / (k + 1); the running sum is made by generate_cw_kernel (one thread: 20 000 additions)
+    const u32 k = blockIdx.x * 256 + threadIdx.x;
+    if (k < GEN_VOCAB) cw_scratch[k] = (1ull << 40) / (u64)(k + 1);
+    (void)seed;
+}
+__global__ void generate_cw_kernel(u64 *cw) {
+    u64 run = 0;
+    for (u32 k = 0; k < GEN_VOCAB; k++) { run += cw[k]; cw[k] = run; }
+}
+__global__ __launch_bounds__(64) void generate_words_kernel(u64 seed, u64 n, const u64 *__restrict__ cw, u8 *out) {
+    const u64 cell = (u64)blockIdx.x * 64 + threadIdx.x;
+    const u64 base = cell * 4096;
+    if (base >= n) return;
+    const u64 end = base + 4096 < n ? base + 4096 : n;
+    const u64 total = cw[GEN_VOCAB - 1];
+    u64 p = base;
+    for (u64 w = 0; p < end; w++) {
+        const u64 u = (gen_mix(seed + 3, cell * 4096 + w) >> 20) % total;
+        u32 lo = 0, hi = GEN_VOCAB - 1;   // first k with cw[k] > u
+        while (lo < hi) {
+            const u32 mid = (lo + hi) >> 1;
+            if (cw[mid] > u) hi = mid; else lo = mid + 1;
+        }
+        const u32 len = 2 + (u32)(gen_mix(seed + 1, lo) % 8);
+        for (u32 t = 0; t < len && p < end; t++, p++) out[p] = (u8)(97 + gen_mix(seed + 2, (u64)lo * 16 + t) % 26);
+        if (p < end) out[p++] = 32;
     }
 }
 
@@ -716,14 +784,26 @@ int tc_encode(tc_ctx *ctx, const uint8_t *text, uint64_t n, tc_block *out) {
 // ============================================================ synthetic input
 int tc_generate_dev(tc_ctx *ctx, int kind, uint64_t seed, uint64_t n, uint8_t *d_out) {
     TC_API_BEGIN(ctx)
-    if (kind < 0 || kind > 1) TC_FAIL(ctx, TC_ERR_ARG, "bad kind");
+    if (kind < 0 || kind > 5) TC_FAIL(ctx, TC_ERR_ARG, "bad kind");
     if (n == 0) return TC_OK;
     if (!d_out) TC_FAIL(ctx, TC_ERR_ARG, "null buffer");
-    u32 grid = tc_cdiv(n, 256 * 16);
-    if (grid > 4096) grid = 4096;
-    generate_kernel<<<grid, 256, 0, ctx->stream>>>(kind, seed, n, d_out);
-    TC_LAUNCH_CHECK(ctx);
-    TC_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    if (kind == 3) {
+        u64 *cw = nullptr;
+        TC_HIP(ctx, hipMalloc((void **)&cw, GEN_VOCAB * sizeof(u64)));
+        generate_vocab_kernel<<<tc_cdiv(GEN_VOCAB, 256), 256, 0, ctx->stream>>>(seed, cw);
+        generate_cw_kernel<<<1, 1, 0, ctx->stream>>>(cw);
+        generate_words_kernel<<<tc_cdiv(tc_cdiv(n, 4096), 64), 64, 0, ctx->stream>>>(seed, n, cw, d_out);
+        const hipError_t e = hipGetLastError();
+        (void)hipStreamSynchronize(ctx->stream);
+        (void)hipFree(cw);
+        TC_HIP(ctx, e);
+    } else {
+        u32 grid = tc_cdiv(n, 256 * 16);
+        if (grid > 4096) grid = 4096;
+        generate_kernel<<<grid, 256, 0, ctx->stream>>>(kind, seed, n, d_out);
+        TC_LAUNCH_CHECK(ctx);
+        TC_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    }
     TC_API_END(ctx)
 }
 
