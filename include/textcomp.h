@@ -86,6 +86,12 @@ typedef struct tc_stats {
     uint32_t ticket_fallbacks;       /* suffix sorts of this ctx that had to be redone with the single tile-ticket
                                         counter because a look-back of the XCD-grouped ticket order ran into its
                                         spin limit (LSD passes only; 0 in a healthy run, cumulative per ctx) */
+    /* Layout note: fields are only ever APPENDED from round 4 on (round 3 put msd_keyonly in front of
+     * ticket_fallbacks: callers built against the round-2 header must be rebuilt). */
+    uint32_t ws_chunks;              /* physical chunks the context's workspace is mapped from (0: one hipMalloc block) */
+    uint32_t ws_grown;               /* how often that workspace grew in place (more chunks mapped; cumulative per ctx) */
+    uint32_t seg_rounds;             /* doubling rounds whose sort was the segmented one (tc_seg.hpp), last suffix sort */
+    uint32_t reserved0;
 } tc_stats;
 
 /* The encoded block of the fused BWT -> MTF -> RLE pipeline.  The reference has
@@ -261,6 +267,9 @@ int tc_decode_stream(tc_ctx *ctx, const uint8_t *stream, uint64_t bytes, uint8_t
  * FMIndex/Internal.hs:275-316), Occ (seqToOccCK :195-259, kept as rank
  * bit-vectors instead of the full sigma x N table) and the suffix array. */
 int tc_fm_build(tc_ctx *ctx, const uint8_t *text, uint64_t n, tc_fm **out);
+/* The same index from a text that already lies in HBM (device pointer; read where it is, never copied or modified;
+ * it may be released once the call has returned). */
+int tc_fm_build_dev(tc_ctx *ctx, const uint8_t *d_text, uint64_t n, tc_fm **out);
 void tc_fm_free(tc_fm *fm);
 /* bytestringFMIndexCountS / ...CountP (FMIndex.hs:362-379,411-432) =
  * countFMIndex (FMIndex/Internal.hs:347-438) mapped over the patterns in ONE

@@ -9,6 +9,11 @@ for c in FETCH_SIZE WRITE_SIZE; do
   rm -rf gpurun_out/pmc_$c
   rocprofv3 --pmc $c --kernel-trace --output-format csv -d gpurun_out/pmc_$c -- python bench.py --n $N --steps 1 --warmup 1 --no-cpu-baseline > gpurun_out/pmc_$c.log 2>&1
 done
+# the whole step by the counters: ONE encode call and nothing else in the process (no warm-up, no extra legs)
+for c in FETCH_SIZE WRITE_SIZE; do
+  rm -rf gpurun_out/pmcstep_$c
+  TC_BENCH_CONTAINER=0 rocprofv3 --pmc $c --kernel-trace --output-format csv -d gpurun_out/pmcstep_$c -- python bench.py --n $N --steps 1 --warmup 0 --no-cpu-baseline --no-fm --no-classes > gpurun_out/pmcstep_$c.log 2>&1
+done
 python - <<'PY'
 import csv,glob,collections,json
 N=1073741824
@@ -44,5 +49,19 @@ for k,d in tot.items():
         res["fm_count_kernel_fetch_bytes_per_launch"]=max(d["FETCH_SIZE"]); res["fm_commit"]=res["commit"]
     if "rle_nib_kernel" in k and d["WRITE_SIZE"]:
         res["rle_nib_kernel_bytes_per_launch"]=2*max(d["FETCH_SIZE"]+[0])+max(d["WRITE_SIZE"])
+# one encode step: every dispatch of the one-call run except the generator (and anything of torch's)
+step=collections.defaultdict(float); nd=collections.Counter()
+for c,mul in (("FETCH_SIZE",2.0),("WRITE_SIZE",1.0)):
+    fs=glob.glob("gpurun_out/pmcstep_%s/*/*counter_collection.csv"%c)
+    for r in (csv.DictReader(open(fs[0])) if fs else []):
+        k=r["Kernel_Name"].split("(")[0][:60]
+        if "generate" in k or "at::" in k or "elementwise" in k: continue
+        step[k]+=mul*float(r["Counter_Value"])*1024
+        if c=="WRITE_SIZE": nd[k]+=1
+if step:
+    res["step_traffic_bytes"]=sum(step.values())
+    res["step_traffic_by_kernel"]={k:{"bytes":v,"dispatches":nd[k]} for k,v in sorted(step.items(), key=lambda kv:-kv[1]) if v>=5e7}
+    res["step_note"]="one tc_encode_dev call of the 1 GiB record alone in the process: sum over ALL its dispatches of 2*FETCH_SIZE + WRITE_SIZE"
+    print("whole step: %.2f GB in %d dispatches"%(res["step_traffic_bytes"]/1e9, sum(nd.values())))
 json.dump(res, open("gpurun_out/traffic_latest.json","w"), indent=1)
 PY

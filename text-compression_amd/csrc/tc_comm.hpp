@@ -84,6 +84,7 @@ struct tc_comm {
     void *comm = nullptr;
     int rank = 0, world = 1;
     hipStream_t stream = nullptr;   // the exchange runs beside the encoder's stream
+    hipEvent_t ev_ready = nullptr;  // recorded on the encoder's stream when a gather is posted: the exchange waits for it on the device
     u64 *d_words = nullptr;         // [1 + world] my size, all sizes
     u64 *h_words = nullptr;         // pinned mirror
     bool inflight = false;
@@ -107,6 +108,7 @@ static void comm_release(tc_comm *c) {
     if (c->comm && c->api) (void)c->api->CommDestroy(c->comm);
     if (c->d_words) (void)hipFree(c->d_words);
     if (c->h_words) (void)hipHostFree(c->h_words);
+    if (c->ev_ready) (void)hipEventDestroy(c->ev_ready);
     if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
 }

@@ -31,6 +31,7 @@ struct tc_ctx {
     // (TC_WS_VMM = log2 of the chunk size; 0 = one hipMalloc block): empty unless that way was taken
     std::vector<hipMemGenericAllocationHandle_t> ws_chunks;
     size_t ws_chunk_bytes = 0, ws_mapped = 0;
+    size_t ws_reserved = 0;   // address range reserved for such a workspace (it grows by mapping more chunks: nothing is released)
     u32 *d_err = nullptr;     // device error word (look-back spin overflow etc.)
     u64 *d_scalars = nullptr; // small device scratch for scalar results (64 words)
     u64 *h_scalars = nullptr; // pinned mirror
@@ -40,6 +41,9 @@ struct tc_ctx {
     int profile = 0;
     int num_cus = 0;
     int reserved_cus = 0;  // CUs left to a tc_comm's stream: the partition levels split their work over the others
+    void *hostpipe = nullptr;   // page-locked staging ring + persistent device buffers of the host entry points (textcomp.hip)
+    u32 stats_ws_grown = 0;  // how often a chunked workspace grew in place
+    int live_comms = 0;    // communicators created on this context and not yet destroyed
     int safe_tickets = 0;  // set after a look-back spin overflow: single ticket counter
     u32 ticket_fallbacks = 0;  // how often that happened (reported in tc_stats)
     int pev_used = 0;

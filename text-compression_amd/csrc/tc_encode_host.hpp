@@ -958,6 +958,7 @@ static void sa_run(tc_ctx *ctx, SaBuffers &b, const u8 *d_text, u64 n, u32 *d_sa
                 TC_LAUNCH_CHECK(ctx);
             }
             seg_sort_pairs(ctx, b.seg, k2, kv, k2alt, kvalt, mm, rbits);
+            st.seg_rounds++;
         } else {
             radix_sort_pairs(ctx, r2, mm, p2, /*gen_idx=*/!vals_idx, /*hist_ready=*/fuse_hist);
         }

@@ -340,7 +340,8 @@ static void fm_release(tc_fm *fm) {
     delete fm;
 }
 
-static tc_fm *fm_build_device(tc_ctx *ctx, const u8 *text_host, u64 n) {
+// text_host or text_dev (a text already in HBM is used where it lies: no copy at all)
+static tc_fm *fm_build_device(tc_ctx *ctx, const u8 *text_host, u64 n, const u8 *text_dev = nullptr) {
     tc_fm *fm = new tc_fm();
     fm->device = ctx->device;
     fm->n = n;
@@ -353,8 +354,12 @@ static tc_fm *fm_build_device(tc_ctx *ctx, const u8 *text_host, u64 n) {
         TC_HIP(ctx, hipMalloc((void **)&fm->d_tab, 768 * sizeof(u32)));
         u8 *d_text = nullptr;
         auto plan = [&](Arena &A, bool dry) {
-            d_text = A.get<u8>(n + 16);
-            if (!dry) tc_h2d(ctx, d_text, text_host, n);
+            if (text_dev) {
+                d_text = const_cast<u8 *>(text_dev);
+            } else {
+                d_text = A.get<u8>(n + 16);
+                if (!dry) tc_h2d(ctx, d_text, text_host, n);
+            }
             sa_build(ctx, A, d_text, n, fm->d_sa, fm->d_L, &fm->primary, fm->counts, dry);
         };
         ctx->stats = tc_stats{};

@@ -21,24 +21,31 @@
 // hipMalloc); workspaces under 32 GiB (TC_WS_VMM_MIN_LOG2) are plain hipMalloc blocks.
 struct TcWs {
     char *p = nullptr;
-    size_t cap = 0, mapped = 0;
+    size_t cap = 0, mapped = 0, reserved = 0;
     std::vector<hipMemGenericAllocationHandle_t> chunks;   // (mapped / chunks.size() bytes each)
 };
 static TcWs ws_detach(tc_ctx *ctx) {
     TcWs w;
-    w.p = ctx->ws; w.cap = ctx->ws_cap; w.mapped = ctx->ws_mapped;
+    w.p = ctx->ws; w.cap = ctx->ws_cap; w.mapped = ctx->ws_mapped; w.reserved = ctx->ws_reserved;
     w.chunks.swap(ctx->ws_chunks);
-    ctx->ws = nullptr; ctx->ws_cap = 0; ctx->ws_mapped = 0;
+    ctx->ws = nullptr; ctx->ws_cap = 0; ctx->ws_mapped = 0; ctx->ws_reserved = 0;
     return w;
 }
 static void ws_attach(tc_ctx *ctx, TcWs &w) {
-    ctx->ws = w.p; ctx->ws_cap = w.cap; ctx->ws_mapped = w.mapped;
+    ctx->ws = w.p; ctx->ws_cap = w.cap; ctx->ws_mapped = w.mapped; ctx->ws_reserved = w.reserved;
     ctx->ws_chunks.swap(w.chunks);
     w = TcWs();
 }
 static void ws_free(TcWs &w) {
     if (!w.p) return;
     if (!w.chunks.empty()) {
+        // hipFree waits for the whole device before it gives memory back; hipMemUnmap / hipMemRelease do NOT -- and a
+        // kernel of ANOTHER stream (the exchange's, a caller's) may still be running over these pages.  Round 3 saw a
+        // GPU memory fault after several chunked workspaces had been created and released in one process; since
+        // then (round 4) a chunked workspace is never released while its context lives (it GROWS by mapping more
+        // chunks into its reserved range: ws_grow_vmm), and where one is released -- the context's end -- the device
+        // is idle first.
+        (void)hipDeviceSynchronize();
         // every mapping is undone on its own (hipMemUnmap takes exactly one mapped range), then its memory
         // released; the address range goes last
         const size_t chunk = w.mapped / w.chunks.size();
@@ -46,11 +53,52 @@ static void ws_free(TcWs &w) {
             if (hipMemUnmap(w.p + i * chunk, chunk) != hipSuccess) (void)hipGetLastError();
             if (hipMemRelease(w.chunks[i]) != hipSuccess) (void)hipGetLastError();
         }
-        if (hipMemAddressFree(w.p, w.mapped) != hipSuccess) (void)hipGetLastError();
+        if (hipMemAddressFree(w.p, w.reserved ? w.reserved : w.mapped) != hipSuccess) (void)hipGetLastError();
     } else {
         (void)hipFree(w.p);
     }
     w = TcWs();
+}
+// more chunks of the same size behind the mapped ones, inside the reserved range: the workspace grows where it is, the
+// pages a running kernel may hold stay mapped
+static bool ws_grow_vmm(tc_ctx *ctx, size_t want) {
+    if (ctx->ws_chunks.empty() || want > ctx->ws_reserved) return false;
+    const size_t chunk = ctx->ws_mapped / ctx->ws_chunks.size();
+    const size_t total = (want + chunk - 1) / chunk * chunk;
+    if (total > ctx->ws_reserved) return false;
+    hipMemAllocationProp prop = {};
+    prop.type = hipMemAllocationTypePinned;
+    prop.location.type = hipMemLocationTypeDevice;
+    prop.location.id = ctx->device;
+    const size_t from = ctx->ws_mapped;
+    size_t done = from;
+    const size_t n0 = ctx->ws_chunks.size();
+    bool ok = true;
+    for (; done < total; done += chunk) {
+        hipMemGenericAllocationHandle_t h;
+        if (hipMemCreate(&h, chunk, &prop, 0) != hipSuccess) { ok = false; break; }
+        if (hipMemMap(ctx->ws + done, chunk, 0, h, 0) != hipSuccess) { (void)hipMemRelease(h); ok = false; break; }
+        ctx->ws_chunks.push_back(h);
+    }
+    if (ok && done > from) {
+        hipMemAccessDesc acc = {};
+        acc.location = prop.location;
+        acc.flags = hipMemAccessFlagsProtReadWrite;
+        ok = hipMemSetAccess(ctx->ws + from, done - from, &acc, 1) == hipSuccess;
+    }
+    if (!ok) {   // (the new chunks only: nothing ever ran on them)
+        (void)hipGetLastError();
+        for (size_t i = n0; i < ctx->ws_chunks.size(); i++) {
+            (void)hipMemUnmap(ctx->ws + i * chunk, chunk);
+            (void)hipMemRelease(ctx->ws_chunks[i]);
+        }
+        ctx->ws_chunks.resize(n0);
+        (void)hipGetLastError();
+        return false;
+    }
+    ctx->ws_mapped = total;
+    ctx->ws_cap = total;
+    return true;
 }
 static bool ws_alloc_vmm(tc_ctx *ctx, size_t want, int chunk_log2, TcWs &w) {
     hipMemAllocationProp prop = {};
@@ -65,10 +113,19 @@ static bool ws_alloc_vmm(tc_ctx *ctx, size_t want, int chunk_log2, TcWs &w) {
     size_t chunk = (size_t)1 << chunk_log2;
     chunk = (chunk + gran - 1) / gran * gran;
     const size_t total = (want + chunk - 1) / chunk * chunk;
+    // the address range: room for the workspace of the longest record (TC_WS_VMM_RESERVE_LOG2, default 2^38 bytes =
+    // 256 GiB of addresses, not of memory), so that a context that meets a longer record later grows in place
+    size_t reserve = (size_t)1 << env_int("TC_WS_VMM_RESERVE_LOG2", 38);
+    reserve = reserve / chunk * chunk;
+    if (reserve < total) reserve = total;
     void *va = nullptr;
-    if (hipMemAddressReserve(&va, total, chunk, nullptr, 0) != hipSuccess) {
+    if (hipMemAddressReserve(&va, reserve, chunk, nullptr, 0) != hipSuccess) {
         (void)hipGetLastError();
-        return false;
+        reserve = total;
+        if (hipMemAddressReserve(&va, reserve, chunk, nullptr, 0) != hipSuccess) {
+            (void)hipGetLastError();
+            return false;
+        }
     }
     size_t done = 0;
     bool ok = true;
@@ -91,11 +148,11 @@ static bool ws_alloc_vmm(tc_ctx *ctx, size_t want, int chunk_log2, TcWs &w) {
             (void)hipMemRelease(w.chunks[i]);
         }
         w.chunks.clear();
-        (void)hipMemAddressFree(va, total);
+        (void)hipMemAddressFree(va, reserve);
         (void)hipGetLastError();
         return false;
     }
-    w.p = (char *)va; w.cap = total; w.mapped = total;
+    w.p = (char *)va; w.cap = total; w.mapped = total; w.reserved = reserve;
     return true;
 }
 // a workspace of `want` bytes (exactly `want` when exact: a second placement of an existing size)
@@ -120,6 +177,11 @@ static void tc_ws_release(tc_ctx *ctx) {
 
 void tc_ws_reserve(tc_ctx *ctx, size_t bytes) {
     if (bytes <= ctx->ws_cap) return;
+    // a chunked workspace grows where it is (more chunks behind the mapped ones): no release, no new placement
+    if (ctx->ws && !ctx->ws_chunks.empty() && ws_grow_vmm(ctx, bytes + (bytes >> 4) + (1u << 20))) {
+        ctx->stats_ws_grown++;
+        return;
+    }
     if (ctx->ws) {
         TC_HIP(ctx, hipStreamSynchronize(ctx->stream));
         tc_ws_release(ctx);
@@ -522,6 +584,7 @@ int tc_ctx_create(int device, tc_ctx **out) {
     return TC_OK;
 }
 
+static void hp_release(tc_ctx *ctx);
 void tc_ctx_destroy(tc_ctx *ctx) {
     if (!ctx) return;
     (void)hipSetDevice(ctx->device);
@@ -530,6 +593,7 @@ void tc_ctx_destroy(tc_ctx *ctx) {
         if (ctx->ev[i]) (void)hipEventDestroy(ctx->ev[i]);
     for (int i = 0; i < 32; i++)
         if (ctx->pev[i]) (void)hipEventDestroy(ctx->pev[i]);
+    hp_release(ctx);
     tc_ws_release(ctx);
     if (ctx->d_err) (void)hipFree(ctx->d_err);
     if (ctx->d_scalars) (void)hipFree(ctx->d_scalars);
@@ -544,6 +608,8 @@ const char *tc_last_error(const tc_ctx *ctx) { return ctx ? ctx->err.c_str() : "
 int tc_get_stats(const tc_ctx *ctx, tc_stats *out) {
     if (!ctx || !out) return TC_ERR_ARG;
     *out = ctx->stats;
+    out->ws_chunks = (uint32_t)ctx->ws_chunks.size();
+    out->ws_grown = ctx->stats_ws_grown;
     return TC_OK;
 }
 
@@ -743,6 +809,148 @@ int tc_encode_dev(tc_ctx *ctx, const uint8_t *d_text, uint64_t n, tc_block *out)
     TC_API_END(ctx)
 }
 
+
+u64 container_bound_any(u64 n);
+// ================================================== host buffers in and out (the path every Haskell caller takes)
+// bytestringToBWT and friends hand over a host ByteString (reference BWT.hs:68-70, RLE.hs:83-85).  Until round 3 the
+// host entry points paid a hipMalloc / hipFree per buffer per call and one blocking copy of a pageable buffer each
+// way (0.95 GB/s for the 1 GiB record).  Now a context keeps (i) its device-side text / output buffers between calls
+// (grown, never shrunk) and (ii) a ring of page-locked staging buffers with HP_WORKERS helper threads: a pageable
+// buffer crosses in HP_CHUNK pieces -- each worker copies its piece into its staging buffer and posts the DMA on its own
+// stream, so the host's memcpy of one piece runs beside the DMA of the others (both directions).  A buffer the caller
+// has page-locked itself (hipHostMalloc / hipHostRegister) is recognised and goes by one asynchronous copy.
+#define HP_WORKERS 4
+#define HP_CHUNK ((size_t)16 << 20)
+struct HostPipe {
+    u8 *pin[HP_WORKERS][2] = {};
+    hipStream_t st[HP_WORKERS] = {};
+    hipEvent_t ev[HP_WORKERS][2] = {};
+    u8 *d_buf[4] = {};        // persistent device buffers: 0 text / container in, 1 container / text out, 2 run counts, 3 run values
+    size_t d_cap[4] = {};
+};
+static HostPipe *hp_get(tc_ctx *ctx) {
+    if (ctx->hostpipe) return static_cast<HostPipe *>(ctx->hostpipe);
+    HostPipe *hp = new HostPipe();
+    ctx->hostpipe = hp;
+    for (int w = 0; w < HP_WORKERS; w++) {
+        TC_HIP(ctx, hipStreamCreateWithFlags(&hp->st[w], hipStreamNonBlocking));
+        for (int q = 0; q < 2; q++) {
+            TC_HIP(ctx, hipHostMalloc((void **)&hp->pin[w][q], HP_CHUNK, hipHostMallocDefault));
+            TC_HIP(ctx, hipEventCreateWithFlags(&hp->ev[w][q], hipEventDisableTiming));
+        }
+    }
+    return hp;
+}
+static void hp_release(tc_ctx *ctx) {
+    HostPipe *hp = static_cast<HostPipe *>(ctx->hostpipe);
+    if (!hp) return;
+    for (int w = 0; w < HP_WORKERS; w++) {
+        if (hp->st[w]) (void)hipStreamSynchronize(hp->st[w]);
+        for (int q = 0; q < 2; q++) {
+            if (hp->pin[w][q]) (void)hipHostFree(hp->pin[w][q]);
+            if (hp->ev[w][q]) (void)hipEventDestroy(hp->ev[w][q]);
+        }
+        if (hp->st[w]) (void)hipStreamDestroy(hp->st[w]);
+    }
+    for (int i = 0; i < 4; i++)
+        if (hp->d_buf[i]) (void)hipFree(hp->d_buf[i]);
+    delete hp;
+    ctx->hostpipe = nullptr;
+}
+// persistent device buffer `which` of at least `bytes` (kept across calls; a longer request replaces it)
+static u8 *hp_dev(tc_ctx *ctx, int which, size_t bytes) {
+    HostPipe *hp = hp_get(ctx);
+    if (hp->d_cap[which] >= bytes && hp->d_buf[which]) return hp->d_buf[which];
+    if (hp->d_buf[which]) {
+        TC_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        (void)hipFree(hp->d_buf[which]);
+        hp->d_buf[which] = nullptr; hp->d_cap[which] = 0;
+    }
+    const size_t want = (bytes + (bytes >> 5) + ((size_t)2 << 20)) & ~(((size_t)2 << 20) - 1);
+    if (hipMalloc((void **)&hp->d_buf[which], want) != hipSuccess) {
+        (void)hipGetLastError();
+        TC_HIP(ctx, hipMalloc((void **)&hp->d_buf[which], bytes + 256));
+        hp->d_cap[which] = bytes + 256;
+    } else {
+        hp->d_cap[which] = want;
+    }
+    return hp->d_buf[which];
+}
+static bool hp_page_locked(const void *p) {
+    hipPointerAttribute_t a;
+    if (hipPointerGetAttributes(&a, p) != hipSuccess) {
+        (void)hipGetLastError();
+        return false;
+    }
+    return a.type == hipMemoryTypeHost;
+}
+// host -> device (to_dev) or device -> host, `bytes` bytes; returns when the data has arrived.  The device side must be
+// complete on the context's stream before a device -> host copy is asked for (the callers have synchronised).
+static void hp_copy(tc_ctx *ctx, void *dst, const void *src, size_t bytes, bool to_dev) {
+    if (!bytes) return;
+    const void *host = to_dev ? src : dst;
+    if (bytes < (1u << 20) || hp_page_locked(host) || env_int("TC_HOST_STAGED", 1) == 0) {
+        TC_HIP(ctx, hipMemcpyAsync(dst, src, bytes, to_dev ? hipMemcpyHostToDevice : hipMemcpyDeviceToHost, ctx->stream));
+        TC_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        return;
+    }
+    HostPipe *hp = hp_get(ctx);
+    const size_t nch = (bytes + HP_CHUNK - 1) / HP_CHUNK;
+    hipError_t errs[HP_WORKERS];
+    std::thread th[HP_WORKERS];
+    const int device = ctx->device;
+    for (int w = 0; w < HP_WORKERS; w++) {
+        errs[w] = hipSuccess;
+        th[w] = std::thread([=, &errs] {
+            hipError_t e = hipSetDevice(device);
+            auto len_of = [&](size_t c) { return c * HP_CHUNK + HP_CHUNK <= bytes ? HP_CHUNK : bytes - c * HP_CHUNK; };
+            if (to_dev) {
+                int q = 0;
+                bool used[2] = {false, false};
+                for (size_t c = (size_t)w; c < nch && e == hipSuccess; c += HP_WORKERS, q ^= 1) {
+                    if (used[q]) e = hipEventSynchronize(hp->ev[w][q]);      // the DMA that last read this staging buffer
+                    if (e != hipSuccess) break;
+                    memcpy(hp->pin[w][q], (const u8 *)src + c * HP_CHUNK, len_of(c));
+                    e = hipMemcpyAsync((u8 *)dst + c * HP_CHUNK, hp->pin[w][q], len_of(c), hipMemcpyHostToDevice, hp->st[w]);
+                    if (e == hipSuccess) e = hipEventRecord(hp->ev[w][q], hp->st[w]);
+                    used[q] = true;
+                }
+                if (e == hipSuccess) e = hipStreamSynchronize(hp->st[w]);
+            } else {
+                // the DMA of piece c + WORKERS runs while piece c is copied out of its staging buffer
+                int q = 0;
+                size_t c = (size_t)w;
+                if (c < nch) {
+                    e = hipMemcpyAsync(hp->pin[w][q], (const u8 *)src + c * HP_CHUNK, len_of(c), hipMemcpyDeviceToHost, hp->st[w]);
+                    if (e == hipSuccess) e = hipEventRecord(hp->ev[w][q], hp->st[w]);
+                }
+                for (; c < nch && e == hipSuccess; c += HP_WORKERS, q ^= 1) {
+                    const size_t nx = c + HP_WORKERS;
+                    if (nx < nch) {
+                        e = hipMemcpyAsync(hp->pin[w][q ^ 1], (const u8 *)src + nx * HP_CHUNK, len_of(nx), hipMemcpyDeviceToHost, hp->st[w]);
+                        if (e == hipSuccess) e = hipEventRecord(hp->ev[w][q ^ 1], hp->st[w]);
+                        if (e != hipSuccess) break;
+                    }
+                    e = hipEventSynchronize(hp->ev[w][q]);
+                    if (e != hipSuccess) break;
+                    memcpy((u8 *)dst + c * HP_CHUNK, hp->pin[w][q], len_of(c));
+                }
+                if (e == hipSuccess) e = hipStreamSynchronize(hp->st[w]);
+            }
+            errs[w] = e;
+        });
+    }
+    hipError_t bad = hipSuccess;
+    for (int w = 0; w < HP_WORKERS; w++) {
+        th[w].join();
+        if (errs[w] != hipSuccess) bad = errs[w];
+    }
+    if (bad != hipSuccess) {
+        (void)hipGetLastError();
+        TC_HIP(ctx, bad);
+    }
+}
+
 int tc_encode(tc_ctx *ctx, const uint8_t *text, uint64_t n, tc_block *out) {
     TC_API_BEGIN(ctx)
     if (!out || n > TC_MAX_N) TC_FAIL(ctx, TC_ERR_ARG, "bad argument");
@@ -752,32 +960,19 @@ int tc_encode(tc_ctx *ctx, const uint8_t *text, uint64_t n, tc_block *out) {
     out->n = n; out->primary = 0; out->sigma = 0; out->nruns = 0;
     if (n == 0) return TC_OK;
     if (!text || !h_count || !h_value) TC_FAIL(ctx, TC_ERR_ARG, "null buffer");
-    // device staging buffers live outside the workspace (the pipeline re-carves it)
-    u8 *d_text = nullptr;
-    u32 *d_count = nullptr;
-    u16 *d_value = nullptr;
-    int rc = TC_OK;
-    try {
-        TC_HIP(ctx, hipMalloc((void **)&d_text, n + 16));
-        TC_HIP(ctx, hipMalloc((void **)&d_count, (cap + 1) * sizeof(u32)));
-        TC_HIP(ctx, hipMalloc((void **)&d_value, (cap + 1) * sizeof(u16)));
-        tc_h2d(ctx, d_text, text, n);
-        tc_block dev = *out;
-        dev.nruns = cap; dev.run_count = d_count; dev.run_value = d_value;
-        encode_device(ctx, d_text, n, &dev, cap);
-        *out = dev;
-        out->run_count = h_count; out->run_value = h_value;
-        tc_d2h(ctx, h_count, d_count, dev.nruns * sizeof(u32));
-        tc_d2h(ctx, h_value, d_value, dev.nruns * sizeof(u16));
-        TC_HIP(ctx, hipStreamSynchronize(ctx->stream));
-    } catch (const TcFail &f) {
-        rc = f.code;
-    }
-    (void)hipStreamSynchronize(ctx->stream);
-    if (d_text) (void)hipFree(d_text);
-    if (d_count) (void)hipFree(d_count);
-    if (d_value) (void)hipFree(d_value);
-    if (rc != TC_OK) throw TcFail{rc};
+    // the device-side buffers live outside the workspace (the pipeline re-carves it) and stay with the context
+    u8 *d_text = hp_dev(ctx, 0, n + 16);
+    u32 *d_count = reinterpret_cast<u32 *>(hp_dev(ctx, 2, (cap + 1) * sizeof(u32)));
+    u16 *d_value = reinterpret_cast<u16 *>(hp_dev(ctx, 3, (cap + 1) * sizeof(u16)));
+    hp_copy(ctx, d_text, text, n, true);
+    tc_block dev = *out;
+    dev.nruns = cap; dev.run_count = d_count; dev.run_value = d_value;
+    encode_device(ctx, d_text, n, &dev, cap);
+    *out = dev;
+    out->run_count = h_count; out->run_value = h_value;
+    TC_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    hp_copy(ctx, h_count, d_count, dev.nruns * sizeof(u32), false);
+    hp_copy(ctx, h_value, d_value, dev.nruns * sizeof(u16), false);
     TC_API_END(ctx)
 }
 
@@ -1508,49 +1703,25 @@ int tc_encode_container(tc_ctx *ctx, const uint8_t *text, uint64_t n, uint8_t *o
     TC_API_BEGIN(ctx)
     if (!bytes || n > TC_MAX_N || (n && !text) || !out) TC_FAIL(ctx, TC_ERR_ARG, "bad argument");
     const u64 cap = *bytes;
-    u8 *d_text = nullptr, *d_out = nullptr;
-    u32 *d_count = nullptr;
-    u16 *d_value = nullptr;
-    int rc = TC_OK;
+    // text in (staged through the context's page-locked ring unless the caller's buffer is page-locked), the record
+    // straight into its container on the device (the call tc_encode_container_dev makes: the RLE stage writes the wire
+    // format), the container out.  The device-side container is sized by what the caller can take, not by the worst case.
+    u8 *d_text = hp_dev(ctx, 0, n + 16);
+    const u64 need_max = container_bound_any(n);
+    u64 dbytes = cap < need_max ? cap : need_max;
+    if (dbytes < TC_CONTAINER_HEADER) dbytes = TC_CONTAINER_HEADER;
+    u8 *d_out = hp_dev(ctx, 1, dbytes + 16);
+    hp_copy(ctx, d_text, text, n, true);
+    u64 used = cap < TC_CONTAINER_HEADER ? 0 : dbytes;   // (0 forces the capacity report)
     try {
-        const u64 runs_cap = n + 2;
-        TC_HIP(ctx, hipMalloc((void **)&d_text, n + 16));
-        TC_HIP(ctx, hipMalloc((void **)&d_count, (runs_cap + 1) * sizeof(u32)));
-        TC_HIP(ctx, hipMalloc((void **)&d_value, (runs_cap + 1) * sizeof(u16)));
-        tc_block dev;
-        memset(&dev, 0, sizeof dev);
-        dev.nruns = runs_cap; dev.run_count = d_count; dev.run_value = d_value;
-        if (n) {
-            tc_h2d(ctx, d_text, text, n);
-            encode_device(ctx, d_text, n, &dev, runs_cap);
-        } else {
-            dev.nruns = 0;
-        }
-        // the device-side container is sized by what the caller can take, not by the worst case
-        const u64 need_max = tc_container_bound(dev.nruns, dev.sigma);
-        u64 dbytes = cap < need_max ? cap : need_max;
-        if (dbytes < TC_CONTAINER_HEADER) dbytes = TC_CONTAINER_HEADER;
-        TC_HIP(ctx, hipMalloc((void **)&d_out, dbytes + 16));
-        u64 used = dbytes;
-        if (cap < TC_CONTAINER_HEADER) used = 0;   // forces the capacity report
-        try {
-            container_write_device(ctx, &dev, d_out, &used);
-        } catch (const TcFail &f) {
-            *bytes = used;
-            throw;
-        }
+        encode_container_device(ctx, d_text, n, d_out, &used);
+    } catch (const TcFail &) {
         *bytes = used;
-        tc_d2h(ctx, out, d_out, used);
-        TC_HIP(ctx, hipStreamSynchronize(ctx->stream));
-    } catch (const TcFail &f) {
-        rc = f.code;
+        throw;
     }
-    (void)hipStreamSynchronize(ctx->stream);
-    if (d_text) (void)hipFree(d_text);
-    if (d_count) (void)hipFree(d_count);
-    if (d_value) (void)hipFree(d_value);
-    if (d_out) (void)hipFree(d_out);
-    if (rc != TC_OK) throw TcFail{rc};
+    *bytes = used;
+    TC_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    hp_copy(ctx, out, d_out, used, false);
     TC_API_END(ctx)
 }
 
@@ -1559,41 +1730,27 @@ int tc_decode_container(tc_ctx *ctx, const uint8_t *container, uint64_t bytes, u
     TC_API_BEGIN(ctx)
     if (!container || !n_out) TC_FAIL(ctx, TC_ERR_ARG, "bad argument");
     if (bytes < TC_CONTAINER_HEADER) TC_FAIL(ctx, TC_ERR_MALFORMED, "container shorter than its header");
-    u8 *d_in = nullptr, *d_text = nullptr;
-    u32 *d_count = nullptr;
-    u16 *d_value = nullptr;
-    int rc = TC_OK;
-    try {
-        ContainerHeader h0;
-        memcpy(&h0, container, sizeof h0);
-        if (memcmp(h0.magic, kContainerMagic, 8) != 0) TC_FAIL(ctx, TC_ERR_MALFORMED, "not a textcomp container");
-        if (h0.n > TC_MAX_N || h0.nruns > (u64)TC_MAX_N + 2) TC_FAIL(ctx, TC_ERR_MALFORMED, "container header is inconsistent");
-        if (h0.n && !text) TC_FAIL(ctx, TC_ERR_ARG, "null buffer");
-        TC_HIP(ctx, hipMalloc((void **)&d_in, bytes + 16));
-        TC_HIP(ctx, hipMalloc((void **)&d_text, h0.n + 16));
-        TC_HIP(ctx, hipMalloc((void **)&d_count, (h0.nruns + 1) * sizeof(u32)));
-        TC_HIP(ctx, hipMalloc((void **)&d_value, (h0.nruns + 1) * sizeof(u16)));
-        tc_h2d(ctx, d_in, container, bytes);
-        tc_block dev;
-        memset(&dev, 0, sizeof dev);
-        dev.nruns = h0.nruns; dev.run_count = d_count; dev.run_value = d_value;
-        container_read_device(ctx, d_in, bytes, &dev);
-        *n_out = dev.n;
-        if (dev.n) {
-            if (dev.nruns == 0) TC_FAIL(ctx, TC_ERR_MALFORMED, "container holds no runs");
-            decode_device(ctx, &dev, d_text);
-            tc_d2h(ctx, text, d_text, dev.n);
-            TC_HIP(ctx, hipStreamSynchronize(ctx->stream));
-        }
-    } catch (const TcFail &f) {
-        rc = f.code;
+    ContainerHeader h0;
+    memcpy(&h0, container, sizeof h0);
+    if (memcmp(h0.magic, kContainerMagic, 8) != 0) TC_FAIL(ctx, TC_ERR_MALFORMED, "not a textcomp container");
+    if (h0.n > TC_MAX_N || h0.nruns > (u64)TC_MAX_N + 2) TC_FAIL(ctx, TC_ERR_MALFORMED, "container header is inconsistent");
+    if (h0.n && !text) TC_FAIL(ctx, TC_ERR_ARG, "null buffer");
+    u8 *d_in = hp_dev(ctx, 0, bytes + 16);
+    u8 *d_text = hp_dev(ctx, 1, h0.n + 16);
+    u32 *d_count = reinterpret_cast<u32 *>(hp_dev(ctx, 2, (h0.nruns + 1) * sizeof(u32)));
+    u16 *d_value = reinterpret_cast<u16 *>(hp_dev(ctx, 3, (h0.nruns + 1) * sizeof(u16)));
+    hp_copy(ctx, d_in, container, bytes, true);
+    tc_block dev;
+    memset(&dev, 0, sizeof dev);
+    dev.nruns = h0.nruns; dev.run_count = d_count; dev.run_value = d_value;
+    container_read_device(ctx, d_in, bytes, &dev);
+    *n_out = dev.n;
+    if (dev.n) {
+        if (dev.nruns == 0) TC_FAIL(ctx, TC_ERR_MALFORMED, "container holds no runs");
+        decode_device(ctx, &dev, d_text);
+        TC_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        hp_copy(ctx, text, d_text, dev.n, false);
     }
-    (void)hipStreamSynchronize(ctx->stream);
-    if (d_in) (void)hipFree(d_in);
-    if (d_text) (void)hipFree(d_text);
-    if (d_count) (void)hipFree(d_count);
-    if (d_value) (void)hipFree(d_value);
-    if (rc != TC_OK) throw TcFail{rc};
     TC_API_END(ctx)
 }
 
@@ -1623,7 +1780,7 @@ struct CopyJob {
 };
 
 static u64 stream_blocks(u64 n, u64 block) { return n ? (n + block - 1) / block : 1; }
-static u64 container_bound_any(u64 n) {
+u64 container_bound_any(u64 n) {
     u64 b = 0;
     for (u32 sg : {6u, 16u, 257u}) {
         const u64 v = tc_container_bound(n + 2, sg);
@@ -1839,6 +1996,21 @@ int tc_fm_build(tc_ctx *ctx, const uint8_t *text, uint64_t n, tc_fm **out) {
     }
     if (!text) TC_FAIL(ctx, TC_ERR_ARG, "null buffer");
     *out = fm_build_device(ctx, text, n);
+    TC_API_END(ctx)
+}
+
+int tc_fm_build_dev(tc_ctx *ctx, const uint8_t *d_text, uint64_t n, tc_fm **out) {
+    TC_API_BEGIN(ctx)
+    if (!out || n > TC_MAX_N) TC_FAIL(ctx, TC_ERR_ARG, "bad argument");
+    *out = nullptr;
+    if (n == 0) {
+        tc_fm *fm = new tc_fm();
+        fm->device = ctx->device;
+        *out = fm;
+        return TC_OK;
+    }
+    if (!d_text) TC_FAIL(ctx, TC_ERR_ARG, "null buffer");
+    *out = fm_build_device(ctx, nullptr, n, d_text);
     TC_API_END(ctx)
 }
 
@@ -2150,7 +2322,7 @@ int tc_comm_create(tc_ctx *ctx, const uint8_t *id, int rank, int world, tc_comm 
         }
         if (!c->stream) TC_HIP(ctx, hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
         c->cus = cus;
-        ctx->reserved_cus = cus;
+        TC_HIP(ctx, hipEventCreateWithFlags(&c->ev_ready, hipEventDisableTiming));
         TC_HIP(ctx, hipMalloc((void **)&c->d_words, (size_t)(1 + world) * sizeof(u64)));
         TC_HIP(ctx, hipHostMalloc((void **)&c->h_words, (size_t)(1 + world) * sizeof(u64), hipHostMallocDefault));
         RcclId u;
@@ -2160,12 +2332,20 @@ int tc_comm_create(tc_ctx *ctx, const uint8_t *id, int rank, int world, tc_comm 
         comm_release(c);
         throw;
     }
+    // (only a communicator that stands takes CUs away from the partition levels; the context keeps the largest
+    // reservation of its live communicators)
+    ctx->live_comms++;
+    if (c->cus > ctx->reserved_cus) ctx->reserved_cus = c->cus;
     *out = c;
     TC_API_END(ctx)
 }
 
 void tc_comm_destroy(tc_comm *comm) {
-    if (comm && comm->ctx) comm->ctx->reserved_cus = 0;
+    if (comm && comm->ctx && comm->comm) {   // (a communicator that was created: tc_comm_create counted it)
+        tc_ctx *ctx = comm->ctx;
+        if (ctx->live_comms > 0) ctx->live_comms--;
+        if (ctx->live_comms == 0) ctx->reserved_cus = 0;
+    }
     comm_release(comm);
 }
 
@@ -2189,8 +2369,10 @@ int tc_comm_gather(tc_comm *c, int root, const uint8_t *d_container, uint64_t by
         TC_FAIL(ctx, TC_ERR_ARG, "bad argument");
     if (c->inflight) TC_FAIL(ctx, TC_ERR_ARG, "the previous gather has not been waited for");
     hipStream_t s = c->stream;
-    // what the encoder produced on its stream must be there before the exchange reads it
-    TC_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    // what the encoder produced on its stream must be there before the exchange reads it: the exchange's stream waits
+    // for it on the device (no host synchronisation: the caller may already have the next record's encode queued)
+    TC_HIP(ctx, hipEventRecord(c->ev_ready, ctx->stream));
+    TC_HIP(ctx, hipStreamWaitEvent(s, c->ev_ready, 0));
     c->h_words[0] = bytes;
     TC_HIP(ctx, hipMemcpyAsync(c->d_words, c->h_words, sizeof(u64), hipMemcpyHostToDevice, s));
     TC_NCCL(c, c->api->AllGather(c->d_words, c->d_words + 1, 1, kNcclUint64, c->comm, s));

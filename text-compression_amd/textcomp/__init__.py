@@ -304,6 +304,12 @@ class Context:
     def fm_build(self, text):
         return FMIndexHandle(self, text)
 
+    def fm_build_dev(self, d_text):
+        """index of a text that already lies in HBM (a torch uint8 tensor on this context's device): tc_fm_build_dev"""
+        h = C.c_void_p()
+        self._check(self.lib.tc_fm_build_dev(self.handle, C.c_void_p(d_text.data_ptr()) if d_text.numel() else None, d_text.numel(), C.byref(h)))
+        return FMIndexHandle(self, None, _handle=h, _n=d_text.numel())
+
 
 class FMIndexHandle:
     """`tc_fm`: the device-resident FM-index of one text."""

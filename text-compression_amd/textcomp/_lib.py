@@ -36,7 +36,8 @@ class Stats(C.Structure):
                 ("radix_launches", C.c_uint32), ("ms_radix", C.c_float),
                 ("keygen_fused", C.c_uint32), ("finish_pass", C.c_uint32),
                 ("sample_dups", C.c_uint32), ("msd_path", C.c_uint32), ("msd_keyonly", C.c_uint32),
-                ("ticket_fallbacks", C.c_uint32)]
+                ("ticket_fallbacks", C.c_uint32), ("ws_chunks", C.c_uint32), ("ws_grown", C.c_uint32),
+                ("seg_rounds", C.c_uint32), ("reserved0", C.c_uint32)]
 
 
 class Block(C.Structure):
@@ -90,6 +91,7 @@ SYMBOLS = [
     ("tc_stream_info", _INT, [_P, _P, _U64, _PU64, _PU64]),
     ("tc_decode_stream", _INT, [_P, _P, _U64, _P, _PU64]),
     ("tc_fm_build", _INT, [_P, _P, _U64, C.POINTER(_P)]),
+    ("tc_fm_build_dev", _INT, [_P, _P, _U64, C.POINTER(_P)]),
     ("tc_fm_free", None, [_P]),
     ("tc_fm_count", _INT, [_P, _P, _P, _P, _U64, _P]),
     ("tc_fm_count_dev", _INT, [_P, _P, _P, _P, _U64, _P]),

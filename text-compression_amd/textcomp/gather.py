@@ -34,6 +34,7 @@ class BlockGather:
         self._inflight = [None] * depth   # per slot: (works, result)
         self._step = 0
         self.completed = []   # rank 0: finished gathers, oldest first (bounded)
+        self.wait_ms = []     # host time spent waiting for posted transfers, per completed slot
 
     def _alloc(self):
         if self._recv is None:
@@ -45,6 +46,8 @@ class BlockGather:
         if entry is None:
             return
         works, result = entry
+        import time
+        t0 = time.perf_counter()
         for w in works:
             w.wait()
         if works and self.device.type == "cuda":
@@ -52,6 +55,7 @@ class BlockGather:
             # encoder runs on its own HIP stream, so complete the transfer on the host before
             # the caller may overwrite the payload buffer
             torch.cuda.current_stream(self.device).synchronize()
+        self.wait_ms.append((time.perf_counter() - t0) * 1e3)
         self._inflight[slot] = None
         if result is not None:
             self.completed.append(result)
@@ -167,12 +171,16 @@ class NativeGather:
         self._pending = None    # (slot, sizes)
         self._step = 0
         self.completed = []
+        self.wait_ms = []       # host time inside tc_comm_wait, per completed exchange
 
     def _finish(self):
         if self._pending is None:
             return
         slot, sizes = self._pending
+        import time
+        t0 = time.perf_counter()
         self.ctx._check(self.lib.tc_comm_wait(self._h))
+        self.wait_ms.append((time.perf_counter() - t0) * 1e3)
         self._pending = None
         if self.rank == 0:
             buf = self._recv[slot]
