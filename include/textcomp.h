@@ -296,7 +296,9 @@ int tc_fm_info(const tc_fm *fm, uint64_t *N, uint32_t *sigma, int16_t *c_sym, ui
  * back.  The caller moves the bytes (RCCL broadcast); tc_fm_import_dev checks the header
  * (TC_ERR_MALFORMED) and copies out of d_in, which may be released afterwards.  An index imported
  * without the locate part answers tc_fm_count only (tc_fm_locate: TC_ERR_ARG).  Buffers 16-byte
- * aligned.  *bytes: in = capacity, out = bytes used (TC_ERR_CAPACITY: bytes needed). */
+ * aligned.  *bytes: in = capacity, out = bytes used (TC_ERR_CAPACITY: bytes needed).  The byte string is BUILD-SPECIFIC
+ * (it carries a format version: "TCFMI02" since round 3; an export of another version is refused with a message that
+ * says so): it travels between the ranks of one job, it is not an archive format. */
 uint64_t tc_fm_export_bound(const tc_fm *fm, int with_locate);
 int tc_fm_export_dev(tc_ctx *ctx, const tc_fm *fm, int with_locate, uint8_t *d_out, uint64_t *bytes);
 int tc_fm_import_dev(tc_ctx *ctx, const uint8_t *d_in, uint64_t bytes, tc_fm **out);

@@ -119,7 +119,87 @@ def genome_like(n, seed=0x6E0E):
     return t
 
 
-CLASSES = {"zipf_words": zipf_words, "bytes256": bytes256, "ascii96": ascii96, "acgt4": acgt4, "genome_like": genome_like}
+# ---- the device-side generators of the bench's classes leg (tc_generate_dev kinds 2 .. 5, csrc/textcomp.hip), restated in
+# numpy: the same integer function of (kind, seed, position), so that the oracle can encode what the device generates
+
+def _mix(seed, i):
+    return splitmix64_at(seed, np.asarray(i, dtype=np.uint64))
+
+
+def dev_periodic(n, seed=0x4B1B, period=4096):
+    blk = _ACGT[_scaled(_mix(seed, np.arange(period)), 4).astype(np.int64)]
+    return np.resize(blk, n)
+
+
+def dev_runs(n, seed=0x9A75):
+    out = np.empty(n, dtype=np.uint8)
+    for lo in range(0, n, _CHUNK):
+        hi = min(n, lo + _CHUNK)
+        a = max(0, lo - 512)
+        i = np.arange(a, hi, dtype=np.uint64)
+        start = (_scaled(_mix(seed, i), 10) == 0) | (i == 0)
+        # the run head of position i: the last start at or before it, at most 512 back (the device walks back 512 steps)
+        last = np.maximum.accumulate(np.where(start, i, np.uint64(0)))
+        head = np.where(i - last > np.uint64(512), i - np.uint64(512), last)
+        head = np.where((i < np.uint64(512)) & (last == 0), np.uint64(0), head)
+        out[lo:hi] = _ACGT[((_mix(seed + 1, head) >> np.uint64(40)) & np.uint64(3)).astype(np.int64)][lo - a:]
+    return out
+
+
+def dev_genome_like(n, seed=0x6E0E):
+    out = np.empty(n, dtype=np.uint8)
+    for lo in range(0, n, _CHUNK):
+        hi = min(n, lo + _CHUNK)
+        i = np.arange(lo, hi, dtype=np.uint64)
+        b = _ACGT[_scaled(_mix(seed, i), 4).astype(np.int64)]
+        c3, o3 = i // np.uint64(3000), i % np.uint64(3000)
+        f0 = _scaled(_mix(seed + 2, c3), 2700)
+        infam = (o3 >= f0) & (o3 < f0 + np.uint64(300))
+        x = _mix(seed + 3, i)
+        fam = _ACGT[_scaled(_mix(seed + 1, np.where(infam, o3 - f0, np.uint64(0))), 4).astype(np.int64)]
+        mut = _ACGT[((x >> np.uint64(8)) & np.uint64(3)).astype(np.int64)]
+        b = np.where(infam, np.where(_scaled(x, 100) < np.uint64(15), mut, fam), b)
+        c2, o2 = i // np.uint64(20000), i % np.uint64(20000)
+        a0 = _scaled(_mix(seed + 4, c2), 19900)
+        al = np.uint64(15) + _scaled(_mix(seed + 5, c2), 45)
+        b = np.where((o2 >= a0) & (o2 < a0 + al), np.uint8(65), b)
+        c1, o1 = i // np.uint64(100000), i % np.uint64(100000)
+        m0 = _scaled(_mix(seed + 6, c1), 99800)
+        inm = (o1 >= m0) & (o1 < m0 + np.uint64(100))
+        b = np.where(inm, np.where(((o1 - m0) & np.uint64(1)) == 1, np.uint8(65), np.uint8(67)), b)
+        out[lo:hi] = b
+    return out
+
+
+def dev_zipf_words(n, seed=0x21BF, vocab=20000):
+    k = np.arange(vocab, dtype=np.uint64)
+    cw = np.cumsum((np.uint64(1) << np.uint64(40)) // (k + np.uint64(1)), dtype=np.uint64)
+    wlen = (2 + _mix(seed + 1, k) % np.uint64(8)).astype(np.int64)
+    letters = (97 + _mix(seed + 2, (k[:, None] * np.uint64(16) + np.arange(16, dtype=np.uint64)[None, :])) % np.uint64(26)).astype(np.uint8)
+    ncell = (n + 4095) // 4096
+    out = np.zeros(ncell * 4096, dtype=np.uint8)
+    pos = np.zeros(ncell, dtype=np.int64)                      # bytes written in each cell so far
+    cells = np.arange(ncell, dtype=np.uint64)
+    w = 0
+    while True:
+        live = np.nonzero(pos < 4096)[0]
+        if live.size == 0:
+            break
+        u = (_mix(seed + 3, cells[live] * np.uint64(4096) + np.uint64(w)) >> np.uint64(20)) % cw[-1]
+        ids = np.searchsorted(cw, u, side="right")
+        ln = wlen[ids]
+        for t in range(10):                                    # letters 0 .. len - 1, then the space
+            ch = np.where(t < ln, letters[ids, min(t, 15)], np.uint8(32))
+            ok = (t <= ln) & (pos[live] + t < 4096)
+            out[(live * 4096 + pos[live] + t)[ok]] = ch[ok]
+        pos[live] += ln + 1
+        w += 1
+    return out[:n]
+
+
+CLASSES = {"zipf_words": zipf_words, "bytes256": bytes256, "ascii96": ascii96, "acgt4": acgt4, "genome_like": genome_like,
+           "dev_genome_like": dev_genome_like, "dev_zipf_words": dev_zipf_words, "dev_runs": dev_runs, "dev_periodic": dev_periodic}
+DEV_KINDS = {"dev_genome_like": (2, 0x6E0E), "dev_zipf_words": (3, 0x21BF), "dev_runs": (4, 0x9A75), "dev_periodic": (5, 0x4B1B)}
 
 
 def make(name, n):

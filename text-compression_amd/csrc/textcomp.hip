@@ -2081,6 +2081,8 @@ int tc_fm_import_dev(tc_ctx *ctx, const uint8_t *d_in, uint64_t bytes, tc_fm **o
     hipStream_t s = ctx->stream;
     TC_HIP(ctx, hipMemcpyAsync(&h, d_in, sizeof h, hipMemcpyDeviceToHost, s));
     TC_HIP(ctx, hipStreamSynchronize(s));
+    if (memcmp(h.magic, "TCFMI0", 6) == 0 && memcmp(h.magic, kFmMagic, 8) != 0)   // (an export of another build: the layout changed)
+        TC_FAIL(ctx, TC_ERR_MALFORMED, "unsupported FM export version %.7s (this build reads %s: an export travels between ranks of one build, it is not an archive format)", h.magic, kFmMagic);
     if (memcmp(h.magic, kFmMagic, 8) != 0 || h.bytes > bytes || h.N != (h.n ? h.n + 1 : 0) || h.n > TC_MAX_N ||
         h.sigma_bytes > 256 || (h.n && h.lines != h.N / FM_LINE_BITS + 1))
         TC_FAIL(ctx, TC_ERR_MALFORMED, "not an exported FM-index");
