@@ -55,7 +55,7 @@ struct Alphabet {
 
 // ------------------------------------------------------------------ suffix array
 #ifndef SA_KDIR_BITS
-#define SA_KDIR_BITS 22
+#define SA_KDIR_BITS 26
 #endif
 struct SaBuffers {
     u64 *k0, *k1;
@@ -110,7 +110,7 @@ static size_t sa_carve(Arena &A, u64 N, SaBuffers &b, bool own_v1) {
     b.t_dir = A.get<u32>(N / 64 + 2);
     b.t_bsum = A.get<u32>(N / 64 / BDIR_TILE + 2);
     b.fin_rc = A.get<u32>(FIN_REGIONS * FIN_RSTRIDE + 128);
-    b.kdir = A.get<u32>((1u << SA_KDIR_BITS) + 2);
+    b.kdir = A.get<u32>(((size_t)1 << SA_KDIR_BITS) + 2 + ((size_t)1 << SA_KDIR_BITS) / KDF_CHUNK + 64);   // directory + block minima of its fill
     b.hist = A.get<u32>(RDX_MAX_PASSES * RDX_BINS);
     b.rstatus = A.get<u64>(radix_status_words(N));
     b.gstatus = A.get<u64>(2 * (size_t)tc_cdiv(N, GRP_TILE) + 4);
@@ -892,8 +892,25 @@ static void sa_run(tc_ctx *ctx, SaBuffers &b, const u8 *d_text, u64 n, u32 *d_sa
                 rl.t_bits = b.t_bits; rl.t_dir = b.t_dir;
                 if (tkeys) {
                     int kb = 64 - tkeys_shift < SA_KDIR_BITS ? 64 - tkeys_shift : SA_KDIR_BITS;
-                    kdir_build_kernel<<<tc_cdiv((1ull << kb) + 1, 256), 256, 0, s>>>(tkeys, (u32)N, kb, b.kdir);
-                    TC_LAUNCH_CHECK(ctx);
+                    // (a directory fine enough to leave ~16 keys per entry: more bits than log2 N - 4 only make it sparser)
+                    while (kb > 16 && (1ull << kb) > N / 16) kb--;
+                    if (env_int("TC_SA_KDIR_SEARCH", 0) != 0) {
+                        kdir_build_kernel<<<tc_cdiv((1ull << kb) + 1, 256), 256, 0, s>>>(tkeys, (u32)N, kb, b.kdir);
+                        TC_LAUNCH_CHECK(ctx);
+                    } else {
+                        const u64 entries = (1ull << kb) + 1;
+                        const u32 nb = tc_cdiv(entries, KDF_CHUNK);
+                        u32 *bmin = b.kdir + ((size_t)1 << SA_KDIR_BITS) + 2;
+                        tc_memset_async(ctx, b.kdir, 0xff, entries * sizeof(u32));
+                        kdir_mark_kernel<<<tc_cdiv(N, 256), 256, 0, s>>>(tkeys, (u32)N, kb, b.kdir);
+                        TC_LAUNCH_CHECK(ctx);
+                        kdir_fill_min_kernel<<<nb, 256, 0, s>>>(b.kdir, entries, bmin);
+                        TC_LAUNCH_CHECK(ctx);
+                        kdir_fill_spine_kernel<<<1, 1024, 0, s>>>(bmin, nb);
+                        TC_LAUNCH_CHECK(ctx);
+                        kdir_fill_apply_kernel<<<nb, 256, 0, s>>>(b.kdir, entries, bmin);
+                        TC_LAUNCH_CHECK(ctx);
+                    }
                     rl.kdir = b.kdir; rl.kdir_bits = kb;
                 }
             }

@@ -317,6 +317,9 @@ __device__ __forceinline__ NibSumm nib_block_excl(NibSumm mine, NibSumm *s_w, Ni
 #ifndef MTF_BACK_MAX
 #define MTF_BACK_MAX 8192
 #endif
+#ifndef MTF_BACK_FAR
+#define MTF_BACK_FAR (1u << 21)
+#endif
 template <class Acc>
 __device__ __forceinline__ bool nib_list_before(Acc acc, u64 pos, u32 sigma, const u8 *s_lut, u64 *out) {
     u32 seen = 0;          // bit c set: code c already placed
@@ -324,7 +327,7 @@ __device__ __forceinline__ bool nib_list_before(Acc acc, u64 pos, u32 sigma, con
     u32 placed = 0;
     u64 p = pos;
     const u32 all = (sigma >= 32 ? 0xffffffffu : ((1u << sigma) - 1u));
-    for (u32 step = 0; step < MTF_BACK_MAX / 64 && p > 0 && __popc(all & ~seen) > 1; step++) {
+    auto step64 = [&]() {
         const u64 lo = p >= 64 ? p - 64 : 0;                 // chunk [lo, p)
         const u64 j = lo + lane_id();
         const u32 c = j < p ? (u32)s_lut[acc(j) + 1] : 0xffu;
@@ -343,6 +346,40 @@ __device__ __forceinline__ bool nib_list_before(Acc acc, u64 pos, u32 sigma, con
             todo &= ~(1u << cc);
         }
         p = lo;
+    };
+    for (u32 step = 0; step < MTF_BACK_MAX / 64 && p > 0 && __popc(all & ~seen) > 1; step++) step64();
+    // Still open after MTF_BACK_MAX positions: the column has long runs here (repeat-rich or periodic text: a poly-A tract
+    // puts tens of thousands of equal symbols side by side).  Such stretches are SKIPPED 1024 positions at a time -- a
+    // lane looks at 16 bytes and only says whether any of them is a code still missing -- and only a block that holds
+    // one is walked 64 positions at a time.  (Round 4: repeat-rich DNA used to fail here and rerun MTF by the
+    // three-kernel path: 5.4 instead of 1.9 ms per GiB.)  A last column with its byte array only; bounded by
+    // MTF_BACK_FAR positions (a text of one letter never gets here: one missing code ends the walk).
+    if constexpr (std::is_same<Acc, BwtAcc>::value) {
+        for (u32 far = 0; far < MTF_BACK_FAR / 1024 && p >= 1024 && (p & 15) == 0 && __popc(all & ~seen) > 1; far++) {
+            const u64 lo = p - 1024;
+            const bool has_primary = acc.primary >= (i64)lo && acc.primary < (i64)p;
+            bool any = has_primary;
+            if (!has_primary && (((uintptr_t)acc.L) & 15) == 0) {
+                const uint4 v = *reinterpret_cast<const uint4 *>(acc.L + lo + 16 * lane_id());
+                const u32 x[4] = {v.x, v.y, v.z, v.w};
+                const u32 todo = all & ~seen;
+                u32 hit = 0;
+#pragma unroll
+                for (int q = 0; q < 16; q++) {
+                    const u32 c = (u32)s_lut[((x[q >> 2] >> (8 * (q & 3))) & 255u) + 1u];
+                    hit |= c < 16u ? (todo >> c) & 1u : 0u;
+                }
+                any = __ballot(hit != 0) != 0ull;
+            } else {
+                any = true;
+            }
+            if (!any) {
+                p = lo;
+                continue;
+            }
+            for (int sub = 0; sub < 16 && __popc(all & ~seen) > 1; sub++) step64();
+            if (__popc(all & ~seen) > 1) p = lo;      // (the sixteen steps covered the block exactly)
+        }
     }
     u32 rest = all & ~seen;
     if (__popc(rest) > 1 && p > 0) return false;   // window exhausted, still ambiguous

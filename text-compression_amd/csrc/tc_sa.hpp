@@ -1359,7 +1359,27 @@ __device__ __forceinline__ u32 rank_of(const RankLookup &r, const u16 *s_lut, u6
     }
     // round-0 key of suffix p, straight from the text
     u64 key = 0;
-    {
+    if (p + 64 <= r.n && r.P * r.s <= 56) {
+        // (the window as seven unaligned 8-byte loads issued together, the symbols picked out of registers: a byte load per
+        // symbol, each waited for, was up to 56 load latencies in a row per lookup -- most of the time of a sparse lookup)
+        u64 wv[7];
+#pragma unroll
+        for (int x = 0; x < 7; x++) __builtin_memcpy(&wv[x], r.text + p + 8 * x, 8);
+        const u32 len = r.P * r.s;
+        int sh = 64;
+        u32 g = 0, t = 0;
+#pragma unroll
+        for (int k = 0; k < 56; k++) {
+            if ((u32)k < len) {
+                g = g * r.B + (u32)s_lut[(u32)(wv[k >> 3] >> (8 * (k & 7))) & 255u];
+                if (++t == r.s) {
+                    sh -= (int)r.w;
+                    key |= (u64)g << sh;
+                    g = 0; t = 0;
+                }
+            }
+        }
+    } else {
         int sh = 64;
         u64 q = p;
         for (u32 f = 0; f < r.P; f++) {
@@ -1381,6 +1401,20 @@ __device__ __forceinline__ u32 rank_of(const RankLookup &r, const u16 *s_lut, u6
                 const u64 v = key >> (64 - r.kdir_bits);
                 lo = r.kdir[v];
                 hi = r.kdir[v + 1];
+            }
+            if (!WAVE && r.kdir && hi - lo <= 64) {
+                // a fine directory leaves a few keys: the rank is lo + the keys of the range below p's key -- keys of
+                // other buckets of the range compare by their top bits alone, keys of p's own bucket (in pass order,
+                // unsorted) by all bits, and p's key is unique.  No search, no dependent loads.
+                u32 below = 0;
+                for (u64 j = lo; j < hi; j += 8) {
+                    u64 t[8];
+#pragma unroll
+                    for (int x = 0; x < 8; x++) t[x] = j + x < hi ? r.tkeys[j + x] : ~0ull;
+#pragma unroll
+                    for (int x = 0; x < 8; x++) below += (t[x] & ~0xffull) < key ? 1u : 0u;
+                }
+                return (u32)lo + below;
             }
             while (lo < hi) {   // first element of p's top-bits bucket
                 const u64 mid = (lo + hi) >> 1;
@@ -1570,6 +1604,76 @@ __global__ __launch_bounds__(256) void bitdir_down_kernel(const u64 *__restrict_
         run += c[k];
     }
 }
+// The same directory in two streaming steps (round 4: 2^26 entries -- a range of ~16 keys at 1 GiB -- would be 2^26 binary
+// searches the other way): kdir_mark_kernel writes the first index of every prefix value that occurs (the array starts as
+// all ones, entry 2^bits = N), kdir_fill_* give an absent value the entry of the next one that occurs (a suffix minimum).
+__global__ __launch_bounds__(256) void kdir_mark_kernel(const u64 *__restrict__ tkeys, u32 N, int bits, u32 *__restrict__ kdir) {
+    const u64 j = (u64)blockIdx.x * 256 + threadIdx.x;
+    if (j == 0) kdir[(size_t)1 << bits] = N;
+    if (j >= N) return;
+    const u64 v = tkeys[j] >> (64 - bits);
+    if (j == 0 || (tkeys[j - 1] >> (64 - bits)) != v) kdir[v] = (u32)j;
+}
+#define KDF_CHUNK 4096
+__global__ __launch_bounds__(256) void kdir_fill_min_kernel(const u32 *__restrict__ kdir, u64 entries, u32 *__restrict__ bmin) {
+    __shared__ u32 sm[4];
+    const u64 base = (u64)blockIdx.x * KDF_CHUNK;
+    u32 m = 0xffffffffu;
+    for (int k = 0; k < KDF_CHUNK / 256; k++) {
+        const u64 i = base + (u64)k * 256 + threadIdx.x;
+        if (i < entries) { const u32 x = kdir[i]; m = m < x ? m : x; }
+    }
+    for (int d = 32; d >= 1; d >>= 1) { const u32 o = (u32)__shfl_xor((int)m, d, 64); m = m < o ? m : o; }
+    if (lane_id() == 0) sm[threadIdx.x >> 6] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        u32 a = sm[0];
+        for (int i = 1; i < 4; i++) a = a < sm[i] ? a : sm[i];
+        bmin[blockIdx.x] = a;
+    }
+}
+// bmin[b] := min over blocks > b (exclusive suffix minimum over at most ~16 K entries: one workgroup)
+__global__ __launch_bounds__(1024) void kdir_fill_spine_kernel(u32 *bmin, u32 nb) {
+    __shared__ u32 s_m[1024];
+    const u32 per = (nb + 1023) / 1024;
+    const u32 lo = threadIdx.x * per < nb ? threadIdx.x * per : nb;
+    const u32 hi = lo + per < nb ? lo + per : nb;
+    u32 m = 0xffffffffu;
+    for (u32 b = lo; b < hi; b++) { const u32 x = bmin[b]; m = m < x ? m : x; }
+    s_m[threadIdx.x] = m;
+    __syncthreads();
+    u32 run = 0xffffffffu;
+    for (u32 t = 1023; t > threadIdx.x; t--) run = run < s_m[t] ? run : s_m[t];
+    for (u32 b = hi; b-- > lo;) {
+        const u32 x = bmin[b];
+        bmin[b] = run;
+        run = run < x ? run : x;
+    }
+}
+__global__ __launch_bounds__(256) void kdir_fill_apply_kernel(u32 *__restrict__ kdir, u64 entries, const u32 *__restrict__ bmin) {
+    __shared__ u32 s_t[256];
+    constexpr int PER = KDF_CHUNK / 256;
+    const u64 base = (u64)blockIdx.x * KDF_CHUNK + (u64)threadIdx.x * PER;
+    u32 v[PER];
+    u32 m = 0xffffffffu;
+#pragma unroll
+    for (int k = PER - 1; k >= 0; k--) {
+        const u64 i = base + k;
+        v[k] = i < entries ? kdir[i] : 0xffffffffu;
+        m = m < v[k] ? m : v[k];
+        v[k] = m;                       // suffix minimum inside the thread's stretch
+    }
+    s_t[threadIdx.x] = m;
+    __syncthreads();
+    u32 carry = bmin[blockIdx.x];       // everything behind this block
+    for (int t = 255; t > (int)threadIdx.x; t--) carry = carry < s_t[t] ? carry : s_t[t];
+#pragma unroll
+    for (int k = 0; k < PER; k++) {
+        const u64 i = base + k;
+        if (i < entries) kdir[i] = v[k] < carry ? v[k] : carry;
+    }
+}
+
 // kdir[v] = first index of tkeys whose top `bits` bits are >= v (v = 0 .. 2^bits)
 __global__ __launch_bounds__(256) void kdir_build_kernel(const u64 *__restrict__ tkeys, u32 N, int bits,
                                                          u32 *__restrict__ kdir) {
