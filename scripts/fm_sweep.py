@@ -8,12 +8,13 @@ from textcomp.synth import c4_patterns_dev
 npat = int(sys.argv[1]) if len(sys.argv) > 1 else 4_000_000
 ctx = textcomp.Context(0); lib = ctx.lib
 lib.tc_fm_count_dev.argtypes = [C.c_void_p] * 4 + [C.c_uint64, C.c_void_p]
-for lg in (20, 22, 24, 25, 26, 27, 28, 29, 30):
+sizes = [int(x) for x in sys.argv[2].split(",")] if len(sys.argv) > 2 else [20, 22, 24, 25, 26, 27, 28, 29, 30]
+for lg in sizes:
     n = 1 << lg
     d_text = torch.empty(n, dtype=torch.uint8, device="cuda")
     assert lib.tc_generate_dev(ctx.handle, 0, 0xC4, n, C.c_void_p(d_text.data_ptr())) == 0
     torch.cuda.synchronize()
-    fm = ctx.fm_build(d_text.cpu().numpy())
+    fm = ctx.fm_build_dev(d_text)
     pats, d_offs = c4_patterns_dev(ctx, d_text, npat, 100)
     d_out = torch.zeros(npat, dtype=torch.int64, device="cuda")
     torch.cuda.synchronize()

@@ -105,6 +105,10 @@ static inline u32 tc_persistent_grid_for(tc_ctx *ctx, K kernel, int threads, int
     }
     return tc_persistent_grid(ctx, occ < want_per_cu ? occ : want_per_cu);
 }
+// device memory as separately created physical chunks mapped into one address range (what the workspace of a long record
+// is made of: textcomp.hip); *handle releases it.  Returns null when the mapping is not available.
+void *tc_chunked_alloc(tc_ctx *ctx, size_t bytes, int chunk_log2, void **handle);
+void tc_chunked_free(void *handle);
 void tc_sync_check(tc_ctx *ctx);  // stream sync + device error word check
 
 static inline u32 tc_cdiv(u64 a, u64 b) { return (u32)((a + b - 1) / b); }

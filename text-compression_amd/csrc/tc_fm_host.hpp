@@ -38,6 +38,7 @@ struct tc_fm {
     u32 *d_tab = nullptr;   // [0..255] code of byte (0xFFFFFFFF absent), [256..511] C[code], [512..767] cnt[code]
     u64 *d_bits2 = nullptr; // [sigma_bytes^2][lines][8]: one rank bit-vector per pair of byte values (or null)
     u32 *d_tab2 = nullptr;  // [FM_PAIR_SIGMA^2] C2[a * sigma_bytes + b]
+    void *bits2_chunks = nullptr;   // d_bits2 as mapped chunks (tc_chunked_alloc) instead of one hipMalloc block, or null
     u64 lines = 0;
     u32 counts[256];
     i16 sym_of_code[256];
@@ -334,10 +335,26 @@ static void fm_release(tc_fm *fm) {
     if (fm->d_L) (void)hipFree(fm->d_L);
     if (fm->d_sa) (void)hipFree(fm->d_sa);
     if (fm->d_bits) (void)hipFree(fm->d_bits);
-    if (fm->d_bits2) (void)hipFree(fm->d_bits2);
+    if (fm->bits2_chunks) tc_chunked_free(fm->bits2_chunks);
+    else if (fm->d_bits2) (void)hipFree(fm->d_bits2);
     if (fm->d_tab2) (void)hipFree(fm->d_tab2);
     if (fm->d_tab) (void)hipFree(fm->d_tab);
     delete fm;
+}
+
+// the pair vectors of a long text are gigabytes (3.6 bytes per text byte): with TC_FM_VMM = 21 .. 34 and from TC_FM_VMM_MIN_LOG2 (default 2^31 bytes) on
+// they are mapped from 2^TC_FM_VMM-byte chunks like the workspace of a long record (default 0: one hipMalloc block -- the experiment
+// of round 4: the count rate at 2^30 bytes of text does not depend on how the vectors are mapped)
+static void fm_alloc_bits2(tc_ctx *ctx, tc_fm *fm, size_t bytes) {
+    const int lg = env_int("TC_FM_VMM", 0);   // (measured, round 4: no gain -- profiles/r04_fm_sweep.txt -- so off unless asked for)
+    if (lg >= 21 && lg <= 34 && bytes >= ((size_t)1 << env_int("TC_FM_VMM_MIN_LOG2", 31))) {
+        void *p = tc_chunked_alloc(ctx, bytes, lg, &fm->bits2_chunks);
+        if (p) {
+            fm->d_bits2 = static_cast<u64 *>(p);
+            return;
+        }
+    }
+    TC_HIP(ctx, hipMalloc((void **)&fm->d_bits2, bytes));
 }
 
 // text_host or text_dev (a text already in HBM is used where it lies: no copy at all)
@@ -384,7 +401,7 @@ static tc_fm *fm_build_device(tc_ctx *ctx, const u8 *text_host, u64 n, const u8 
         TC_LAUNCH_CHECK(ctx);
         if (sig <= FM_PAIR_SIGMA && n >= 2 && env_int("TC_FM_PAIRS", 1) != 0) {
             TC_HIP(ctx, hipMalloc((void **)&fm->d_tab2, FM_PAIR_SIGMA * FM_PAIR_SIGMA * sizeof(u32)));
-            TC_HIP(ctx, hipMalloc((void **)&fm->d_bits2, (size_t)sig * sig * fm->lines * 64));
+            fm_alloc_bits2(ctx, fm, (size_t)sig * sig * fm->lines * 64);
             TC_HIP(ctx, hipMemsetAsync(fm->d_tab2, 0, FM_PAIR_SIGMA * FM_PAIR_SIGMA * sizeof(u32), s));
             fm_bits2_kernel<<<tc_cdiv(fm->lines, 4), 256, 0, s>>>(fm->d_L, fm->d_sa, d_text, N, fm->d_tab, sig,
                                                                  fm->lines, fm->d_bits2);

@@ -499,9 +499,17 @@ __global__ __launch_bounds__(MSD_NT) void msd_partition_kernel(MsdLevel L, const
 #endif
     __shared__ u16 s_live[256];
     __shared__ u16 s_klut[KEYGEN ? 256 : 1];
+    // KG_SPLIT (round 4; the key-only level 1, whose LDS has the room): the key-generation image -- the tile's text bytes
+    // and its field bytes -- has its OWN region instead of lying over the staging area, so that the image of tile t + 1 is
+    // made while tile t is still staged and stored: its text is written there between the landing of the prefetch and
+    // barrier B3, its field bytes are computed beside the store phase (S4), and the keys are assembled right behind the
+    // next B0 -- no barrier of its own (the overlaid image needed three per tile, in front of the ranking).
+    constexpr bool KG_SPLIT = KEYGEN && !VALS && MSD_ITEMS == 8;
+    __shared__ __attribute__((aligned(16))) u8 s_kr[KG_SPLIT ? MSD_TILE + 16 + 80 + 32 : 16];
+    __shared__ __attribute__((aligned(16))) u8 s_kg8[KG_SPLIT ? MSD_TILE + 64 : 16];
     __shared__ u32 s_scan2[2];
     static_assert(MSD_GROUP == 8 || MSD_GROUP == 16 || MSD_GROUP == 32, "group = 8, 16 or 32 pairs");
-    static_assert(((size_t)MSD_TILE * (VALS ? 12 : 8) + 256 * MSD_GROUP * (VALS ? 12 : 8) + 8192) * (VALS ? 1 : MSD_BPC) <= 163840, "LDS budget");
+    static_assert(((size_t)MSD_TILE * (VALS ? 12 : 8) + 256 * MSD_GROUP * (VALS ? 12 : 8) + 8192 + (KG_SPLIT ? 2 * MSD_TILE + 256 : 0)) * (VALS ? 1 : MSD_BPC) <= 163840, "LDS budget");
     __shared__ MsdTileInfo s_info[4];
 
     const u32 tid = threadIdx.x, G = gridDim.x, b = msd_logical_wg(blockIdx.x, G);
@@ -642,6 +650,42 @@ __global__ __launch_bounds__(MSD_NT) void msd_partition_kernel(MsdLevel L, const
                 asm volatile("s_waitcnt vmcnt(0)" : "+v"(nk4[0]), "+v"(nk4[1]), "+v"(nv4[0]) : : "memory");
         }
     };
+    const u32 B = kg.B;
+    (void)B;
+    auto gen_group = [&](u8 *k_r, u8 *k_g8, u32 grp) {   // positions 8 grp .. 8 grp + 7
+        const u32 *rp = reinterpret_cast<const u32 *>(k_r + KG_PRE + 8 * grp);
+        const u32 x0 = rp[0], x1 = rp[1], x2 = rp[2];
+        u32 c[10];
+        if (kg.hash_ok) {   // (block-uniform) the codes of four bytes by one v_perm_b32 from a table in registers
+            const u32 y0 = __builtin_amdgcn_perm(kg.thi, kg.tlo, (x0 >> kg.hsh) & 0x07070707u);
+            const u32 y1 = __builtin_amdgcn_perm(kg.thi, kg.tlo, (x1 >> kg.hsh) & 0x07070707u);
+            const u32 y2 = __builtin_amdgcn_perm(kg.thi, kg.tlo, (x2 >> kg.hsh) & 0x07070707u);
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                c[j] = (y0 >> (8 * j)) & 255u;
+                c[4 + j] = (y1 >> (8 * j)) & 255u;
+            }
+            c[8] = y2 & 255u;
+            c[9] = (y2 >> 8) & 255u;
+        } else {
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            c[j] = (u32)s_klut[(x0 >> (8 * j)) & 255u];
+            c[4 + j] = (u32)s_klut[(x1 >> (8 * j)) & 255u];
+        }
+        c[8] = (u32)s_klut[x2 & 255u];
+        c[9] = (u32)s_klut[(x2 >> 8) & 255u];
+        }
+        u32 lo = 0, hi = 0;
+#pragma unroll
+        for (int j = 0; j < 8; j++) {
+            const u32 g = kg.s == 3 ? (c[j] * B + c[j + 1]) * B + c[j + 2] : kg.s == 2 ? c[j] * B + c[j + 1] : c[j];
+            if (j < 4) lo |= g << (8 * j);
+            else hi |= g << (8 * (j - 4));
+        }
+        *reinterpret_cast<uint2 *>(k_g8 + 8 * grp) = make_uint2(lo, hi);
+    };
+    auto kg_fast = [&](const MsdTileInfo x) { return KEYGEN && kg.s <= 3 && MSD_ITEMS == 8 && x.valid != 0 && !kg_edge(x); };
     auto seg_init = [&](u32 qq) {   // threads < 256
         const u32 sb = L.seg[((size_t)qq + b) * 256 + tid];
         s_cur[tid] = sb & ~(u32)(MSD_GROUP - 1);
@@ -678,6 +722,12 @@ __global__ __launch_bounds__(MSD_NT) void msd_partition_kernel(MsdLevel L, const
         load_plain(s_info[0]);
     }
     detach();
+    if (KG_SPLIT && kg_fast(s_info[0])) {   // the first tile's image, before the loop
+        if (tid < kg_units) *reinterpret_cast<uint4 *>(s_kr + tid * 16) = make_uint4(raw.x, raw.y, raw.z, raw.w);
+        __syncthreads();
+        gen_group(s_kr, s_kg8, tid);
+        if (tid < 3) gen_group(s_kr, s_kg8, MSD_NT + tid);
+    }
 
     for (u32 t = t0; t < t1; t++) {
         const u32 slot = (t - t0) & 3u;
@@ -713,53 +763,23 @@ __global__ __launch_bounds__(MSD_NT) void msd_partition_kernel(MsdLevel L, const
             // VALU per thread; level 1: 5.44 -> 5.12 ms.  Issuing the level's small prefetch after the keys instead of before
             // them -- right behind B0 the memory pipeline is still full of the previous tile's stores -- moves the wait,
             // it does not remove it: the level is bound by its 13 GB of scattered stores, 43 % of the fill rate.)
-            if (tid < kg_units) *reinterpret_cast<uint4 *>(k_r + tid * 16) = make_uint4(raw.x, raw.y, raw.z, raw.w);
-            __syncthreads();
-            u8 *k_g8 = reinterpret_cast<u8 *>(k_c);   // field bytes of positions 0 .. MSD_TILE + 23 (the u16 images are unused here)
-            const u32 B = kg.B;
-            auto gen_group = [&](u32 grp) {   // positions 8 grp .. 8 grp + 7
-                const u32 *rp = reinterpret_cast<const u32 *>(k_r + KG_PRE + 8 * grp);
-                const u32 x0 = rp[0], x1 = rp[1], x2 = rp[2];
-                u32 c[10];
-                if (kg.hash_ok) {   // (block-uniform) the codes of four bytes by one v_perm_b32 from a table in registers
-                    const u32 y0 = __builtin_amdgcn_perm(kg.thi, kg.tlo, (x0 >> kg.hsh) & 0x07070707u);
-                    const u32 y1 = __builtin_amdgcn_perm(kg.thi, kg.tlo, (x1 >> kg.hsh) & 0x07070707u);
-                    const u32 y2 = __builtin_amdgcn_perm(kg.thi, kg.tlo, (x2 >> kg.hsh) & 0x07070707u);
-#pragma unroll
-                    for (int j = 0; j < 4; j++) {
-                        c[j] = (y0 >> (8 * j)) & 255u;
-                        c[4 + j] = (y1 >> (8 * j)) & 255u;
-                    }
-                    c[8] = y2 & 255u;
-                    c[9] = (y2 >> 8) & 255u;
-                } else {
-#pragma unroll
-                for (int j = 0; j < 4; j++) {
-                    c[j] = (u32)s_klut[(x0 >> (8 * j)) & 255u];
-                    c[4 + j] = (u32)s_klut[(x1 >> (8 * j)) & 255u];
-                }
-                c[8] = (u32)s_klut[x2 & 255u];
-                c[9] = (u32)s_klut[(x2 >> 8) & 255u];
-                }
-                u32 lo = 0, hi = 0;
-#pragma unroll
-                for (int j = 0; j < 8; j++) {
-                    const u32 g = kg.s == 3 ? (c[j] * B + c[j + 1]) * B + c[j + 2] : kg.s == 2 ? c[j] * B + c[j + 1] : c[j];
-                    if (j < 4) lo |= g << (8 * j);
-                    else hi |= g << (8 * (j - 4));
-                }
-                *reinterpret_cast<uint2 *>(k_g8 + 8 * grp) = make_uint2(lo, hi);
-            };
-            gen_group(tid);
-            if (tid < 3) gen_group(MSD_NT + tid);   // the 6 s <= 18 positions behind the tile that its last suffixes reach
-            __syncthreads();
+            u8 *kr = KG_SPLIT ? s_kr : k_r;
+            u8 *k_g8 = KG_SPLIT ? s_kg8 : reinterpret_cast<u8 *>(k_c);   // field bytes of positions 0 .. MSD_TILE + 23 (the u16 images are unused here)
+            if (!KG_SPLIT) {
+                if (tid < kg_units) *reinterpret_cast<uint4 *>(kr + tid * 16) = make_uint4(raw.x, raw.y, raw.z, raw.w);
+                __syncthreads();
+                gen_group(kr, k_g8, tid);
+                if (tid < 3) gen_group(kr, k_g8, MSD_NT + tid);   // the 6 s <= 18 positions behind the tile that its last suffixes reach
+                __syncthreads();
+            }
+            // (KG_SPLIT: this tile's image was made during the previous tile -- or before the loop -- and B0 has published it)
             {
                 const u32 *gp = reinterpret_cast<const u32 *>(k_g8 + 8 * tid);
                 u32 D[8];
 #pragma unroll
                 for (int i = 0; i < 8; i++) D[i] = gp[i];
                 // the byte before each suffix: text bytes p - 1 .. p + 6
-                const u32 *rq = reinterpret_cast<const u32 *>(k_r + KG_PRE + 8 * tid - 4);
+                const u32 *rq = reinterpret_cast<const u32 *>(kr + KG_PRE + 8 * tid - 4);
                 const u32 r0 = rq[0], r1 = rq[1], r2 = rq[2];
                 const u32 PR[2] = {__builtin_amdgcn_alignbyte(r1, r0, 3), __builtin_amdgcn_alignbyte(r2, r1, 3)};
                 // byte j of the field bytes / byte k of PR into the wanted byte lane
@@ -786,7 +806,7 @@ __global__ __launch_bounds__(MSD_NT) void msd_partition_kernel(MsdLevel L, const
                 else if (kg.s == 2) build(std::integral_constant<int, 2>{});
                 else build(std::integral_constant<int, 1>{});
             }
-            __syncthreads();   // image dead: the staging area may be written
+            if (!KG_SPLIT) __syncthreads();   // image dead: the staging area may be written
         } else if (KEYGEN) {
             const i64 nt = (i64)kg.n_text;
             if (tid < kg_units) {
@@ -910,8 +930,10 @@ __global__ __launch_bounds__(MSD_NT) void msd_partition_kernel(MsdLevel L, const
 #ifdef MSD_PROFILE
         tq[5] = __builtin_readcyclecounter();
 #endif
+        const bool kg_next = KG_SPLIT && kg_fast(nx);
         if (KEYGEN) {
             raw = nraw;
+            if (kg_next && tid < kg_units) *reinterpret_cast<uint4 *>(s_kr + tid * 16) = make_uint4(raw.x, raw.y, raw.z, raw.w);
         } else {
 #pragma unroll
             for (int k = 0; k < MSD_ITEMS; k++) {
@@ -927,6 +949,10 @@ __global__ __launch_bounds__(MSD_NT) void msd_partition_kernel(MsdLevel L, const
 #ifdef MSD_PROFILE
         tq[6] = __builtin_readcyclecounter();
 #endif
+        if (kg_next) {   // the field bytes of tile t + 1, beside the stores of tile t
+            gen_group(s_kr, s_kg8, tid);
+            if (tid < 3) gen_group(s_kr, s_kg8, MSD_NT + tid);
+        }
         // (S4) every digit belongs to one lane group of MSD_GROUP lanes (digits g, g + NG, ...): it stores
         // the whole groups of (carry ++ segment) -- group k = elements [G k, G k + G) -- and then keeps what
         // is left as the new carry.  No other lane group touches the digit's state: no barrier in between.

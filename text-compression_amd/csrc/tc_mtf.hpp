@@ -349,36 +349,32 @@ __device__ __forceinline__ bool nib_list_before(Acc acc, u64 pos, u32 sigma, con
     };
     for (u32 step = 0; step < MTF_BACK_MAX / 64 && p > 0 && __popc(all & ~seen) > 1; step++) step64();
     // Still open after MTF_BACK_MAX positions: the column has long runs here (repeat-rich or periodic text: a poly-A tract
-    // puts tens of thousands of equal symbols side by side).  Such stretches are SKIPPED 1024 positions at a time -- a
-    // lane looks at 16 bytes and only says whether any of them is a code still missing -- and only a block that holds
+    // puts tens of thousands of equal symbols side by side).  Such stretches are SKIPPED 256 positions at a time -- a
+    // lane looks at 4 bytes and only says whether any of them is a code still missing -- and only a block that holds
     // one is walked 64 positions at a time.  (Round 4: repeat-rich DNA used to fail here and rerun MTF by the
     // three-kernel path: 5.4 instead of 1.9 ms per GiB.)  A last column with its byte array only; bounded by
     // MTF_BACK_FAR positions (a text of one letter never gets here: one missing code ends the walk).
     if constexpr (std::is_same<Acc, BwtAcc>::value) {
-        for (u32 far = 0; far < MTF_BACK_FAR / 1024 && p >= 1024 && (p & 15) == 0 && __popc(all & ~seen) > 1; far++) {
-            const u64 lo = p - 1024;
+        for (u32 far = 0; far < MTF_BACK_FAR / 256 && p >= 256 && (p & 3) == 0 && __popc(all & ~seen) > 1; far++) {
+            const u64 lo = p - 256;
             const bool has_primary = acc.primary >= (i64)lo && acc.primary < (i64)p;
-            bool any = has_primary;
-            if (!has_primary && (((uintptr_t)acc.L) & 15) == 0) {
-                const uint4 v = *reinterpret_cast<const uint4 *>(acc.L + lo + 16 * lane_id());
-                const u32 x[4] = {v.x, v.y, v.z, v.w};
+            bool any = true;
+            if (!has_primary && (((uintptr_t)acc.L) & 3) == 0) {   // (a lane looks at 4 bytes: few registers -- these kernels are tight)
+                const u32 x = *reinterpret_cast<const u32 *>(acc.L + lo + 4 * lane_id());
                 const u32 todo = all & ~seen;
                 u32 hit = 0;
 #pragma unroll
-                for (int q = 0; q < 16; q++) {
-                    const u32 c = (u32)s_lut[((x[q >> 2] >> (8 * (q & 3))) & 255u) + 1u];
+                for (int q = 0; q < 4; q++) {
+                    const u32 c = (u32)s_lut[((x >> (8 * q)) & 255u) + 1u];
                     hit |= c < 16u ? (todo >> c) & 1u : 0u;
                 }
                 any = __ballot(hit != 0) != 0ull;
-            } else {
-                any = true;
             }
             if (!any) {
                 p = lo;
                 continue;
             }
-            for (int sub = 0; sub < 16 && __popc(all & ~seen) > 1; sub++) step64();
-            if (__popc(all & ~seen) > 1) p = lo;      // (the sixteen steps covered the block exactly)
+            for (int sub = 0; sub < 4 && __popc(all & ~seen) > 1; sub++) step64();
         }
     }
     u32 rest = all & ~seen;

@@ -100,7 +100,7 @@ static bool ws_grow_vmm(tc_ctx *ctx, size_t want) {
     ctx->ws_cap = total;
     return true;
 }
-static bool ws_alloc_vmm(tc_ctx *ctx, size_t want, int chunk_log2, TcWs &w) {
+static bool ws_alloc_vmm(tc_ctx *ctx, size_t want, int chunk_log2, TcWs &w, bool growable = true) {
     hipMemAllocationProp prop = {};
     prop.type = hipMemAllocationTypePinned;
     prop.location.type = hipMemLocationTypeDevice;
@@ -115,7 +115,7 @@ static bool ws_alloc_vmm(tc_ctx *ctx, size_t want, int chunk_log2, TcWs &w) {
     const size_t total = (want + chunk - 1) / chunk * chunk;
     // the address range: room for the workspace of the longest record (TC_WS_VMM_RESERVE_LOG2, default 2^38 bytes =
     // 256 GiB of addresses, not of memory), so that a context that meets a longer record later grows in place
-    size_t reserve = (size_t)1 << env_int("TC_WS_VMM_RESERVE_LOG2", 38);
+    size_t reserve = growable ? (size_t)1 << env_int("TC_WS_VMM_RESERVE_LOG2", 38) : total;
     reserve = reserve / chunk * chunk;
     if (reserve < total) reserve = total;
     void *va = nullptr;
@@ -169,6 +169,21 @@ static bool ws_alloc(tc_ctx *ctx, size_t want, TcWs &w) {
     }
     w.cap = want;
     return true;
+}
+void *tc_chunked_alloc(tc_ctx *ctx, size_t bytes, int chunk_log2, void **handle) {
+    TcWs *w = new TcWs();
+    if (!ws_alloc_vmm(ctx, bytes, chunk_log2, *w, /*growable=*/false)) {   // (no spare address range: this block never grows)
+        delete w;
+        return nullptr;
+    }
+    *handle = w;
+    return w->p;
+}
+void tc_chunked_free(void *handle) {
+    TcWs *w = static_cast<TcWs *>(handle);
+    if (!w) return;
+    ws_free(*w);
+    delete w;
 }
 static void tc_ws_release(tc_ctx *ctx) {
     TcWs w = ws_detach(ctx);
