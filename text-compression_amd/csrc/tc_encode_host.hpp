@@ -778,7 +778,11 @@ static void sa_run(tc_ctx *ctx, SaBuffers &b, const u8 *d_text, u64 n, u32 *d_sa
                 st.finish_pass = 1;
                 st.rounds = 1;
                 st.m[0] = N; st.key_bytes[0] = 8; st.passes[0] = (u32)npass_stat; st.h[0] = 0;
-                if (m > 0) {  // bring the tied set into SA order (refine relies on it); void entries go last
+                const bool tiny_set = fm <= SEG_W && env_int("TC_SA_TINY", 1) != 0;
+                if (m > 0 && tiny_set) {   // (a few thousand members: one workgroup, tc_seg.hpp)
+                    tied_small_kernel<0><<<1, SEG_NT, 0, s>>>(b.act[0][0], b.act[0][1], b.act[0][2], fm, nullptr, nullptr, nullptr);
+                    TC_LAUNCH_CHECK(ctx);
+                } else if (m > 0) {  // bring the tied set into SA order (refine relies on it); void entries go last
                     u32 mm = fm;
                     pack_active_kernel<<<tc_cdiv(mm, 256), 256, 0, s>>>(b.act[0][0], b.act[0][2], mm, b.sk[0]);
                     TC_LAUNCH_CHECK(ctx);
@@ -862,7 +866,10 @@ static void sa_run(tc_ctx *ctx, SaBuffers &b, const u8 *d_text, u64 n, u32 *d_sa
         rl.isa = b.isa;
     } else {
         rl.skeys = skeys; rl.tkeys = tkeys; rl.tshift = tkeys_shift; rl.sa = sa; rl.t_idx = b.t_idx; rl.t_rank = b.t_rank; rl.t_n = (u32)m;
-        if (m > 0) {
+        if (m > 0 && m <= SEG_W && env_int("TC_SA_TINY", 1) != 0) {
+            tied_small_kernel<1><<<1, SEG_NT, 0, s>>>(b.act[0][0], b.act[0][1], b.act[0][2], (u32)m, b.t_idx, b.t_rank, b.act[0][3]);
+            TC_LAUNCH_CHECK(ctx);
+        } else if (m > 0) {
             u32 mm = (u32)m;
             widen_u32_kernel<<<tc_cdiv(mm, 256), 256, 0, s>>>(b.act[0][1], b.sk[0], mm);
             TC_LAUNCH_CHECK(ctx);

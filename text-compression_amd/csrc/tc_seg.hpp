@@ -566,6 +566,65 @@ __global__ __launch_bounds__(SEG_NT) void seg_small_kernel(u64 *__restrict__ kx,
     }
 }
 
+// ---- a tied set of at most 4096 members (an iid text: 2 404 of 2^30 suffixes) ---------------------------------
+// One workgroup and the network above instead of two radix sorts of a few thousand pairs (each: a histogram, a scan, a
+// memset, four passes, copies -- ~20 launches of ~8 us for 30 KB of data): MODE 0 brings the set (slot, idx, grp) into SA
+// order in place (void entries, slot = ~0, go last); MODE 1 builds the sparse rank table from it -- t_idx sorted by text
+// position, t_rank = the member's group, tpos[k] = its row -- (table_build_kernel in tc_sa.hpp).
+template <int MODE>
+__global__ __launch_bounds__(SEG_NT) void tied_small_kernel(u32 *__restrict__ slot, u32 *__restrict__ idx, u32 *__restrict__ grp,
+                                                            u32 m, u32 *__restrict__ t_idx, u32 *__restrict__ t_rank,
+                                                            u32 *__restrict__ tpos) {
+    __shared__ u64 s_cmp[SEG_W + SEG_W / 16];
+    __shared__ u32 s_a[SEG_W], s_b[SEG_W];
+    const u32 tid = threadIdx.x, p0 = tid * 16;
+    int lw = 4;
+    while ((1u << lw) < m) lw++;
+    for (u32 p = tid; p < (1u << lw); p += SEG_NT) {
+        u64 c = ~0ull;
+        if (p < m) {
+            const u32 k = MODE == 0 ? slot[p] : idx[p];
+            c = ((u64)k << 12) | p;
+            s_a[p] = MODE == 0 ? idx[p] : grp[p];
+            if (MODE == 0) s_b[p] = grp[p];
+        }
+        s_cmp[SEG_PADX(p)] = c;
+    }
+    __syncthreads();
+    u64 e[16];
+    if (p0 < (1u << lw)) seg_lds_load<0>(s_cmp, e, tid);
+    seg_merge<1>(s_cmp, e, tid, lw);
+    seg_merge<2>(s_cmp, e, tid, lw);
+    seg_merge<3>(s_cmp, e, tid, lw);
+    seg_merge<4>(s_cmp, e, tid, lw);
+    if (lw >= 5) seg_merge<5>(s_cmp, e, tid, lw);
+    if (lw >= 6) seg_merge<6>(s_cmp, e, tid, lw);
+    if (lw >= 7) seg_merge<7>(s_cmp, e, tid, lw);
+    if (lw >= 8) seg_merge<8>(s_cmp, e, tid, lw);
+    if (lw >= 9) seg_merge<9>(s_cmp, e, tid, lw);
+    if (lw >= 10) seg_merge<10>(s_cmp, e, tid, lw);
+    if (lw >= 11) seg_merge<11>(s_cmp, e, tid, lw);
+    if (lw >= 12) seg_merge<12>(s_cmp, e, tid, lw);
+    if (p0 < (1u << lw)) {
+#pragma unroll
+        for (int q = 0; q < 16; q++) {
+            const u32 c = p0 + q;
+            if (c < m) {
+                const u32 src = (u32)e[q] & 4095u, k = (u32)(e[q] >> 12);
+                if (MODE == 0) {
+                    slot[c] = k;
+                    idx[c] = s_a[src];
+                    grp[c] = s_b[src];
+                } else {
+                    t_idx[c] = k;
+                    t_rank[c] = s_a[src];
+                    tpos[src] = c;
+                }
+            }
+        }
+    }
+}
+
 __global__ __launch_bounds__(256) void seg_mm_init_kernel(u32 *__restrict__ mm, u32 nruns) {
     const u32 s = blockIdx.x * 256 + threadIdx.x;
     if (s < nruns) { mm[2 * (size_t)s] = 0xffffffffu; mm[2 * (size_t)s + 1] = 0u; }
