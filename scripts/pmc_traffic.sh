@@ -12,7 +12,7 @@ done
 # the whole step by the counters: ONE encode call and nothing else in the process (no warm-up, no extra legs)
 for c in FETCH_SIZE WRITE_SIZE; do
   rm -rf gpurun_out/pmcstep_$c
-  TC_BENCH_CONTAINER=0 rocprofv3 --pmc $c --kernel-trace --output-format csv -d gpurun_out/pmcstep_$c -- python bench.py --n $N --steps 1 --warmup 0 --no-cpu-baseline --no-fm --no-classes > gpurun_out/pmcstep_$c.log 2>&1
+  TC_BENCH_CONTAINER=0 rocprofv3 --pmc $c --kernel-trace --output-format csv -d gpurun_out/pmcstep_$c -- python bench.py --n $N --steps 1 --warmup 0 --no-cpu-baseline --no-fm --no-classes --no-host-path > gpurun_out/pmcstep_$c.log 2>&1
 done
 python - <<'PY'
 import csv,glob,collections,json
