@@ -115,6 +115,9 @@ def self_launch(a):
                # (rebuilt from the parsed values: torchrun's own parser chokes on abbreviations such as --n)
                "--gpus", str(a.gpus), "--steps", str(a.steps), "--warmup", str(a.warmup), "--record-bytes", str(a.n),
                "--cpu-sample", str(a.cpu_sample)] + (["--no-cpu-baseline"] if a.no_cpu_baseline else []) + (["--no-fm"] if a.no_fm else []) + (["--no-classes"] if a.no_classes else []) + (["--no-host-path"] if a.no_host_path else [])
+        if os.environ.get("TC_BENCH_CHILD_CMD"):      # test hook (CPU suite): the parent's deadline / fallback logic around any child
+            import shlex
+            cmd = shlex.split(os.environ["TC_BENCH_CHILD_CMD"])
         with tempfile.TemporaryFile(mode="w+") as fo, tempfile.TemporaryFile(mode="w+") as fe:
             p = subprocess.Popen(cmd, env=env, stdout=fo, stderr=fe, start_new_session=True)
             why = None

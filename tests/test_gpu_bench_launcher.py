@@ -84,3 +84,53 @@ def test_parent_does_not_touch_gpu_or_torch():
     body = src[src.index("def main()"):]
     assert body.index("self_launch(a)") < body.index("import torch")
     assert "os.exec" not in src
+
+
+# ---- the parent's deadline / fallback logic on its own (no GPU, no torch: any child command) ----------------------------
+_CHILD = ("import os, sys, time\n"
+          "mode = os.environ['TC_TEST_CHILD']\n"
+          "fb = 'TC_BENCH_FALLBACK_REASON' in os.environ\n"
+          "if mode == 'stall_first' and not fb: time.sleep(1000)\n"
+          "if mode == 'stall_always': time.sleep(1000)\n"
+          "if mode == 'die_first' and not fb: sys.exit(7)\n"
+          "print('{\"path\": \"%s\", \"gather\": \"%s\", \"cus\": \"%s\", \"why\": \"%s\"}' % ('fallback' if fb else 'first', "
+          "os.environ.get('TC_BENCH_GATHER', ''), os.environ.get('TC_COMM_CUS', ''), os.environ.get('TC_BENCH_FALLBACK_REASON', '')))\n")
+
+
+def _parent(mode, deadline):
+    import time
+    child = os.path.join(ROOT, "gpurun_out", "_launcher_child.py")
+    os.makedirs(os.path.dirname(child), exist_ok=True)
+    with open(child, "w") as f:
+        f.write(_CHILD)
+    t0 = time.time()
+    p = _run(["--gpus", "2", "--steps", "1", "--warmup", "0"],
+             {"TC_BENCH_CHILD_CMD": "%s %s" % (sys.executable, child), "TC_TEST_CHILD": mode, "TC_BENCH_DEADLINE_S": str(deadline)}, timeout=120)
+    return p, time.time() - t0
+
+
+def test_parent_falls_back_after_a_stall_cpu():
+    p, took = _parent("stall_first", 3)
+    assert p.returncode == 0, p.stderr[-2000:]
+    out = json.loads([l for l in p.stdout.splitlines() if l.startswith("{")][0])
+    assert out["path"] == "fallback" and out["gather"] == "torch" and out["cus"] == "0" and "deadline" in out["why"]
+    assert took < 3 + 15 and "starting fresh ranks" in p.stderr
+
+
+def test_parent_falls_back_after_a_dead_rank_cpu():
+    p, _ = _parent("die_first", 20)
+    assert p.returncode == 0
+    out = json.loads([l for l in p.stdout.splitlines() if l.startswith("{")][0])
+    assert out["path"] == "fallback" and "exit code 7" in out["why"]
+
+
+def test_parent_gives_up_after_two_stalls_cpu():
+    p, took = _parent("stall_always", 2)
+    assert p.returncode != 0 and not [l for l in p.stdout.splitlines() if l.startswith("{")]
+    assert took < 2 * (2 + 12) + 5 and "fallback ranks failed as well" in p.stderr
+
+
+def test_first_attempt_line_is_forwarded_unchanged_cpu():
+    p, _ = _parent("ok", 20)
+    assert p.returncode == 0 and json.loads(p.stdout.strip())["path"] == "first" and "starting fresh ranks" not in p.stderr
+

@@ -309,14 +309,14 @@ __device__ __forceinline__ void seg_lds_load(const u64 *s_key, u64 (&e)[16], con
     const u32 ibase = ((tid >> LO) << (LO + 4)) | (tid & ((1u << LO) - 1u));
 #pragma unroll
     for (int q = 0; q < 16; q++)
-        if ((u32)q < Q) e[q] = s_key[SEG_PADX(ibase | ((u32)q << LO))];
+        if ((u32)q < Q) e[q] = s_key[SEG_PADX(ibase + ((u32)q << LO))];
 }
 template <int LO>
 __device__ __forceinline__ void seg_lds_store(u64 *s_key, const u64 (&e)[16], const u32 tid, const u32 Q = 16) {
     const u32 ibase = ((tid >> LO) << (LO + 4)) | (tid & ((1u << LO) - 1u));
 #pragma unroll
     for (int q = 0; q < 16; q++)
-        if ((u32)q < Q) s_key[SEG_PADX(ibase | ((u32)q << LO))] = e[q];
+        if ((u32)q < Q) s_key[SEG_PADX(ibase + ((u32)q << LO))] = e[q];
 }
 // one merge size of the network over the first 2^lw elements of s_key (lw >= 4, lw >= LK).  Which threads hold keys, and
 // how many, depends on the layout: layout 0: threads below 2^(lw - 4), 16 keys each; layout 4: threads whose upper four
@@ -364,7 +364,8 @@ __global__ __launch_bounds__(SEG_NT) void seg_small_kernel(u64 *__restrict__ kx,
     __shared__ u64 s_cmp[SEG_W + SEG_W / 16];    // the network's keys; at the end the staged output keys
     __shared__ u32 s_rank[SEG_W], s_hi[SEG_W / 64], s_val[SEG_W];
     __shared__ u16 s_att[SEG_W];                 // [11:0] head of the slot's run (window slot), [15:12] 0 nothing to do, 1 .. 14: tiny run of 2 .. 15, 15: mid
-    __shared__ u64 s_bits[SEG_EXTW], s_yb[SEG_W / 64], s_midw[SEG_W / 64];
+    __shared__ u64 s_bits[SEG_EXTW], s_yb[SEG_W / 64], s_midw[SEG_W / 64], s_tinyw[SEG_W / 64];
+    __shared__ u32 s_merge;
     __shared__ i32 s_last[SEG_EXTW + 1], s_first[SEG_EXTW + 1];   // last head before word j / first head in words >= j (ext. slots)
     __shared__ u32 s_wpre[SEG_W / 64 + 1];
     __shared__ u16 s_wm[SEG_NT];
@@ -401,7 +402,7 @@ __global__ __launch_bounds__(SEG_NT) void seg_small_kernel(u64 *__restrict__ kx,
     __syncthreads();
     // attributes of this thread's 16 consecutive slots
     const u32 p0 = tid * 16;
-    u32 mine16 = 0, pass16 = 0, mid16 = 0, tmax = 0;
+    u32 mine16 = 0, pass16 = 0, mid16 = 0, tiny16 = 0, tmax = 0;
     {
         const int wi = LBW + (int)(tid >> 2), sub = (int)(tid & 3) * 16;
         const u64 word = s_bits[wi];
@@ -423,6 +424,7 @@ __global__ __launch_bounds__(SEG_NT) void seg_small_kernel(u64 *__restrict__ kx,
             mine16 |= (mine ? 1u : 0u) << q;
             pass16 |= (pass ? 1u : 0u) << q;
             mid16 |= (code == 15u ? 1u : 0u) << q;
+            tiny16 |= (code >= 1u && code < 15u ? 1u : 0u) << q;
             if (code >= 1u && code < 15u && size > tmax) tmax = size;
         }
     }
@@ -435,6 +437,10 @@ __global__ __launch_bounds__(SEG_NT) void seg_small_kernel(u64 *__restrict__ kx,
         w4 |= __shfl_xor(w4, 1, 64);
         w4 |= __shfl_xor(w4, 2, 64);
         if ((tid & 3) == 0) s_midw[tid >> 2] = w4;
+        u64 t4 = (u64)tiny16 << ((tid & 3) * 16);
+        t4 |= __shfl_xor(t4, 1, 64);
+        t4 |= __shfl_xor(t4, 2, 64);
+        if ((tid & 3) == 0) s_tinyw[tid >> 2] = t4;
     }
     __syncthreads();
     if (!s_any) {
@@ -448,7 +454,22 @@ __global__ __launch_bounds__(SEG_NT) void seg_small_kernel(u64 *__restrict__ kx,
         return;
     }
     if (tid < 64) {
-        const u32 c = (u32)__popcll(s_midw[tid]);
+        // The network's size is the power of two that holds the mid members.  When the window's tiny members fit into the
+        // same power of two they go through the network as well -- it costs the same with them -- instead of each
+        // counting its run (a walk as long as the wave's longest tiny run, for all 16 slots of a thread).
+        u64 mw = s_midw[tid];
+        const u64 tw = s_tinyw[tid];
+        const u32 nm = wave_sum((u32)__popcll(mw)), nt = wave_sum((u32)__popcll(tw));
+        int la = 4, lb = 4;
+        while ((1u << la) < nm) la++;
+        while ((1u << lb) < nm + nt) lb++;
+        const bool merge = nm > 0 && nt > 0 && la == lb;
+        if (merge) {
+            mw |= tw;
+            s_midw[tid] = mw;
+        }
+        if (tid == 0) s_merge = merge ? 1u : 0u;
+        const u32 c = (u32)__popcll(mw);
         const u32 inc = wave_incl_sum(c);
         s_wpre[tid] = inc - c;
         if (tid == 63) s_wpre[64] = inc;
@@ -476,11 +497,13 @@ __global__ __launch_bounds__(SEG_NT) void seg_small_kernel(u64 *__restrict__ kx,
     while ((1u << lw) < nmid) lw++;
     // tiny runs: a member's place = head + the members of its run that sort before it; mid members: into the compact array
     u32 tdest[SEG_ITEMS], trank[SEG_ITEMS], tval[SEG_ITEMS];
+    const bool merge_tiny = s_merge != 0u;
 #pragma unroll
     for (int q = 0; q < SEG_ITEMS; q++) {
         const u32 p = q * SEG_NT + tid;
         const u32 att = s_att[p];
-        const u32 code = att >> 12, hsw = att & 4095u;
+        const u32 hsw = att & 4095u;
+        const u32 code = (merge_tiny && (att >> 12) != 0u) ? 15u : att >> 12;
         const u32 rk = s_rank[p];
         tdest[q] = 0xffffffffu;
         trank[q] = rk;
