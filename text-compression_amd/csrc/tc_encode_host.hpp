@@ -125,6 +125,7 @@ static size_t sa_carve(Arena &A, u64 N, SaBuffers &b, bool own_v1) {
             g.lstart[q] = A.get<u32>(g.cap_runs);
             g.lsize[q] = A.get<u32>(g.cap_runs);
             g.ltbase[q] = A.get<u32>(g.cap_runs);
+            g.lshift[q] = A.get<u32>(g.cap_runs);
         }
         g.tile_seg = A.get<u32>(g.cap_tiles);
         g.hist = A.get<u32>(g.cap_runs * 256);
@@ -162,17 +163,20 @@ static void seg_sort_pairs(tc_ctx *ctx, SegBuffers &g, u64 *kx, u32 *vx, u64 *ky
     TC_HIP(ctx, hipMemsetAsync(g.counters, 0, 8 * sizeof(u32), s));
     u32 igrid = tc_cdiv((u64)nwords * 64, 256);
     if (igrid > 16384) igrid = 16384;
-    seg_init_kernel<<<igrid, 256, 0, s>>>(kx, m, g.segbits, nwords, g.lstart[0], g.lsize[0], g.ltbase[0], g.counters, (u32)g.cap_runs);
+    seg_init_kernel<<<igrid, 256, 0, s>>>(kx, m, g.segbits, nwords, g.lstart[0], g.lsize[0], g.ltbase[0], g.lshift[0],
+                                          (u32)(rbits > 8 ? rbits - 8 : 0), g.counters, (u32)g.cap_runs);
     TC_LAUNCH_CHECK(ctx);
-    const int nlev = rbits > 8 ? (rbits + 7) / 8 : 1;
+    // (a level either splits a run by 8 more rank bits or -- all members in one digit -- re-lists it with a better shift:
+    // at most 4 of the first kind and 4 of the second per run)
+    const int nlev = 8;
     int cur = 0;
-    for (int L = 0; L < nlev; L++) {
+    for (int L = 0;; L++) {
         TC_HIP(ctx, hipMemcpyAsync(&ctx->h_scalars[24], g.counters + 2 * cur, 2 * sizeof(u32), hipMemcpyDeviceToHost, s));
         TC_HIP(ctx, hipStreamSynchronize(s));
         const u32 S = (u32)(ctx->h_scalars[24] & 0xffffffffu), T = (u32)(ctx->h_scalars[24] >> 32);
         if (S == 0) break;
+        if (L >= nlev) TC_FAIL(ctx, TC_ERR_INTERNAL, "segmented sort: %u runs still unsorted after %d levels", S, nlev);
         if (S > g.cap_runs || T > g.cap_tiles) TC_FAIL(ctx, TC_ERR_INTERNAL, "segmented sort: %u long runs / %u tiles exceed the tables", S, T);
-        const int shift = rbits - 8 * (L + 1) > 0 ? rbits - 8 * (L + 1) : 0;
         const int nxt = cur ^ 1;
         TC_HIP(ctx, hipMemsetAsync(g.hist, 0, (size_t)S * 256 * sizeof(u32), s));
         seg_mm_init_kernel<<<tc_cdiv(S, 256), 256, 0, s>>>(g.mm, S);
@@ -182,12 +186,12 @@ static void seg_sort_pairs(tc_ctx *ctx, SegBuffers &g, u64 *kx, u32 *vx, u64 *ky
         if (wgrid > 8192) wgrid = 8192;
         seg_tilemap_kernel<<<wgrid, 256, 0, s>>>(g.lsize[cur], g.ltbase[cur], S, g.tile_seg, (u32)g.cap_tiles);
         TC_LAUNCH_CHECK(ctx);
-        seg_count_kernel<<<T, 256, 0, s>>>(kx, ky, g.lstart[cur], g.lsize[cur], g.ltbase[cur], g.tile_seg, g.counters + 2 * cur, shift, g.hist, g.mm);
+        seg_count_kernel<<<T, 256, 0, s>>>(kx, ky, g.lstart[cur], g.lsize[cur], g.ltbase[cur], g.lshift[cur], g.tile_seg, g.counters + 2 * cur, g.hist, g.mm);
         TC_LAUNCH_CHECK(ctx);
-        seg_scan_kernel<<<wgrid, 256, 0, s>>>(g.lstart[cur], g.lsize[cur], g.counters + 2 * cur, g.hist, g.mm, g.segbits, L == nlev - 1 ? 1 : 0,
-                                              g.lstart[nxt], g.lsize[nxt], g.ltbase[nxt], g.counters + 2 * nxt, (u32)g.cap_runs);
+        seg_scan_kernel<<<wgrid, 256, 0, s>>>(g.lstart[cur], g.lsize[cur], g.lshift[cur], g.counters + 2 * cur, g.hist, g.mm, g.segbits, 0,
+                                              g.lstart[nxt], g.lsize[nxt], g.ltbase[nxt], g.lshift[nxt], g.counters + 2 * nxt, (u32)g.cap_runs);
         TC_LAUNCH_CHECK(ctx);
-        seg_scatter_kernel<<<T, 256, 0, s>>>(kx, vx, ky, vy, g.lstart[cur], g.lsize[cur], g.ltbase[cur], g.tile_seg, g.counters + 2 * cur, shift,
+        seg_scatter_kernel<<<T, 256, 0, s>>>(kx, vx, ky, vy, g.lstart[cur], g.lsize[cur], g.ltbase[cur], g.lshift[cur], g.tile_seg, g.counters + 2 * cur,
                                              g.hist, g.mm, g.ybits);
         TC_LAUNCH_CHECK(ctx);
         cur = nxt;

@@ -33,6 +33,7 @@ struct SegBuffers {
     u32 *lstart[2];    // long runs of the current / next level
     u32 *lsize[2];     // bit 31: the run sits in the alternate buffers
     u32 *ltbase[2];    // first tile of the run
+    u32 *lshift[2];    // the run's digit = (rank >> shift) & 255 at this level
     u32 *tile_seg;     // tile -> run
     u32 *hist;         // [runs][256] digit counts, then cursors
     u32 *mm;           // [runs][2] smallest / largest rank of a run (equal: nothing to sort, the run is left alone)
@@ -49,7 +50,8 @@ static inline size_t seg_bit_words(u64 m) { return (size_t)(m / 64 + SEG_EXTW + 
 // is long iff slot k + CAP still belongs to it; its end by a binary search)
 __global__ __launch_bounds__(256) void seg_init_kernel(const u64 *__restrict__ keys, u32 m, u64 *__restrict__ segbits,
                                                        u32 nwords, u32 *__restrict__ lstart, u32 *__restrict__ lsize,
-                                                       u32 *__restrict__ ltbase, u32 *__restrict__ counters, u32 cap_runs) {
+                                                       u32 *__restrict__ ltbase, u32 *__restrict__ lshift, u32 shift0,
+                                                       u32 *__restrict__ counters, u32 cap_runs) {
     const u32 nw_used = (m + 63) / 64;
     for (u64 k0 = ((u64)blockIdx.x * 256 + threadIdx.x) & ~63ull; k0 < (u64)nwords * 64; k0 += (u64)gridDim.x * 256) {
         const u64 k = k0 + (threadIdx.x & 63);
@@ -74,6 +76,7 @@ __global__ __launch_bounds__(256) void seg_init_kernel(const u64 *__restrict__ k
                 lstart[s] = (u32)k;
                 lsize[s] = size;
                 ltbase[s] = tb;
+                lshift[s] = shift0;
             }
         }
     }
@@ -93,15 +96,16 @@ __global__ __launch_bounds__(256) void seg_tilemap_kernel(const u32 *__restrict_
 // digit counts of every long run: hist[run][digit]
 __global__ __launch_bounds__(256) void seg_count_kernel(const u64 *__restrict__ kx, const u64 *__restrict__ ky,
                                                         const u32 *__restrict__ lstart, const u32 *__restrict__ lsize,
-                                                        const u32 *__restrict__ ltbase, const u32 *__restrict__ tile_seg,
-                                                        const u32 *__restrict__ counters, int shift, u32 *__restrict__ hist,
-                                                        u32 *__restrict__ mm) {
+                                                        const u32 *__restrict__ ltbase, const u32 *__restrict__ lshift,
+                                                        const u32 *__restrict__ tile_seg, const u32 *__restrict__ counters,
+                                                        u32 *__restrict__ hist, u32 *__restrict__ mm) {
     __shared__ u32 s_h[256];
     __shared__ u32 s_mm[2];
     const u32 tile = blockIdx.x;
     if (tile >= counters[1]) return;
     const u32 s = tile_seg[tile];
     const u32 sz = lsize[s];
+    const u32 shift = lshift[s];
     const u64 *src = (sz >> 31) ? ky : kx;
     const u32 size = sz & 0x7fffffffu;
     const u32 off = (tile - ltbase[s]) * SEG_PT;
@@ -154,19 +158,46 @@ __global__ __launch_bounds__(256) void seg_count_kernel(const u64 *__restrict__ 
 // per run (one wave): counts -> cursors; the children's heads into segbits; children still longer than the cap onto the
 // next level's list (not after the last level: its children hold equal ranks)
 __global__ __launch_bounds__(256) void seg_scan_kernel(const u32 *__restrict__ lstart, const u32 *__restrict__ lsize,
-                                                       const u32 *__restrict__ counters, u32 *__restrict__ hist,
-                                                       const u32 *__restrict__ mm, u64 *__restrict__ segbits, int last_level,
-                                                       u32 *__restrict__ nstart, u32 *__restrict__ nsize,
-                                                       u32 *__restrict__ ntbase, u32 *__restrict__ ncounters, u32 cap_runs) {
+                                                       const u32 *__restrict__ lshift, const u32 *__restrict__ counters,
+                                                       u32 *__restrict__ hist, u32 *__restrict__ mm, u64 *__restrict__ segbits,
+                                                       int last_level, u32 *__restrict__ nstart, u32 *__restrict__ nsize,
+                                                       u32 *__restrict__ ntbase, u32 *__restrict__ nshift,
+                                                       u32 *__restrict__ ncounters, u32 cap_runs) {
     const u32 nruns = counters[0] < cap_runs ? counters[0] : cap_runs;
     const u32 nwaves = gridDim.x * 4, l = threadIdx.x & 63;
     for (u32 s = blockIdx.x * 4 + (threadIdx.x >> 6); s < nruns; s += nwaves) {
-        if (mm[2 * (size_t)s] == mm[2 * (size_t)s + 1]) continue;   // equal ranks: the run stays as it is, where it is
+        const u32 rmin = mm[2 * (size_t)s], rmax = mm[2 * (size_t)s + 1];
+        if (rmin == rmax) continue;   // equal ranks: the run stays as it is, where it is
         u32 *h = hist + (size_t)s * 256;
         const uint4 c = *reinterpret_cast<const uint4 *>(h + 4 * l);
         const u32 mine = c.x + c.y + c.z + c.w;
         const u32 excl = wave_incl_sum(mine) - mine;
         const u32 start = lstart[s];
+        const u32 shift = lshift[s];
+        // ALL members in one digit (the ranks of a repeat's members lie next to each other: the top digits separate
+        // nothing): no copy -- the run goes onto the next level's list as it is, with the shift that puts its highest
+        // differing rank bit on top of the digit (that level then separates its smallest from its largest rank)
+        {
+            const u64 nz = __ballot(mine != 0);
+            const bool one = __popcll(nz) == 1 && (c.x == mine || c.y == mine || c.z == mine || c.w == mine);
+            if (__ballot(mine != 0 && one) == nz && __popcll(nz) == 1) {   // (wave-uniform)
+                if (l == 0 && !last_level) {
+                    const u32 hb = 31u - (u32)__builtin_clz(rmin ^ rmax);
+                    const u32 sz = lsize[s];
+                    const u32 t = atomicAdd(&ncounters[0], 1u);
+                    const u32 tb = atomicAdd(&ncounters[1], ((sz & 0x7fffffffu) + SEG_PT - 1) / SEG_PT);
+                    if (t < cap_runs) {
+                        nstart[t] = start;
+                        nsize[t] = sz;
+                        ntbase[t] = tb;
+                        nshift[t] = hb >= 7u ? hb - 7u : 0u;
+                    }
+                    mm[2 * (size_t)s] = 0u;          // (seg_scatter_kernel leaves a run with equal marks alone)
+                    mm[2 * (size_t)s + 1] = 0u;
+                }
+                continue;
+            }
+        }
         const u32 other = (~lsize[s]) & 0x80000000u;   // the children sit in the buffers this level writes
         const u32 cc[4] = {c.x, c.y, c.z, c.w};
         u32 run = start + excl;
@@ -176,13 +207,14 @@ __global__ __launch_bounds__(256) void seg_scan_kernel(const u32 *__restrict__ l
             cur[q] = run;
             if (cc[q]) {
                 atomicOr((unsigned long long *)&segbits[run >> 6], 1ull << (run & 63));
-                if (cc[q] > SEG_CAP && !last_level) {
+                if (cc[q] > SEG_CAP && !last_level && shift > 0u) {   // (shift 0: the children hold equal ranks)
                     const u32 t = atomicAdd(&ncounters[0], 1u);
                     const u32 tb = atomicAdd(&ncounters[1], (cc[q] + SEG_PT - 1) / SEG_PT);
                     if (t < cap_runs) {
                         nstart[t] = run;
                         nsize[t] = cc[q] | other;
                         ntbase[t] = tb;
+                        nshift[t] = shift >= 8u ? shift - 8u : 0u;
                     }
                 }
             }
@@ -197,9 +229,9 @@ __global__ __launch_bounds__(256) void seg_scan_kernel(const u32 *__restrict__ l
 __global__ __launch_bounds__(256) void seg_scatter_kernel(u64 *__restrict__ kx, u32 *__restrict__ vx,
                                                           u64 *__restrict__ ky, u32 *__restrict__ vy,
                                                           const u32 *__restrict__ lstart, const u32 *__restrict__ lsize,
-                                                          const u32 *__restrict__ ltbase, const u32 *__restrict__ tile_seg,
-                                                          const u32 *__restrict__ counters, int shift, u32 *__restrict__ cursor,
-                                                          const u32 *__restrict__ mm, u64 *__restrict__ ybits) {
+                                                          const u32 *__restrict__ ltbase, const u32 *__restrict__ lshift,
+                                                          const u32 *__restrict__ tile_seg, const u32 *__restrict__ counters,
+                                                          u32 *__restrict__ cursor, const u32 *__restrict__ mm, u64 *__restrict__ ybits) {
     __shared__ u64 s_k[SEG_PT];
     __shared__ u32 s_v[SEG_PT];
     __shared__ u32 s_cnt[256], s_lb[256], s_gb[256];
@@ -207,8 +239,9 @@ __global__ __launch_bounds__(256) void seg_scatter_kernel(u64 *__restrict__ kx, 
     const u32 tile = blockIdx.x, tid = threadIdx.x;
     if (tile >= counters[1]) return;
     const u32 s = tile_seg[tile];
-    if (mm[2 * (size_t)s] == mm[2 * (size_t)s + 1]) return;   // (equal ranks: see seg_scan_kernel)
+    if (mm[2 * (size_t)s] == mm[2 * (size_t)s + 1]) return;   // (equal ranks, or all in one digit: see seg_scan_kernel)
     const u32 sz = lsize[s];
+    const u32 shift = lshift[s];
     const bool from_y = (sz >> 31) != 0;
     const u64 *ksrc = from_y ? ky : kx;
     const u32 *vsrc = from_y ? vy : vx;
