@@ -461,9 +461,10 @@ __global__ __launch_bounds__(GRP_NT, 4) void group_kernel(GroupArgs a) {
             }
         } else {
             const u32 i = a.vals_are_idx ? k0 : a.in_idx[k0];
-            // dense mode never reads the SA during the rounds: a member that stays tied is
-            // placed (SA, last column) in the round that resolves it
-            if (!(a.isa && act)) {
+            // nothing reads the SA during the rounds (ranks come from the rank array / the rank table and the sorted
+            // keys): a member that stays tied is placed (SA, last column -- a random text byte) in the round that
+            // resolves it, not in every round it lives through (round 4: also with the sparse rank table)
+            if (!act) {
                 a.sa[slot] = i;
                 a.L[slot] = i ? a.text[i - 1] : (u8)0;
             }
