@@ -74,6 +74,22 @@ def test_class_digest_equals_oracle(ctx, key):
             assert st.msd_path == 1
         if d["class"] in ("zipf_words", "genome_like"):
             assert st.msd_path == 0 and st.rounds >= 2
+        if d["class"] == "genome_like":
+            # round 4: the same record by the MSD way with the big finish instance forced -- its whole buckets (the repeat
+            # family, poly-A) go through the KEY ROUND (ordered by the key's remaining 32 bits before any rank exists) --
+            # against the same oracle digest
+            os.environ.update({"TC_SA_MSD": "2", "TC_SA_MSD_BIG": "1"})
+            try:
+                blk2 = Block()
+                blk2.nruns, blk2.run_count, blk2.run_value = cap, d_cnt.data_ptr(), d_val.data_ptr()
+                assert lib.tc_encode_dev(ctx.handle, C.c_void_p(d_text.data_ptr()), n, C.byref(blk2)) == 0, lib.tc_last_error(ctx.handle)
+            finally:
+                os.environ.pop("TC_SA_MSD", None)
+                os.environ.pop("TC_SA_MSD_BIG", None)
+            st2 = ctx.stats()
+            assert st2.msd_path == 1 and st2.rounds >= 3
+            assert (int(blk2.primary), int(blk2.nruns)) == (d["primary"], d["nruns"])
+            assert _checksum(lib, ctx, d_cnt, 4 * k) == d["run_count_checksum64"]
     # and the block decodes
     d_back = torch.empty(n, dtype=torch.uint8, device="cuda")
     assert lib.tc_decode_dev(ctx.handle, C.byref(blk), C.c_void_p(d_back.data_ptr())) == 0, lib.tc_last_error(ctx.handle)

@@ -487,7 +487,14 @@ static void sa_run(tc_ctx *ctx, SaBuffers &b, const u8 *d_text, u64 n, u32 *d_sa
             // suffixes come by binary search in its sorted keys -- but repeat-rich DNA is slower this way
             // than by the LSD way, whose finish orders 14+ symbols instead of 12: 1 GiB genome-like
             // 188 ms against 116 ms.  So the sample decides for both instances.)
-            const bool try_msd = msd_cand && cfg.P == 7 && (env_int("TC_SA_MSD", 1) == 2 || (msd_fits && msd_iid));
+            // (round 4 tried to send repeat-rich DNA this way as well -- the big instance's whole buckets go through the KEY
+            // ROUND below and come out tied on all 21 symbols -- but on such text the levels and the big finish themselves are
+            // slow: 8.1 instead of 5.9 ms per level and 32 instead of 7 ms for the finish at 1 GiB (one workgroup per level-3
+            // parent: the parents of the repeat family are the tail), 112 ms against 99 by the LSD way.  TC_SA_MSD=3: that
+            // experiment; the key round itself stays for the whole buckets an iid-looking text still has.)
+            const bool keyround = env_int("TC_SA_KEYROUND", 1) != 0;
+            const bool try_msd = msd_cand && cfg.P == 7 && (env_int("TC_SA_MSD", 1) == 2 ||
+                                                            (msd_fits && (msd_iid || (msd_big && keyround && env_int("TC_SA_MSD", 1) == 3))));
             // no suffix array asked for (encode, BWT): the levels can move keys only (tc_msd.hpp, VALS = false).  Both
             // finish instances; the big one's over-long buckets (whole tied groups: msd_whole_kernel works from the
             // suffix starts) send the text through the levels again with the starts moving along
@@ -801,6 +808,31 @@ static void sa_run(tc_ctx *ctx, SaBuffers &b, const u8 *d_text, u64 n, u32 *d_sa
                     TC_LAUNCH_CHECK(ctx);
                     TC_HIP(ctx, hipMemcpyAsync(b.act[0][1], rs.vals, mm * sizeof(u32), hipMemcpyDeviceToDevice, s));
                 }
+                // the key round (tc_sa.hpp): whole buckets were emitted as groups that share 9 symbols; the key holds 12 more
+                if (msd && msd_big && (over & 2u) && keyround && m >= (u64)env_int("TC_SA_SEG_MIN", 1 << 16) && env_int("TC_SA_SEG", 1) != 0) {
+                    const u32 mm = (u32)m;
+                    u64 *kall = const_cast<u64 *>(kbuf_sorted);
+                    key_round_kernel<<<tc_cdiv(mm, 256), 256, 0, s>>>(b.act[0][0], b.act[0][2], kall, mm, b.sk[0], b.sv[0]);
+                    TC_LAUNCH_CHECK(ctx);
+                    seg_sort_pairs(ctx, b.seg, b.sk[0], b.sv[0], b.sk[1], b.sv[1], mm, 32);
+                    key_round_store_kernel<<<tc_cdiv(mm, 256), 256, 0, s>>>(b.sk[0], b.act[0][0], mm, kall);
+                    TC_LAUNCH_CHECK(ctx);
+                    GroupArgs gk = {};
+                    gk.keys = b.sk[0]; gk.count = mm; gk.vals = b.sv[0]; gk.vals_are_idx = 0; gk.norank = 1;
+                    gk.in_slot = b.act[0][0]; gk.in_idx = b.act[0][1];
+                    gk.out_slot = b.act[1][0]; gk.out_idx = b.act[1][1]; gk.out_grp = b.act[1][2];
+                    run_group(false, gk, sa);
+                    const u64 m2 = fetch_m();
+                    for (int q = 0; q < 3; q++)
+                        if (m2) TC_HIP(ctx, hipMemcpyAsync(b.act[0][q], b.act[1][q], m2 * sizeof(u32), hipMemcpyDeviceToDevice, s));
+                    st.m[st.rounds] = m; st.key_bytes[st.rounds] = 8; st.passes[st.rounds] = 1; st.h[st.rounds] = (u32)h_start;
+                    st.rounds++;
+                    st.seg_rounds++;
+                    if (env_int("TC_SA_TRACE", 0))
+                        fprintf(stderr, "textcomp: key round: %u members of whole buckets ordered by the key's remaining 32 bits, %llu stay tied\n", mm, (unsigned long long)m2);
+                    m = m2;
+                    h_start = cfg.h0;   // every tie now shares the whole key
+                }
             }
             }   // way
         }
@@ -901,19 +933,20 @@ static void sa_run(tc_ctx *ctx, SaBuffers &b, const u8 *d_text, u64 n, u32 *d_sa
                 bitdir_down_kernel<<<nb, 256, 0, s>>>(b.t_bits, nwords, b.t_bsum, b.t_dir);
                 TC_LAUNCH_CHECK(ctx);
                 rl.t_bits = b.t_bits; rl.t_dir = b.t_dir;
-                if (tkeys) {
-                    int kb = 64 - tkeys_shift < SA_KDIR_BITS ? 64 - tkeys_shift : SA_KDIR_BITS;
+                const u64 *dkeys = tkeys ? tkeys : ((skeys == b.k0 || skeys == b.k1) ? skeys : nullptr);   // (sorted keys: a directory serves them too)
+                if (dkeys) {
+                    int kb = tkeys ? (64 - tkeys_shift < SA_KDIR_BITS ? 64 - tkeys_shift : SA_KDIR_BITS) : SA_KDIR_BITS;
                     // (a directory fine enough to leave ~16 keys per entry: more bits than log2 N - 4 only make it sparser)
                     while (kb > 16 && (1ull << kb) > N / 16) kb--;
                     if (env_int("TC_SA_KDIR_SEARCH", 0) != 0) {
-                        kdir_build_kernel<<<tc_cdiv((1ull << kb) + 1, 256), 256, 0, s>>>(tkeys, (u32)N, kb, b.kdir);
+                        kdir_build_kernel<<<tc_cdiv((1ull << kb) + 1, 256), 256, 0, s>>>(dkeys, (u32)N, kb, b.kdir);
                         TC_LAUNCH_CHECK(ctx);
                     } else {
                         const u64 entries = (1ull << kb) + 1;
                         const u32 nb = tc_cdiv(entries, KDF_CHUNK);
                         u32 *bmin = b.kdir + ((size_t)1 << SA_KDIR_BITS) + 2;
                         tc_memset_async(ctx, b.kdir, 0xff, entries * sizeof(u32));
-                        kdir_mark_kernel<<<tc_cdiv(N, 256), 256, 0, s>>>(tkeys, (u32)N, kb, b.kdir);
+                        kdir_mark_kernel<<<tc_cdiv(N, 256), 256, 0, s>>>(dkeys, (u32)N, kb, b.kdir);
                         TC_LAUNCH_CHECK(ctx);
                         kdir_fill_min_kernel<<<nb, 256, 0, s>>>(b.kdir, entries, bmin);
                         TC_LAUNCH_CHECK(ctx);

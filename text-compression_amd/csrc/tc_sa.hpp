@@ -298,6 +298,7 @@ struct GroupArgs {
     u8 *L;
     u32 *out_slot, *out_idx, *out_grp, *out_tpos;  // next active set
     int isa_only;
+    int norank;         // REFINE, the key round (tc_encode_host.hpp): no rank array / table exists yet -- nothing to store, no table rows
     u64 *status_max, *status_sum;  // look-back granules, [tiles] each
     u32 *ticket;
     u64 *scalars;  // [1] active count
@@ -474,7 +475,7 @@ __global__ __launch_bounds__(GRP_NT, 4) void group_kernel(GroupArgs a) {
             u32 tp = 0;
             if (a.pairs) a.pairs[j] = moved ? ((u64)i << 32) | g : ~0ull;
             else if (a.isa) { if (moved) a.isa[i] = g; }
-            else {
+            else if (!a.norank) {
                 tp = a.in_tpos[k0];
                 if (moved) a.t_rank[tp] = g;
             }
@@ -482,7 +483,7 @@ __global__ __launch_bounds__(GRP_NT, 4) void group_kernel(GroupArgs a) {
                 a.out_slot[o] = slot;
                 a.out_idx[o] = i;
                 a.out_grp[o] = g;
-                if (!a.isa) a.out_tpos[o] = tp;
+                if (!a.isa && !a.norank) a.out_tpos[o] = tp;
             }
         }
     }
@@ -1467,6 +1468,22 @@ __device__ __forceinline__ u32 rank_of(const RankLookup &r, const u16 *s_lut, u6
         return (u32)lo;
     }
     u64 lo = 0, hi = r.N;  // lower_bound over the key bits above the payload byte
+    if (r.kdir) {          // (the directory over the sorted keys: a range of ~16 of them, counted instead of searched)
+        const u64 v = key >> (64 - r.kdir_bits);
+        lo = r.kdir[v];
+        hi = r.kdir[v + 1];
+        if (hi - lo <= 64) {
+            u32 below = 0;
+            for (u64 j = lo; j < hi; j += 8) {
+                u64 t[8];
+#pragma unroll
+                for (int x = 0; x < 8; x++) t[x] = j + x < hi ? r.skeys[j + x] : ~0ull;
+#pragma unroll
+                for (int x = 0; x < 8; x++) below += (t[x] & ~0xffull) < key ? 1u : 0u;
+            }
+            return (u32)lo + below;
+        }
+    }
     while (lo < hi) {
         u64 mid = (lo + hi) >> 1;
         if ((r.skeys[mid] & ~0xffull) < key) lo = mid + 1; else hi = mid;
@@ -1514,6 +1531,29 @@ __global__ __launch_bounds__(256) void key2_kernel(const u32 *__restrict__ idx,
             if (c) atomicAdd(&hist[i], c);
         }
     }
+}
+
+// ---- the key round (round 4): whole buckets of the MSD way's big finish leave as tied groups that share only the 9 symbols
+// of the three levels.  Before any rank exists they are ordered by what the KEY still holds -- its bits 39..8, the next 12
+// symbols -- with the machinery of a doubling round: key2 = group << 32 | those bits (read where the members lie:
+// keys[slot]), the segmented sort, group_kernel<REFINE> without ranks.  The bucket's keys are put back in sorted order, so
+// that the sorted-key lookups of the later rounds hold for the suffixes this round resolves.
+__global__ __launch_bounds__(256) void key_round_kernel(const u32 *__restrict__ slot, const u32 *__restrict__ grp,
+                                                        const u64 *__restrict__ keys, u32 m, u64 *__restrict__ k2,
+                                                        u32 *__restrict__ kv) {
+    const u32 k = blockIdx.x * 256 + threadIdx.x;
+    if (k >= m) return;
+    k2[k] = ((u64)grp[k] << 32) | ((keys[slot[k]] >> 8) & 0xffffffffull);
+    kv[k] = k;
+}
+// sorted position j goes to slot[j] (the slots of a group are its members' slots in order): key bits 39..8 from the sorted
+// key2, the bits above from the key that lies there now (a member of the same bucket: the same 24 bits), low byte 0
+__global__ __launch_bounds__(256) void key_round_store_kernel(const u64 *__restrict__ k2, const u32 *__restrict__ slot, u32 m,
+                                                              u64 *__restrict__ keys) {
+    const u32 j = blockIdx.x * 256 + threadIdx.x;
+    if (j >= m) return;
+    const u32 p = slot[j];
+    keys[p] = (keys[p] & 0xffffff0000000000ull) | ((k2[j] & 0xffffffffull) << 8);
 }
 
 // primary = rank of suffix 0 (its SA position once everything is resolved)
