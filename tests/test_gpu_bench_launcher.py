@@ -52,28 +52,16 @@ def test_stalled_first_exchange_falls_back_within_the_deadline():
     import time
     t0 = time.time()
     p = _run(["--gpus", "2", "--steps", "2", "--warmup", "1", "--n", str(1 << 22)],
-             {"TC_BENCH_REHEARSAL": "1", "TC_BENCH_STALL_RANK": "1", "TC_BENCH_DEADLINE_S": "75"}, timeout=400)
+             {"TC_BENCH_REHEARSAL": "1", "TC_BENCH_STALL_RANK": "1", "TC_BENCH_DEADLINE_S": "60"}, timeout=400)
     took = time.time() - t0
     assert p.returncode == 0, p.stderr[-4000:]
-    assert took < 75 + 75 + 30, took
+    assert took < 60 + 60 + 30, took
     lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1, p.stdout
     g = json.loads(lines[0])["gather"]
     assert g["path"] == "torch" and "deadline" in g["fallback_reason"], g
     assert g["containers_verified"] == 2 and g["exchange_wait_ms"]["calls"] >= 1
     assert "starting fresh ranks" in p.stderr
-
-
-@pytest.mark.gpu
-def test_stall_in_both_attempts_fails_within_two_deadlines():
-    import time
-    t0 = time.time()
-    p = _run(["--gpus", "2", "--steps", "1", "--warmup", "0", "--n", str(1 << 20)],
-             {"TC_BENCH_REHEARSAL": "1", "TC_BENCH_STALL_ALWAYS": "1", "TC_BENCH_DEADLINE_S": "45"}, timeout=400)
-    assert p.returncode != 0
-    assert time.time() - t0 < 2 * 45 + 40
-    assert not [l for l in p.stdout.splitlines() if l.startswith("{")]
-    assert "fallback ranks failed as well" in p.stderr
 
 
 def test_parent_does_not_touch_gpu_or_torch():
