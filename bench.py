@@ -89,7 +89,7 @@ def self_launch(a):
 
     The first N > 1 exchange over RCCL cannot be rehearsed on the builder's one-GPU boxes, so the parent makes sure
     the driver gets a line whatever happens to it: the ranks run in their own process group under a DEADLINE
-    (start-up allowance + (warm-up + steps) x 10 x the N = 1 step of a record of this size + the verification of the
+    (300 s start-up allowance -- a fresh box pages torch in for a minute or two, N ranks at once -- + (warm-up + steps) x 10 x the N = 1 step of a record of this size + the verification of the
     gathered containers; TC_BENCH_DEADLINE_S overrides).  If they exceed it, or exit non-zero, they are killed as a
     group and FRESH ranks are started once with the most conservative exchange (TC_BENCH_GATHER=torch: the
     torch.distributed batch on torch's stream; TC_COMM_CUS=0: no CU-restricted stream); the line then says so
@@ -144,7 +144,7 @@ def self_launch(a):
             return why, fo.read(), fe.read()[-6000:]
 
     step_est = max(0.005, 0.025 * a.n / GIB)          # the N = 1 step of a record of this size (25 ms per GiB), seconds
-    deadline = float(os.environ.get("TC_BENCH_DEADLINE_S", "0")) or (240.0 + (a.warmup + a.steps) * 10.0 * step_est + 2.0 * a.gpus)
+    deadline = float(os.environ.get("TC_BENCH_DEADLINE_S", "0")) or (300.0 + (a.warmup + a.steps) * 10.0 * step_est + 2.0 * a.gpus)
     why, out, err = attempt({}, deadline)
     if why is not None:
         sys.stderr.write("bench.py: the ranks failed (%s); last lines:\n%s\nbench.py: starting fresh ranks with TC_BENCH_GATHER=torch TC_COMM_CUS=0\n" % (why, err[-3000:]))

@@ -19,6 +19,11 @@ SLICES = [
     ("fuzz_long.py", ["60", "103", "200000"], {"TC_SA_MSD": "2", "TC_SA_MSD_MIN_LOG2": "10", "TC_SA_MSD_BIG": "1"}),
     ("fuzz_long.py", ["80", "104", "120000"], {"TC_MTF_TS": "2", "TC_SA_BIN_MIN_LOG2": "0"}),
     ("fuzz_long.py", ["60", "105", "120000"], {"TC_SA_BIN_MIN_LOG2": "0", "TC_SA_DENSE": "1"}),
+    # round 4: the segmented sort of the doubling rounds at every size (sparse and dense ranks), the streamed key
+    # directory, the key round of the MSD way's whole buckets
+    ("fuzz_long.py", ["80", "109", "120000"], {"TC_SA_SEG_MIN": "1", "TC_SA_ACCEL_MIN": "1"}),
+    ("fuzz_long.py", ["60", "110", "200000"], {"TC_SA_SEG_MIN": "1", "TC_SA_DENSE": "1", "TC_SA_BIN_MIN_LOG2": "0"}),
+    ("fuzz_long.py", ["60", "111", "300000"], {"TC_SA_MSD": "2", "TC_SA_MSD_MIN_LOG2": "10", "TC_SA_MSD_BIG": "1", "TC_SA_SEG_MIN": "1", "TC_SA_ACCEL_MIN": "1"}),
     ("fuzz_raw.py", ["150", "106"], {}),
     ("fuzz_raw.py", ["100", "107"], {"TC_MTF_TS": "2"}),
     ("fuzz_fm.py", ["60", "108"], {}),
