@@ -198,6 +198,18 @@ static void seg_sort_pairs(tc_ctx *ctx, SegBuffers &g, u64 *kx, u32 *vx, u64 *ky
     }
     seg_small_kernel<<<tc_cdiv(m, SEG_SPAN), SEG_NT, 0, s>>>(kx, vx, ky, vy, m, g.segbits, g.ybits);
     TC_LAUNCH_CHECK(ctx);
+#ifdef SEG_PROFILE
+    {   // cycles per phase of thread 0, per window (diagnostic build only)
+        u64 h[16];
+        TC_HIP(ctx, hipStreamSynchronize(s));
+        TC_HIP(ctx, hipMemcpyFromSymbol(h, HIP_SYMBOL(seg_prof), sizeof h));
+        const double w = (double)(h[7] | 1);
+        fprintf(stderr, "seg_small: %llu members, %llu windows (that sort), mid members per window %.0f | cycles per window: bits %.0f attr+masks %.0f (prefix) %.0f image %.0f tiny+compact %.0f tiny store %.0f network %.0f store %.0f\n",
+                (unsigned long long)m, (unsigned long long)h[7], h[8] / w, h[0] / w, h[1] / w, 0.0, h[2] / w, h[3] / w, h[4] / w, h[5] / w, h[6] / w);
+        memset(h, 0, sizeof h);
+        TC_HIP(ctx, hipMemcpyToSymbol(HIP_SYMBOL(seg_prof), h, sizeof h));
+    }
+#endif
 }
 
 static void sa_choose_config(tc_ctx *ctx, const u32 *counts, u64 n, SaConfig &c) {

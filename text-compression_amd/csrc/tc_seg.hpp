@@ -386,21 +386,25 @@ __device__ __forceinline__ void seg_merge(u64 *s_key, u64 (&e)[16], const u32 ti
     }
 }
 
+#ifdef SEG_PROFILE
+__device__ u64 seg_prof[16];   // cycles per phase of seg_small_kernel (thread 0 of every window), windows, mid members
+#endif
 // Window w is responsible for the slots [w * SPAN, (w + 1) * SPAN): it sorts every run of at most CAP members whose head
 // lies there (the last of them may reach CAP - 1 slots further: the window's image holds W = SPAN + CAP slots), and it
 // brings the slots of longer runs (equal ranks: nothing to sort) home from the alternate buffers.  Output in place into the
 // primary buffers: no other window reads what this one writes (a neighbour may LOAD such a slot as part of its image, but
 // never uses it).
-__global__ __launch_bounds__(SEG_NT) void seg_small_kernel(u64 *__restrict__ kx, u32 *__restrict__ vx,
+__global__ __launch_bounds__(SEG_NT, 2) void seg_small_kernel(u64 *__restrict__ kx, u32 *__restrict__ vx,
                                                            const u64 *__restrict__ ky, const u32 *__restrict__ vy, u32 m,
                                                            const u64 *__restrict__ segbits, const u64 *__restrict__ ybits) {
     __shared__ u64 s_cmp[SEG_W + SEG_W / 16];    // the network's keys; at the end the staged output keys
     __shared__ u32 s_rank[SEG_W], s_hi[SEG_W / 64], s_val[SEG_W];
-    __shared__ u16 s_att[SEG_W];                 // [11:0] head of the slot's run (window slot), [15:12] 0 nothing to do, 1 .. 14: tiny run of 2 .. 15, 15: mid
+    __shared__ __attribute__((aligned(16))) u16 s_att[SEG_W];                 // [11:0] head of the slot's run (window slot), [15:12] 0 nothing to do, 1 .. 14: tiny run of 2 .. 15, 15: mid
     __shared__ u64 s_bits[SEG_EXTW], s_yb[SEG_W / 64], s_midw[SEG_W / 64], s_tinyw[SEG_W / 64];
     __shared__ u32 s_merge;
     __shared__ i32 s_last[SEG_EXTW + 1], s_first[SEG_EXTW + 1];   // last head before word j / first head in words >= j (ext. slots)
     __shared__ u32 s_wpre[SEG_W / 64 + 1];
+    __shared__ u32 s_lastp[128], s_firstp[128], s_scan2w[4];
     __shared__ u16 s_wm[SEG_NT];
     __shared__ u32 s_any, s_tmax;
     (void)s_hi;
@@ -408,6 +412,10 @@ __global__ __launch_bounds__(SEG_NT) void seg_small_kernel(u64 *__restrict__ kx,
     const u64 t0 = (u64)blockIdx.x * SEG_SPAN;
     constexpr int LBW = SEG_CAP / 64;          // look-back words
     constexpr i32 BIG = 1 << 30;
+#ifdef SEG_PROFILE
+    u64 sp_t[10];
+    if (tid == 0) sp_t[0] = __builtin_readcyclecounter();
+#endif
     // bit words of the extended window [t0 - CAP, t0 + W]; slot m counts as a head
     if (tid < SEG_EXTW) {
         const i64 gw = (i64)(t0 >> 6) - LBW + tid;
@@ -418,21 +426,47 @@ __global__ __launch_bounds__(SEG_NT) void seg_small_kernel(u64 *__restrict__ kx,
     if (tid >= 128 && tid < 128 + SEG_W / 64) s_yb[tid - 128] = ybits[(t0 >> 6) + (tid - 128)];
     if (tid == 0) { s_any = 0; s_tmax = 0; }
     __syncthreads();
-    if (tid <= SEG_EXTW) {
-        i32 last = -BIG, first = BIG;
+    // s_last[j]: last head in the words before j; s_first[j]: first head in the words from j on (two waves, shuffles:
+    // a loop over the 81 words per thread was 20 000 cycles of a window's 138 000 -- SEG_PROFILE)
+    if (tid < 128) {
+        const u32 l = tid & 63, w = tid >> 6;
+        const u64 bf = tid < SEG_EXTW ? s_bits[tid] : 0ull;                       // forward: word tid
+        const u32 rj = 127u - tid;                                                // backward: word 127 - tid
+        const u64 bb = rj < SEG_EXTW ? s_bits[rj] : 0ull;
+        u32 lp = bf ? (u32)(tid * 64 + 63 - __builtin_clzll(bf)) + 1u : 0u;       // (1 + position; 0: none)
+        u32 fp = bb ? (u32)(rj * 64 + __builtin_ctzll(bb)) : 0x7fffffffu;
 #pragma unroll
-        for (int j = 0; j < SEG_EXTW; j++) {
-            const u64 b = s_bits[j];
-            if (j < (int)tid) {
-                if (b) last = j * 64 + 63 - __builtin_clzll(b);
-            } else if (b && first == BIG) {
-                first = j * 64 + __builtin_ctzll(b);
-            }
+        for (int d = 1; d < 64; d <<= 1) {
+            const u32 a = (u32)__shfl_up((int)lp, d, 64), c = (u32)__shfl_up((int)fp, d, 64);
+            if ((int)l >= d) { lp = lp > a ? lp : a; fp = fp < c ? fp : c; }
         }
-        s_last[tid] = last;
-        s_first[tid] = first;
+        if (l == 63) { s_scan2w[w] = lp; s_scan2w[2 + w] = fp; }
+        s_lastp[tid] = lp;      // inclusive over the wave's words up to tid
+        s_firstp[tid] = fp;     // inclusive over the wave's (reversed) words
     }
     __syncthreads();
+    if (tid <= SEG_EXTW) {
+        // exclusive prefix maximum over words < tid
+        u32 lp = 0;
+        if (tid > 0) {
+            const u32 j = tid - 1;
+            lp = s_lastp[j];
+            if (j >= 64) lp = lp > s_scan2w[0] ? lp : s_scan2w[0];
+        }
+        s_last[tid] = lp ? (i32)(lp - 1u) : -BIG;
+        // inclusive suffix minimum over words >= tid: reversed index 127 - tid
+        u32 fp = 0x7fffffffu;
+        if (tid < SEG_EXTW) {
+            const u32 t = 127u - tid;
+            fp = s_firstp[t];
+            if (t >= 64) fp = fp < s_scan2w[2] ? fp : s_scan2w[2];
+        }
+        s_first[tid] = fp == 0x7fffffffu ? BIG : (i32)fp;
+    }
+    __syncthreads();
+#ifdef SEG_PROFILE
+    if (tid == 0) sp_t[1] = __builtin_readcyclecounter();
+#endif
     // attributes of this thread's 16 consecutive slots
     const u32 p0 = tid * 16;
     u32 mine16 = 0, pass16 = 0, mid16 = 0, tiny16 = 0, tmax = 0;
@@ -440,26 +474,49 @@ __global__ __launch_bounds__(SEG_NT) void seg_small_kernel(u64 *__restrict__ kx,
         const int wi = LBW + (int)(tid >> 2), sub = (int)(tid & 3) * 16;
         const u64 word = s_bits[wi];
         const u32 yw = (u32)(s_yb[tid >> 2] >> sub) & 0xffffu;
+        // the run of each of the 16 slots: its head = the last head at or before the slot, its end = the first head behind
+        // it -- two 64-bit looks outside the thread's 16 bits, then two walks over them in 32-bit arithmetic (sixteen
+        // clz / ctz of 64-bit masks per thread were 15 000 cycles of a window's 138 000)
+        const u32 bits16 = (u32)(word >> sub) & 0xffffu;
+        const u64 below = sub ? word & ((1ull << sub) - 1ull) : 0ull;
+        const u64 above = sub + 16 < 64 ? word >> (sub + 16) : 0ull;
+        const i32 base = wi * 64 + sub;
+        i32 hsv[16], hev[16];
+        {
+            i32 cur = below ? wi * 64 + 63 - __builtin_clzll(below) : s_last[wi];
+#pragma unroll
+            for (int q = 0; q < 16; q++) {
+                if ((bits16 >> q) & 1u) cur = base + q;
+                hsv[q] = cur;
+            }
+            cur = above ? base + 16 + __builtin_ctzll(above) : s_first[wi + 1];
+#pragma unroll
+            for (int q = 15; q >= 0; q--) {
+                hev[q] = cur;
+                if ((bits16 >> q) & 1u) cur = base + q;
+            }
+        }
+        u32 attv[8] = {0, 0, 0, 0, 0, 0, 0, 0};
 #pragma unroll
         for (int q = 0; q < 16; q++) {
-            const int b = sub + q;
-            const u64 le = word & ((2ull << b) - 1ull);
-            const u64 gt = b == 63 ? 0ull : word & ~((2ull << b) - 1ull);
-            const i32 hs = le ? wi * 64 + 63 - __builtin_clzll(le) : s_last[wi];
-            const i32 he = gt ? wi * 64 + __builtin_ctzll(gt) : s_first[wi + 1];
+            const i32 hs = hsv[q], he = hev[q];
             const bool valid = t0 + p0 + q < m;
             const bool small = hs >= 0 && he < BIG && he - hs <= SEG_CAP;
             const bool mine = valid && small && hs >= SEG_CAP && hs < SEG_CAP + SEG_SPAN;
             const bool pass = valid && !small && p0 + q < SEG_SPAN && ((yw >> q) & 1u);
             const u32 size = mine ? (u32)(he - hs) : 0u;
             const u32 code = size < 2 ? 0u : (size <= SEG_TINY ? size - 1u : 15u);
-            s_att[p0 + q] = (u16)((mine ? (u32)(hs - SEG_CAP) : 0u) | (code << 12));
+            attv[q >> 1] |= (((mine ? (u32)(hs - SEG_CAP) : 0u) | (code << 12)) & 0xffffu) << (16 * (q & 1));
             mine16 |= (mine ? 1u : 0u) << q;
             pass16 |= (pass ? 1u : 0u) << q;
             mid16 |= (code == 15u ? 1u : 0u) << q;
             tiny16 |= (code >= 1u && code < 15u ? 1u : 0u) << q;
             if (code >= 1u && code < 15u && size > tmax) tmax = size;
         }
+        // (the 16 attributes as two 16-byte stores: sixteen 2-byte stores 32 bytes apart between lanes collide on the banks)
+        uint4 *ap = reinterpret_cast<uint4 *>(s_att + p0);
+        ap[0] = make_uint4(attv[0], attv[1], attv[2], attv[3]);
+        ap[1] = make_uint4(attv[4], attv[5], attv[6], attv[7]);
     }
     s_wm[tid] = (u16)(mine16 | pass16);
     if (mine16) s_any = 1;
@@ -507,30 +564,62 @@ __global__ __launch_bounds__(SEG_NT) void seg_small_kernel(u64 *__restrict__ kx,
         s_wpre[tid] = inc - c;
         if (tid == 63) s_wpre[64] = inc;
     }
+#ifdef SEG_PROFILE
+    if (tid == 0) sp_t[2] = __builtin_readcyclecounter();
+#endif
     // image: keys and values, coalesced, each slot from the buffer that holds it (the top key halves stay in registers)
     u32 hi[SEG_ITEMS];
+    // (a thread's loads four slots at a time -- eight loads in flight -- then their stores into the image: as one loop it
+    // was a load, a wait, a store, sixteen times: 20 000 cycles of the window by SEG_PROFILE; all sixteen slots at once
+    // cost 64 address registers and spilled)
 #pragma unroll
-    for (int q = 0; q < SEG_ITEMS; q++) {
-        const u32 p = q * SEG_NT + tid;
-        const u64 k = t0 + p;
-        u64 key = 0;
-        u32 val = 0;
-        if (k < m) {
-            const bool iny = (s_yb[p >> 6] >> (p & 63)) & 1ull;
-            key = iny ? ky[k] : kx[k];
-            val = iny ? vy[k] : vx[k];
+    for (int q0 = 0; q0 < SEG_ITEMS; q0 += 4) {
+        u64 ikey[4];
+        u32 ival[4];
+#pragma unroll
+        for (int x = 0; x < 4; x++) {
+            const u32 p = (q0 + x) * SEG_NT + tid;
+            const u64 k = t0 + p;
+            ikey[x] = 0;
+            ival[x] = 0;
+            if (k < m) {
+                const bool iny = (s_yb[p >> 6] >> (p & 63)) & 1ull;
+                ikey[x] = iny ? ky[k] : kx[k];
+                ival[x] = iny ? vy[k] : vx[k];
+            }
         }
-        hi[q] = (u32)(key >> 32);
-        s_rank[p] = (u32)key;
-        s_val[p] = val;
+#pragma unroll
+        for (int x = 0; x < 4; x++) {
+            const u32 p = (q0 + x) * SEG_NT + tid;
+            hi[q0 + x] = (u32)(ikey[x] >> 32);
+            s_rank[p] = (u32)ikey[x];
+            s_val[p] = ival[x];
+        }
     }
     __syncthreads();
+#ifdef SEG_PROFILE
+    if (tid == 0) sp_t[3] = __builtin_readcyclecounter();
+#endif
     const u32 nmid = s_wpre[64];
     int lw = 4;                                   // the network covers 2^lw >= nmid elements
     while ((1u << lw) < nmid) lw++;
     // tiny runs: a member's place = head + the members of its run that sort before it; mid members: into the compact array
     u32 tdest[SEG_ITEMS], trank[SEG_ITEMS], tval[SEG_ITEMS];
     const bool merge_tiny = s_merge != 0u;
+    u32 wtiny = 0;   // the longest tiny run among the slots of this wave (0: none, or they go through the network)
+    if (!merge_tiny && s_tmax) {
+#pragma unroll
+        for (int q = 0; q < SEG_ITEMS; q++) {
+            const u32 c = (u32)s_att[q * SEG_NT + tid] >> 12;
+            const u32 sz = (c >= 1u && c < 15u) ? c + 1u : 0u;
+            wtiny = wtiny > sz ? wtiny : sz;
+        }
+#pragma unroll
+        for (int dd = 32; dd >= 1; dd >>= 1) {
+            const u32 o = (u32)__shfl_xor((int)wtiny, dd, 64);
+            wtiny = wtiny > o ? wtiny : o;
+        }
+    }
 #pragma unroll
     for (int q = 0; q < SEG_ITEMS; q++) {
         const u32 p = q * SEG_NT + tid;
@@ -545,17 +634,11 @@ __global__ __launch_bounds__(SEG_NT) void seg_small_kernel(u64 *__restrict__ kx,
             const u32 c = s_wpre[p >> 6] + (u32)__popcll(s_midw[p >> 6] & ((1ull << (p & 63)) - 1ull));
             s_cmp[SEG_PADX(c)] = ((u64)hsw << 44) | ((u64)rk << 12) | p;
         }
-        {
-            // (bounded by the longest tiny run among this wave's 64 slots; a wave without tiny members skips the walk)
+        if (wtiny) {   // (wave-uniform: the longest tiny run among ALL slots this wave handles, one reduction per window)
             const u32 size = (code >= 1u && code < 15u) ? code + 1u : 0u;
-            u32 wmax = size;
-#pragma unroll
-            for (int dd = 32; dd >= 1; dd >>= 1) {
-                const u32 o = (u32)__shfl_xor((int)wmax, dd, 64);
-                wmax = wmax > o ? wmax : o;
-            }
             u32 cnt = 0;
-            for (u32 d = 0; d < wmax; d++) {
+#pragma unroll 5
+            for (u32 d = 0; d < wtiny; d++) {   // (unrolled: five image reads in flight instead of one per turn)
                 const u32 j = hsw + d;
                 const u32 r = s_rank[j & (SEG_W - 1)];
                 cnt += (d < size && (r < rk || (r == rk && j < p))) ? 1u : 0u;
@@ -567,6 +650,9 @@ __global__ __launch_bounds__(SEG_NT) void seg_small_kernel(u64 *__restrict__ kx,
         for (u32 c = nmid + tid; c < (1u << lw); c += SEG_NT) s_cmp[SEG_PADX(c)] = ~0ull;
     }
     __syncthreads();
+#ifdef SEG_PROFILE
+    if (tid == 0) sp_t[4] = __builtin_readcyclecounter();
+#endif
     // tiny members to their places (all reads of the image are done)
 #pragma unroll
     for (int q = 0; q < SEG_ITEMS; q++) {
@@ -575,6 +661,9 @@ __global__ __launch_bounds__(SEG_NT) void seg_small_kernel(u64 *__restrict__ kx,
             s_val[tdest[q]] = tval[q];
         }
     }
+#ifdef SEG_PROFILE
+    if (tid == 0) sp_t[5] = __builtin_readcyclecounter();
+#endif
     if (nmid) {   // (block-uniform)
         const bool on = p0 < (1u << lw);
         u64 e[16];
@@ -612,6 +701,9 @@ __global__ __launch_bounds__(SEG_NT) void seg_small_kernel(u64 *__restrict__ kx,
         }
     }
     __syncthreads();
+#ifdef SEG_PROFILE
+    if (tid == 0) sp_t[6] = __builtin_readcyclecounter();
+#endif
 #pragma unroll
     for (int q = 0; q < SEG_ITEMS; q++) {
         const u32 p = q * SEG_NT + tid;
@@ -620,6 +712,14 @@ __global__ __launch_bounds__(SEG_NT) void seg_small_kernel(u64 *__restrict__ kx,
             vx[t0 + p] = s_val[p];
         }
     }
+#ifdef SEG_PROFILE
+    if (tid == 0) {
+        sp_t[7] = __builtin_readcyclecounter();
+        for (int x = 0; x < 7; x++) atomicAdd((unsigned long long *)&seg_prof[x], (unsigned long long)(sp_t[x + 1] - sp_t[x]));
+        atomicAdd((unsigned long long *)&seg_prof[7], 1ull);
+        atomicAdd((unsigned long long *)&seg_prof[8], (unsigned long long)nmid);
+    }
+#endif
 }
 
 // ---- a tied set of at most 4096 members (an iid text: 2 404 of 2^30 suffixes) ---------------------------------
