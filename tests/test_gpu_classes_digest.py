@@ -81,6 +81,21 @@ def test_class_digest_equals_oracle(ctx, key):
             assert st.msd_path == 1
         if d["class"] in ("zipf_words", "genome_like"):
             assert st.msd_path == 0 and st.rounds >= 2
+        if d["class"] == "dev_periodic":
+            # round 4: round 0 leaves all but a few suffixes tied -> the first doubling round is a CHAIN round (tc_chain.hpp) and
+            # the record is done in 3 rounds instead of log2(n / 21) + 2; the same record with the chain rounds off, same digest
+            assert st.chain_rounds >= 1 and st.rounds <= 6, (st.chain_rounds, st.rounds)
+            os.environ["TC_SA_CHAIN"] = "0"
+            try:
+                blk2 = Block()
+                blk2.nruns, blk2.run_count, blk2.run_value = cap, d_cnt.data_ptr(), d_val.data_ptr()
+                assert lib.tc_encode_dev(ctx.handle, C.c_void_p(d_text.data_ptr()), n, C.byref(blk2)) == 0, lib.tc_last_error(ctx.handle)
+            finally:
+                os.environ.pop("TC_SA_CHAIN", None)
+            st2 = ctx.stats()
+            assert st2.chain_rounds == 0 and st2.rounds > 10
+            assert (int(blk2.primary), int(blk2.nruns)) == (d["primary"], d["nruns"])
+            assert _checksum(lib, ctx, d_cnt, 4 * k) == d["run_count_checksum64"]
         if d["class"] == "genome_like":
             # round 4: the same record by the MSD way with the big finish instance forced -- its whole buckets (the repeat
             # family, poly-A) go through the KEY ROUND (ordered by the key's remaining 32 bits before any rank exists) --

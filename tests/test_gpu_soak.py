@@ -24,6 +24,11 @@ SLICES = [
     ("fuzz_long.py", ["80", "109", "120000"], {"TC_SA_SEG_MIN": "1", "TC_SA_ACCEL_MIN": "1"}),
     ("fuzz_long.py", ["60", "110", "200000"], {"TC_SA_SEG_MIN": "1", "TC_SA_DENSE": "1", "TC_SA_BIN_MIN_LOG2": "0"}),
     ("fuzz_long.py", ["60", "111", "300000"], {"TC_SA_MSD": "2", "TC_SA_MSD_MIN_LOG2": "10", "TC_SA_MSD_BIG": "1", "TC_SA_SEG_MIN": "1", "TC_SA_ACCEL_MIN": "1"}),
+    # round 4, second half: a chain round (tc_chain.hpp) in every dense doubling round with h >= 4 -- texts made of periods
+    # (fuzz_chain.py) and the general mix
+    ("fuzz_chain.py", ["150", "112", "30000"], {"TC_SA_CHAIN": "2", "TC_SA_DENSE": "1", "TC_SA_SEG_MIN": "1"}),
+    ("fuzz_chain.py", ["80", "113", "120000"], {"TC_SA_CHAIN": "2", "TC_SA_DENSE": "1", "TC_SA_SEG_MIN": "1", "TC_SA_BIN_MIN_LOG2": "0"}),
+    ("fuzz_long.py", ["60", "114", "60000"], {"TC_SA_CHAIN": "2", "TC_SA_DENSE": "1", "TC_SA_SEG_MIN": "1"}),
     ("fuzz_raw.py", ["150", "106"], {}),
     ("fuzz_raw.py", ["100", "107"], {"TC_MTF_TS": "2"}),
     ("fuzz_fm.py", ["60", "108"], {}),

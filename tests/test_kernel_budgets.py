@@ -18,8 +18,8 @@ BUDGETS = {
     "msd_count_kernelILb0ELb1EE": (64, 0, 4),
     "13finish_kernel10FinishArgs": (96, 0, 5),
     "rle_encode_idx_kernelIhE": (128, 0, 4),
-    "mtf_nib_apply_kernelI6BwtAccLb1EhLb0EE": (64, 0, 4),
-    "mtf_nib_apply_kernelI6BwtAccLb1EhLb1EE": (64, 0, 4),     # round 3: the list in 32 bits; a tile's 8 loads in flight together
+    "mtf_nib_apply_kernelI6BwtAccLb1EhLb0EE": (80, 0, 4),     # (round 4: 64 -> 76 with the far backward scan's 16-byte loads; still 4 waves)
+    "mtf_nib_apply_kernelI6BwtAccLb1EhLb1EE": (80, 0, 4),     # round 3: the list in 32 bits; a tile's 8 loads in flight together
     "mtf_ts_apply_kernelI6BwtAccLi5EE": (64, 0, 8),
     "radix_pass_kernelILb0ELb0ELi1ELb0ELb0EE": (160, 0, 3),
     "14rle_nib_kernel10RleNibArgs": (128, 0, 4),          # round 3: the fused RLE -> wire-format kernel (2 x 512 threads per CU)

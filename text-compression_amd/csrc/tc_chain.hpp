@@ -1,0 +1,213 @@
+// tc_chain.hpp -- the CHAIN ROUND of the prefix doubling (round 4): periodic text in O(1) rounds instead of log2 n.
+//
+// A doubling round of createSuffixArray's replacement (reference BWT/Internal.hs:110-134; tc_sa.hpp) orders the members
+// of a tied group g by rank[i + h].  On a text with a long period p every residue class is one group, every member but
+// the few nearest the end sees the SAME rank at i + h, the round sheds those few -- and log2(n / h) rounds each sort all
+// N members for nothing (1 GiB: 27 rounds, 2.5 s).  But what decides the order of two members a, b of g is known without
+// more rounds: follow both by steps of h while they keep seeing the same thing.  Give every tied group g a reference
+// rank ref[g] (the rank one of its members sees at + h: ANY choice is correct, the majority's is the useful one).
+// Position q (group g) is ON PATH iff rank[q + h] == ref[g]; otherwise it is a terminal with sign s = (rank[q + h] > ref[g]).
+// For a member a let k(a) = the number of on-path steps from a (a, a + h, .. a + (k - 1) h on path, a + k h terminal)
+// and s(a) the terminal's sign.  Two members of one group walk through the same groups while both are on path, so
+//   k(a) < k(b):  at step k(a) b sees ref, a sees something smaller (s = 0: a < b) or larger (s = 1: a > b);
+//   k(a) = k(b), s differ: the s = 0 one is smaller;   k, s equal: decided by the rank the terminals see (or tied on).
+// So the order inside g is by the code  s = 0: k   |   s = 1: 0xffffffff - k   (pass 1), then by rank[a + (k + 1) h] (pass 2),
+// and members equal on both share at least (k + 2) h >= 2 h symbols: the doubling goes on with 2 h as after a plain round.
+// A plain round is the special case k = 0 everywhere; on periodic text k(a) ~ (n - a) / h is different for every member of
+// a residue class and ONE such round resolves the text.  A position that is not tied (ref = none) is a terminal: at most
+// one member of a group can reach it on path (its rank is its own), so its code needs no sign.
+//
+// (k, s) per position is a suffix scan along stride h: k(q) = on_path(q) ? k(q + h) + 1 : 0.  Here: flags as two bitmaps
+// (chain_flags_kernel: streaming over the dense rank array + one gather of ref), then a three-phase scan over the
+// (row block, column) grid of the N / h x h matrix of positions: block summaries (A), their scan down every column (B),
+// the codes (C).  Both sorts are the segmented sort of the ordinary rounds (tc_seg.hpp), the groups group_kernel<REFINE>.
+// Dense ranks only (a text that ties nearly everything); chosen by the host when a round shed next to nothing.
+#pragma once
+#include "tc_common.hpp"
+
+#define CHAIN_NONE 0xffffffffu
+#define CHAIN_THREADS_LOG2 18     // (row block, column) cells the scan is cut into, about
+
+struct ChainDims {
+    u32 N, h;
+    u32 rows;   // ceil(N / h)
+    u32 bk;     // rows per block
+    u32 nb;     // blocks
+};
+
+static inline ChainDims chain_dims(u64 N, u64 h) {
+    ChainDims d;
+    d.N = (u32)N; d.h = (u32)h;
+    d.rows = (u32)((N + h - 1) / h);
+    u64 nb = h >= (1ull << CHAIN_THREADS_LOG2) ? 1 : ((1ull << CHAIN_THREADS_LOG2) + h - 1) / h;
+    if (nb > d.rows) nb = d.rows;
+    if (nb < 1) nb = 1;
+    d.bk = (u32)((d.rows + nb - 1) / nb);
+    d.nb = (u32)((d.rows + d.bk - 1) / d.bk);
+    return d;
+}
+// words of the block summaries (nb * h <= 2^18 + h < 2^19 whenever nb > 1)
+static inline size_t chain_summ_words() { return ((size_t)2 << CHAIN_THREADS_LOG2) + 64; }
+
+#ifdef __HIPCC__
+
+// ref[g] for every tied group: the rank its MIDDLE member (in the active set's order) sees at + h.  (Not the last one:
+// round 0 leaves a group's members in the order of their positions, the plain rounds leave equal keys where they are --
+// so the last member is the one nearest the end of the text, the very one that deviates on periodic text.)  The members
+// of a group are contiguous in the active set and fill the group's slots: its size is the last member's slot - head + 1.
+__global__ __launch_bounds__(256) void chain_ref_kernel(const u32 *__restrict__ slot, const u32 *__restrict__ idx,
+                                                        const u32 *__restrict__ grp, const u32 *__restrict__ isa, u32 m, u32 h,
+                                                        u32 N, u32 *__restrict__ ref) {
+    const u64 k = (u64)blockIdx.x * 256 + threadIdx.x;
+    if (k >= m) return;
+    const u32 g = grp[k];
+    if (k + 1 < m && grp[k + 1] == g) return;
+    u32 size = slot[k] - g + 1u;
+    if ((u64)size > k + 1) size = (u32)(k + 1);   // (cannot happen while the invariant above holds)
+    const u64 p = (u64)idx[k - size / 2] + h;
+    ref[g] = p < N ? isa[p] : 0u;
+}
+
+// on-path / sign bits of every position (one 64-bit word per wave and turn)
+__global__ __launch_bounds__(256) void chain_flags_kernel(const u32 *__restrict__ isa, const u32 *__restrict__ ref, u32 N, u32 h,
+                                                          u64 *__restrict__ pathbits, u64 *__restrict__ signbits, u32 nwords) {
+    const u32 lane = threadIdx.x & 63;
+    for (u64 w = ((u64)blockIdx.x * 256 + threadIdx.x) >> 6; w < nwords; w += ((u64)gridDim.x * 256) >> 6) {
+        const u64 q = w * 64 + lane;
+        bool on = false, sg = false;
+        if (q < N) {
+            const u32 r = ref[isa[q]];
+            if (r != CHAIN_NONE) {
+                const u32 nxt = q + h < N ? isa[q + h] : 0u;
+                on = nxt == r;
+                sg = nxt > r;
+            }
+        }
+        const u64 bo = __ballot(on), bs = __ballot(sg);
+        if (lane == 0) {
+            pathbits[w] = bo;
+            signbits[w] = bs;
+        }
+    }
+}
+
+// state of a walk up a column: k on-path steps seen, s the terminal's sign; `thru`: no terminal met yet in this block
+// (packed: bit 31 thru, bit 30 s, bits 29..0 k -- k < N / h < 2^30: the host takes h >= 4)
+__device__ __forceinline__ u32 chain_pack(bool thru, u32 s, u32 k) { return (thru ? 0x80000000u : 0u) | (s << 30) | k; }
+
+__device__ __forceinline__ bool chain_bit(const u64 *__restrict__ bits, u64 q) { return (bits[q >> 6] >> (q & 63)) & 1ull; }
+
+// bits of rows row - 1, row - 2, .. (nr <= 4 of them) of column c: f = on path | sign << 1; a cell beyond the text (last row
+// only; never stepped onto) reads as a terminal
+__device__ __forceinline__ void chain_fetch4(const u64 *__restrict__ pathbits, const u64 *__restrict__ signbits, const ChainDims &d,
+                                             u32 row, u32 nr, u32 c, u32 (&f)[4]) {
+    u64 pw[4], sw[4];
+#pragma unroll
+    for (u32 j = 0; j < 4; j++) {
+        const u64 q = j < nr ? (u64)(row - 1u - j) * d.h + c : 0ull;
+        const bool in = j < nr && q < d.N;
+        pw[j] = in ? pathbits[q >> 6] : 0ull;
+        sw[j] = in ? signbits[q >> 6] : 0ull;
+    }
+#pragma unroll
+    for (u32 j = 0; j < 4; j++) {
+        const u64 q = j < nr ? (u64)(row - 1u - j) * d.h + c : 0ull;
+        f[j] = (u32)((pw[j] >> (q & 63)) & 1ull) | ((u32)((sw[j] >> (q & 63)) & 1ull) << 1);
+    }
+}
+
+// phase A: summary of block b of column c -- walked from its last row up to its first
+__global__ __launch_bounds__(256) void chain_scan_a_kernel(const u64 *__restrict__ pathbits, const u64 *__restrict__ signbits,
+                                                           ChainDims d, u32 *__restrict__ summ) {
+    const u64 t = (u64)blockIdx.x * 256 + threadIdx.x;
+    if (t >= (u64)d.nb * d.h) return;
+    const u32 b = (u32)(t / d.h), c = (u32)(t - (u64)b * d.h);
+    const u32 row0 = b * d.bk;
+    const u32 row1 = row0 + d.bk < d.rows ? row0 + d.bk : d.rows;
+    bool thru = true;
+    u32 k = 0, s = 0;
+    for (u32 row = row1; row > row0;) {   // (four rows' bits fetched together: the addresses do not depend on the state)
+        const u32 nr = row - row0 < 4u ? row - row0 : 4u;
+        u32 f[4];
+        chain_fetch4(pathbits, signbits, d, row, nr, c, f);
+#pragma unroll
+        for (u32 j = 0; j < 4; j++) {
+            if (j >= nr) break;
+            if (f[j] & 1u) k++;
+            else { thru = false; k = 0; s = f[j] >> 1; }
+        }
+        row -= nr;
+    }
+    summ[t] = chain_pack(thru, s, k);
+}
+
+// phase B: per column, the state that enters every block from below (in place of its summary)
+__global__ __launch_bounds__(256) void chain_scan_b_kernel(u32 *__restrict__ summ, ChainDims d) {
+    const u32 c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= d.h) return;
+    u32 k = 0, s = 0;
+    for (u32 b = d.nb; b-- > 0;) {
+        const size_t at = (size_t)b * d.h + c;
+        const u32 x = summ[at];
+        summ[at] = chain_pack(false, s, k);
+        if (x & 0x80000000u) k += x & 0x3fffffffu;
+        else { k = x & 0x3fffffffu; s = (x >> 30) & 1u; }
+    }
+}
+
+// phase C: the codes -- s = 0: k, s = 1: 0xffffffff - k
+__global__ __launch_bounds__(256) void chain_scan_c_kernel(const u64 *__restrict__ pathbits, const u64 *__restrict__ signbits,
+                                                           ChainDims d, const u32 *__restrict__ summ, u32 *__restrict__ code) {
+    const u64 t = (u64)blockIdx.x * 256 + threadIdx.x;
+    if (t >= (u64)d.nb * d.h) return;
+    const u32 b = (u32)(t / d.h), c = (u32)(t - (u64)b * d.h);
+    const u32 row0 = b * d.bk;
+    const u32 row1 = row0 + d.bk < d.rows ? row0 + d.bk : d.rows;
+    u32 k = 0, s = 0;
+    if (d.nb > 1) {
+        const u32 x = summ[t];
+        k = x & 0x3fffffffu;
+        s = (x >> 30) & 1u;
+    }
+    for (u32 row = row1; row > row0;) {
+        const u32 nr = row - row0 < 4u ? row - row0 : 4u;
+        u32 f[4];
+        chain_fetch4(pathbits, signbits, d, row, nr, c, f);
+#pragma unroll
+        for (u32 j = 0; j < 4; j++) {
+            if (j >= nr) break;
+            const u64 q = (u64)(row - 1u - j) * d.h + c;
+            if (f[j] & 1u) k++;
+            else { k = 0; s = f[j] >> 1; }
+            if (q < d.N) code[q] = s ? 0xffffffffu - k : k;
+        }
+        row -= nr;
+    }
+}
+
+// pass 1: key2 = group << 32 | code of the member's position
+__global__ __launch_bounds__(256) void chain_key1_kernel(const u32 *__restrict__ idx, const u32 *__restrict__ grp,
+                                                         const u32 *__restrict__ code, u32 m, u64 *__restrict__ keys,
+                                                         u32 *__restrict__ vals_out) {
+    const u64 k = (u64)blockIdx.x * 256 + threadIdx.x;
+    if (k >= m) return;
+    const u32 i = idx[k];
+    keys[k] = ((u64)grp[k] << 32) | code[i];
+    vals_out[k] = i;
+}
+
+// pass 2: key2 = group << 32 | the rank the member's terminal sees: rank[i + (k + 1) h]
+__global__ __launch_bounds__(256) void chain_key2_kernel(const u32 *__restrict__ idx, const u32 *__restrict__ grp,
+                                                         const u32 *__restrict__ code, const u32 *__restrict__ isa, u32 m,
+                                                         u32 h, u32 N, u64 *__restrict__ keys, u32 *__restrict__ vals_out) {
+    const u64 k = (u64)blockIdx.x * 256 + threadIdx.x;
+    if (k >= m) return;
+    const u32 i = idx[k];
+    const u32 cd = code[i];
+    const u32 steps = (cd >> 31) ? ~cd : cd;
+    const u64 p = (u64)i + ((u64)steps + 1) * h;
+    keys[k] = ((u64)grp[k] << 32) | (p < N ? isa[p] : 0u);
+    vals_out[k] = i;
+}
+
+#endif  // __HIPCC__

@@ -14,6 +14,7 @@
 #include "tc_sa.hpp"
 #include "tc_msd.hpp"
 #include "tc_seg.hpp"
+#include "tc_chain.hpp"
 
 // ---------------------------------------------------------------- small helpers
 static inline void tc_memset_async(tc_ctx *ctx, void *p, int v, size_t bytes) {
@@ -84,6 +85,8 @@ struct SaBuffers {
     u32 msd_grid;
     TiedTable tp;     // key-only levels: hash table of the tied keys (tc_sa.hpp)
     SegBuffers seg;   // segmented sort of the doubling rounds (tc_seg.hpp)
+    // chain rounds (tc_chain.hpp): reference rank per group head slot, code per text position, block summaries of the scan
+    u32 *chain_ref, *chain_code, *chain_summ;
 };
 
 // the MSD round 0 pays from this many suffixes on (level-3 buckets of >= ~64 members on DNA)
@@ -150,6 +153,10 @@ static size_t sa_carve(Arena &A, u64 N, SaBuffers &b, bool own_v1) {
         b.tp.cnt = A.get<u32>((size_t)1 << TP_SLOT_BITS);
         b.tp.bloom = A.get<u32>(((size_t)1 << TP_BLOOM_LOG2) / 32);
     }
+    // (carved last: everything above keeps the offsets it had before the chain rounds existed)
+    b.chain_ref = A.get<u32>(N + 1);
+    b.chain_code = A.get<u32>(N + 1);
+    b.chain_summ = A.get<u32>(chain_summ_words());
     return A.off;
 }
 
@@ -978,6 +985,13 @@ static void sa_run(tc_ctx *ctx, SaBuffers &b, const u8 *d_text, u64 n, u32 *d_sa
     int cur = 0;
     if (env_int("TC_SA_H_START", 0) > 0) h_start = (u64)env_int("TC_SA_H_START", 0);  // experiments: any h <= sorted depth is valid
     u64 h = h_start;
+    // chain rounds (tc_chain.hpp): when a dense round sheds next to nothing (periodic text) the next one orders every group
+    // by how long its members keep seeing the same thing at + h, + 2 h, .. -- two passes of the same sort at one h.
+    // TC_SA_CHAIN: 0 never, 1 (default) after a round that resolved < 1/256 of a set of >= 2^20 members -- or at once when round 0
+    // left fewer than N / 4096 suffixes untied --, 2 every dense round
+    const int chain_env = env_int("TC_SA_CHAIN", 1);
+    int keymode = 0;      // 0: key2 = rank[i + h]; 1: the chain code; 2: the rank the member's terminal sees
+    u64 prev_mm = 0;      // members of the last plain doubling round (0: none yet, or a chain round came since)
     while (m > 0) {
         if (st.rounds >= TC_MAX_ROUNDS) TC_FAIL(ctx, TC_ERR_INTERNAL, "suffix sort did not converge");
         u32 mm = (u32)m;
@@ -1006,10 +1020,41 @@ static void sa_run(tc_ctx *ctx, SaBuffers &b, const u8 *d_text, u64 n, u32 *d_sa
         // large rounds: digit histograms on the way; dense: the suffix starts are sorted along
         // (no gather through the active set afterwards)
         const bool seg_round = env_int("TC_SA_SEG", 1) != 0 && mm >= (u32)env_int("TC_SA_SEG_MIN", 1 << 16);
-        const bool fuse_hist = mm >= (1u << 20) && !seg_round;
+        const bool fuse_hist = mm >= (1u << 20) && !seg_round && keymode == 0;
         const bool vals_idx = dense;
         if (fuse_hist) tc_memset_async(ctx, b.hist, 0, sizeof(u32) * RDX_MAX_PASSES * RDX_BINS);
-        {
+        if (keymode == 0 && dense && seg_round && hh >= 4 && h < N && chain_env != 0 &&
+            (chain_env == 2 || (mm >= (1u << 20) && ((prev_mm > 0 && (prev_mm - m) * 256 < prev_mm) ||
+                                                      (st.rounds == 1 && (N - m) * 4096 < N))))) {   // (or round 0 left all but a few tied)
+            // reference ranks, on-path / sign bits of every position, their scan along stride h -> a code per position
+            const ChainDims cd = chain_dims(N, hh);
+            const u32 nwords = (u32)(N / 64 + 1);
+            u64 *pathbits = b.t_bits, *signbits = b.seg.ybits;   // (both free here: sparse-mode bitmap; the sort's, zeroed again below)
+            tc_memset_async(ctx, b.chain_ref, 0xff, (size_t)N * sizeof(u32));
+            chain_ref_kernel<<<tc_cdiv(mm, 256), 256, 0, s>>>(b.act[cur][0], b.act[cur][1], b.act[cur][2], b.isa, mm, hh, (u32)N, b.chain_ref);
+            TC_LAUNCH_CHECK(ctx);
+            u32 fgrid = tc_cdiv(nwords, 4);
+            if (fgrid > 16384) fgrid = 16384;
+            chain_flags_kernel<<<fgrid, 256, 0, s>>>(b.isa, b.chain_ref, (u32)N, hh, pathbits, signbits, nwords);
+            TC_LAUNCH_CHECK(ctx);
+            const u32 cgrid = (u32)tc_cdiv((u64)cd.nb * cd.h, 256);
+            if (cd.nb > 1) {
+                chain_scan_a_kernel<<<cgrid, 256, 0, s>>>(pathbits, signbits, cd, b.chain_summ);
+                TC_LAUNCH_CHECK(ctx);
+                chain_scan_b_kernel<<<tc_cdiv(cd.h, 256), 256, 0, s>>>(b.chain_summ, cd);
+                TC_LAUNCH_CHECK(ctx);
+            }
+            chain_scan_c_kernel<<<cgrid, 256, 0, s>>>(pathbits, signbits, cd, b.chain_summ, b.chain_code);
+            TC_LAUNCH_CHECK(ctx);
+            keymode = 1;
+            st.chain_rounds++;
+            trace("chain round: codes", N);
+        }
+        if (keymode == 1) {
+            chain_key1_kernel<<<tc_cdiv(mm, 256), 256, 0, s>>>(b.act[cur][1], b.act[cur][2], b.chain_code, mm, k2, kv);
+        } else if (keymode == 2) {
+            chain_key2_kernel<<<tc_cdiv(mm, 256), 256, 0, s>>>(b.act[cur][1], b.act[cur][2], b.chain_code, b.isa, mm, hh, (u32)N, k2, kv);
+        } else {
             // one lookup per thread for small sets (latency-bound); coarser when histograms are kept
             u32 kgrid = fuse_hist ? tc_cdiv(mm, 256 * 8) : tc_cdiv(mm, 256);
             if (fuse_hist && kgrid > 8192) kgrid = 8192;
@@ -1030,7 +1075,7 @@ static void sa_run(tc_ctx *ctx, SaBuffers &b, const u8 *d_text, u64 n, u32 *d_sa
                 seg_iota_kernel<<<tc_cdiv(mm, 256), 256, 0, s>>>(kv, mm);
                 TC_LAUNCH_CHECK(ctx);
             }
-            seg_sort_pairs(ctx, b.seg, k2, kv, k2alt, kvalt, mm, rbits);
+            seg_sort_pairs(ctx, b.seg, k2, kv, k2alt, kvalt, mm, keymode == 1 ? 32 : rbits);
             st.seg_rounds++;
         } else {
             radix_sort_pairs(ctx, r2, mm, p2, /*gen_idx=*/!vals_idx, /*hist_ready=*/fuse_hist);
@@ -1054,7 +1099,12 @@ static void sa_run(tc_ctx *ctx, SaBuffers &b, const u8 *d_text, u64 n, u32 *d_sa
         m = fetch_m();
         trace("round: groups", mm);
         cur ^= 1;
-        h *= 2;
+        if (keymode == 1) keymode = 2;   // (the second pass of a chain round: same h)
+        else {
+            prev_mm = keymode == 2 ? 0 : mm;
+            keymode = 0;
+            h *= 2;
+        }
     }
     primary_kernel<<<1, 64, 0, s>>>(rl, ctx->d_scalars);
     TC_LAUNCH_CHECK(ctx);

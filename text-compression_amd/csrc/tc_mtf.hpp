@@ -318,10 +318,10 @@ __device__ __forceinline__ NibSumm nib_block_excl(NibSumm mine, NibSumm *s_w, Ni
 #define MTF_BACK_MAX 8192
 #endif
 #ifndef MTF_BACK_FAR
-#define MTF_BACK_FAR (1u << 21)
+#define MTF_BACK_FAR (1u << 19)
 #endif
 template <class Acc>
-__device__ __forceinline__ bool nib_list_before(Acc acc, u64 pos, u32 sigma, const u8 *s_lut, u64 *out) {
+__device__ __forceinline__ bool nib_list_before(Acc acc, u64 pos, u32 sigma, const u8 *s_lut, u64 *out, const u32 *giveup = nullptr) {
     u32 seen = 0;          // bit c set: code c already placed
     u64 list = 0;          // placed codes, most recent first
     u32 placed = 0;
@@ -349,23 +349,29 @@ __device__ __forceinline__ bool nib_list_before(Acc acc, u64 pos, u32 sigma, con
     };
     for (u32 step = 0; step < MTF_BACK_MAX / 64 && p > 0 && __popc(all & ~seen) > 1; step++) step64();
     // Still open after MTF_BACK_MAX positions: the column has long runs here (repeat-rich or periodic text: a poly-A tract
-    // puts tens of thousands of equal symbols side by side).  Such stretches are SKIPPED 256 positions at a time -- a
-    // lane looks at 4 bytes and only says whether any of them is a code still missing -- and only a block that holds
+    // puts tens of thousands of equal symbols side by side).  Such stretches are SKIPPED 1024 positions at a time -- a
+    // lane looks at 16 bytes and only says whether any of them is a code still missing -- and only a block that holds
     // one is walked 64 positions at a time.  (Round 4: repeat-rich DNA used to fail here and rerun MTF by the
     // three-kernel path: 5.4 instead of 1.9 ms per GiB.)  A last column with its byte array only; bounded by
-    // MTF_BACK_FAR positions (a text of one letter never gets here: one missing code ends the walk).
+    // MTF_BACK_FAR positions (a text of one letter never gets here: one missing code ends the walk).  The bound is
+    // what a tile may spend: on a text of period 4096 (runs of n / 4096 equal symbols in the last column) every tile of
+    // the 1 GiB record walked back over a million positions, 256 at a time -- 218 ms of MTF; now the walk gives up after
+    // 2^19 positions, at once when another tile already has (`giveup`: the caller's flag -- the kernel's result is void
+    // then), and the record takes the three-kernel path.
     if constexpr (std::is_same<Acc, BwtAcc>::value) {
-        for (u32 far = 0; far < MTF_BACK_FAR / 256 && p >= 256 && (p & 3) == 0 && __popc(all & ~seen) > 1; far++) {
-            const u64 lo = p - 256;
+        for (u32 far = 0; far < MTF_BACK_FAR / 1024 && p >= 1024 && (p & 15) == 0 && __popc(all & ~seen) > 1; far++) {
+            if (giveup && (far & 15) == 0 && __atomic_load_n(giveup, __ATOMIC_RELAXED) != 0u) return false;
+            const u64 lo = p - 1024;
             const bool has_primary = acc.primary >= (i64)lo && acc.primary < (i64)p;
             bool any = true;
-            if (!has_primary && (((uintptr_t)acc.L) & 3) == 0) {   // (a lane looks at 4 bytes: few registers -- these kernels are tight)
-                const u32 x = *reinterpret_cast<const u32 *>(acc.L + lo + 4 * lane_id());
+            if (!has_primary && (((uintptr_t)acc.L) & 15) == 0) {
+                const uint4 x4 = *reinterpret_cast<const uint4 *>(acc.L + lo + 16 * lane_id());
+                const u32 xs[4] = {x4.x, x4.y, x4.z, x4.w};
                 const u32 todo = all & ~seen;
                 u32 hit = 0;
 #pragma unroll
-                for (int q = 0; q < 4; q++) {
-                    const u32 c = (u32)s_lut[((x >> (8 * q)) & 255u) + 1u];
+                for (int q = 0; q < 16; q++) {
+                    const u32 c = (u32)s_lut[((xs[q >> 2] >> (8 * (q & 3))) & 255u) + 1u];
                     hit |= c < 16u ? (todo >> c) & 1u : 0u;
                 }
                 any = __ballot(hit != 0) != 0ull;
@@ -374,7 +380,7 @@ __device__ __forceinline__ bool nib_list_before(Acc acc, u64 pos, u32 sigma, con
                 p = lo;
                 continue;
             }
-            for (int sub = 0; sub < 4 && __popc(all & ~seen) > 1; sub++) step64();
+            for (int sub = 0; sub < 16 && __popc(all & ~seen) > 1; sub++) step64();
         }
     }
     u32 rest = all & ~seen;
@@ -500,7 +506,7 @@ __global__ __launch_bounds__(MTF_NT) void mtf_nib_apply_kernel(Acc acc, u64 N,
     auto list_in = [&]() {
         if (FASTIN && threadIdx.x < 64) {
             u64 l0 = NIB_IDENT;
-            bool ok = nib_list_before(acc, base, sigma, s_lut, &l0);
+            bool ok = nib_list_before(acc, base, sigma, s_lut, &l0, flag);
             if (threadIdx.x == 0) {
                 s_in = l0;
                 if (!ok) atomicOr(flag, 1u);

@@ -746,7 +746,7 @@ __global__ __launch_bounds__(MTF_NT) void mtf_rle_kernel(MtfRleArgs a) {
         if (tid == 0 && base + MTF_TILE < N) nsym = (u32)(a.acc(base + MTF_TILE) + 1);
         if (tid < 64) {
             u64 l0 = NIB_IDENT;
-            const bool ok = nib_list_before(a.acc, base, a.sigma, s_lut, &l0);
+            const bool ok = nib_list_before(a.acc, base, a.sigma, s_lut, &l0, a.flag);
             if (tid == 0) {
                 s_in = l0;
                 if (!ok) atomicOr(a.flag, 1u);

@@ -37,7 +37,7 @@ class Stats(C.Structure):
                 ("keygen_fused", C.c_uint32), ("finish_pass", C.c_uint32),
                 ("sample_dups", C.c_uint32), ("msd_path", C.c_uint32), ("msd_keyonly", C.c_uint32),
                 ("ticket_fallbacks", C.c_uint32), ("ws_chunks", C.c_uint32), ("ws_grown", C.c_uint32),
-                ("seg_rounds", C.c_uint32), ("reserved0", C.c_uint32)]
+                ("seg_rounds", C.c_uint32), ("chain_rounds", C.c_uint32)]
 
 
 class Block(C.Structure):
