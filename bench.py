@@ -257,7 +257,8 @@ def classes_leg(ctx, lib, torch, n=1 << 28):
     """Away from iid ACGTN, after the timed region: four records of 2^28 bytes from the device-side generators
     (tc_generate_dev kinds 2 .. 5: repeat-rich DNA, Zipf-distributed words, runs, a 4 KiB block repeated), each
     encoded twice by the same call as the headline (tc_encode_dev; best of the two), decoded, and compared with the
-    text on the device.  `rounds` / `m` are the prefix-doubling rounds and their tied sets (tc_stats)."""
+    text on the device.  `rounds` / `m` are the prefix-doubling rounds and their tied sets (tc_stats); `chain_rounds`: how many
+    of them ran as chain rounds (tc_chain.hpp: the periodic record is done in 3 rounds instead of 25)."""
     from textcomp import Block
     cap = n + 2
     d_text = torch.empty(n, dtype=torch.uint8, device="cuda")
@@ -286,7 +287,7 @@ def classes_leg(ctx, lib, torch, n=1 << 28):
                 dec.append(time.perf_counter() - t0)
                 assert rc == 0, "decode rc=%d: %s" % (rc, lib.tc_last_error(ctx.handle).decode())
             res[name] = {"kind": kind, "seed": seed, "encode_ms": round(min(enc) * 1e3, 2), "encode_MBps": round(n / min(enc) / 1e6, 1),
-                         "decode_ms": round(min(dec) * 1e3, 2), "rounds": int(st.rounds),
+                         "decode_ms": round(min(dec) * 1e3, 2), "rounds": int(st.rounds), "chain_rounds": int(st.chain_rounds),
                          "m": [int(st.m[i]) for i in range(min(int(st.rounds), 6))], "sigma": int(blk.sigma), "runs": int(blk.nruns),
                          "round_trip_exact": bool(torch.equal(d_out, d_text))}
         except Exception as e:   # noqa: BLE001
