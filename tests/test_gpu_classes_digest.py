@@ -82,8 +82,8 @@ def test_class_digest_equals_oracle(ctx, key):
         if d["class"] in ("zipf_words", "genome_like"):
             assert st.msd_path == 0 and st.rounds >= 2
         if d["class"] == "dev_periodic":
-            # round 4: round 0 leaves all but a few suffixes tied -> the first doubling round is a CHAIN round (tc_chain.hpp) and
-            # the record is done in 3 rounds instead of log2(n / 21) + 2; the same record with the chain rounds off, same digest
+            # round 4: the first doubling round sheds next to nothing -> the second one is a CHAIN round (tc_chain.hpp) and
+            # the record is done in 3-4 rounds instead of log2(n / 21) + 2; the same record with the chain rounds off, same digest
             assert st.chain_rounds >= 1 and st.rounds <= 6, (st.chain_rounds, st.rounds)
             os.environ["TC_SA_CHAIN"] = "0"
             try:

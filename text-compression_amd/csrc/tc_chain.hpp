@@ -185,6 +185,26 @@ __global__ __launch_bounds__(256) void chain_scan_c_kernel(const u64 *__restrict
     }
 }
 
+// TC_SA_TRACE: what the chain tables look like -- [0] tied positions (ref known), [1] of them on path, [2] codes with k = 0,
+// [3] the largest k, [4] positions whose group's ref is the group itself
+__global__ __launch_bounds__(256) void chain_diag_kernel(const u32 *__restrict__ isa, const u32 *__restrict__ ref,
+                                                         const u64 *__restrict__ pathbits, const u32 *__restrict__ code, u32 N,
+                                                         unsigned long long *__restrict__ out) {
+    unsigned long long tied = 0, on = 0, k0 = 0, kmax = 0, self = 0;
+    for (u64 q = (u64)blockIdx.x * 256 + threadIdx.x; q < N; q += (u64)gridDim.x * 256) {
+        const u32 g = isa[q], r = ref[g];
+        if (r == CHAIN_NONE) continue;
+        tied++;
+        if ((pathbits[q >> 6] >> (q & 63)) & 1ull) on++;
+        const u32 cd = code[q];
+        const u32 k = (cd >> 31) ? ~cd : cd;
+        if (k == 0) k0++;
+        if (k > kmax) kmax = k;
+        if (r == g) self++;
+    }
+    atomicAdd(&out[0], tied); atomicAdd(&out[1], on); atomicAdd(&out[2], k0); atomicMax(&out[3], kmax); atomicAdd(&out[4], self);
+}
+
 // pass 1: key2 = group << 32 | code of the member's position
 __global__ __launch_bounds__(256) void chain_key1_kernel(const u32 *__restrict__ idx, const u32 *__restrict__ grp,
                                                          const u32 *__restrict__ code, u32 m, u64 *__restrict__ keys,

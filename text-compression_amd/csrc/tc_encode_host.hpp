@@ -987,8 +987,12 @@ static void sa_run(tc_ctx *ctx, SaBuffers &b, const u8 *d_text, u64 n, u32 *d_sa
     u64 h = h_start;
     // chain rounds (tc_chain.hpp): when a dense round sheds next to nothing (periodic text) the next one orders every group
     // by how long its members keep seeing the same thing at + h, + 2 h, .. -- two passes of the same sort at one h.
-    // TC_SA_CHAIN: 0 never, 1 (default) after a round that resolved < 1/256 of a set of >= 2^20 members -- or at once when round 0
-    // left fewer than N / 4096 suffixes untied --, 2 every dense round
+    // TC_SA_CHAIN: 0 never, 1 (default) after a PLAIN round that resolved < 1/256 of a set of >= 2^20 members, 2 every dense round.
+    // (Not in the very first doubling round, however few suffixes round 0 resolved: a chain is cut wherever two residue classes
+    // of the period share their h symbols -- members of the merged group see two different ranks at + h, one of them is not the
+    // reference -- and the cut repeats with the period, so all members of a class get the SAME k.  One such coincidence in a
+    // 1 MiB period at h = 21 left 97 % of a 1 GiB record tied after the chain round; a plain round first splits the merged
+    // groups, and 2 h symbols rarely coincide: chain round at 42 -> everything resolved.)
     const int chain_env = env_int("TC_SA_CHAIN", 1);
     int keymode = 0;      // 0: key2 = rank[i + h]; 1: the chain code; 2: the rank the member's terminal sees
     u64 prev_mm = 0;      // members of the last plain doubling round (0: none yet, or a chain round came since)
@@ -1024,8 +1028,7 @@ static void sa_run(tc_ctx *ctx, SaBuffers &b, const u8 *d_text, u64 n, u32 *d_sa
         const bool vals_idx = dense;
         if (fuse_hist) tc_memset_async(ctx, b.hist, 0, sizeof(u32) * RDX_MAX_PASSES * RDX_BINS);
         if (keymode == 0 && dense && seg_round && hh >= 4 && h < N && chain_env != 0 &&
-            (chain_env == 2 || (mm >= (1u << 20) && ((prev_mm > 0 && (prev_mm - m) * 256 < prev_mm) ||
-                                                      (st.rounds == 1 && (N - m) * 4096 < N))))) {   // (or round 0 left all but a few tied)
+            (chain_env == 2 || (mm >= (1u << 20) && prev_mm > 0 && (prev_mm - m) * 256 < prev_mm))) {
             // reference ranks, on-path / sign bits of every position, their scan along stride h -> a code per position
             const ChainDims cd = chain_dims(N, hh);
             const u32 nwords = (u32)(N / 64 + 1);
@@ -1049,6 +1052,17 @@ static void sa_run(tc_ctx *ctx, SaBuffers &b, const u8 *d_text, u64 n, u32 *d_sa
             keymode = 1;
             st.chain_rounds++;
             trace("chain round: codes", N);
+            if (trace_on) {
+                unsigned long long *dg = reinterpret_cast<unsigned long long *>(b.hist);
+                tc_memset_async(ctx, dg, 0, 8 * sizeof(u64));
+                chain_diag_kernel<<<4096, 256, 0, s>>>(b.isa, b.chain_ref, pathbits, b.chain_code, (u32)N, dg);
+                u64 hd[8];
+                tc_d2h(ctx, hd, dg, sizeof hd);
+                (void)hipStreamSynchronize(s);
+                fprintf(stderr, "textcomp:   chain tables (h = %u, %u x %u cells of %u rows): tied positions %llu, on path %llu, k = 0: %llu, largest k %llu, groups referring to themselves: %llu positions\n",
+                        hh, cd.nb, cd.h, cd.bk, (unsigned long long)hd[0], (unsigned long long)hd[1], (unsigned long long)hd[2], (unsigned long long)hd[3], (unsigned long long)hd[4]);
+                trace_t0 = std::chrono::steady_clock::now();
+            }
         }
         if (keymode == 1) {
             chain_key1_kernel<<<tc_cdiv(mm, 256), 256, 0, s>>>(b.act[cur][1], b.act[cur][2], b.chain_code, mm, k2, kv);
