@@ -91,8 +91,8 @@ typedef struct tc_stats {
     uint32_t ws_chunks;              /* physical chunks the context's workspace is mapped from (0: one hipMalloc block) */
     uint32_t ws_grown;               /* how often that workspace grew in place (more chunks mapped; cumulative per ctx) */
     uint32_t seg_rounds;             /* doubling rounds whose sort was the segmented one (tc_seg.hpp), last suffix sort */
-    uint32_t chain_rounds;           /* doubling rounds run as chain rounds (tc_chain.hpp: periodic text), last suffix sort; each is two
-                                        entries of m[] / h[] at one h (was reserved0: same layout) */
+    uint32_t chain_rounds;           /* doubling rounds run as chain rounds (tc_chain.hpp: periodic text), last suffix sort; each is ONE
+                                        entry of m[] / h[] with passes[] = 2 (was reserved0: same layout) */
 } tc_stats;
 
 /* The encoded block of the fused BWT -> MTF -> RLE pipeline.  The reference has

@@ -1107,9 +1107,13 @@ static void sa_run(tc_ctx *ctx, SaBuffers &b, const u8 *d_text, u64 n, u32 *d_sa
         if (gr_pairs) gr.pairs = r2.keys_alt;
         run_group(false, gr, sa);
         if (gr_pairs) apply_pairs(r2.keys_alt, mm, r2.keys);
-        st.m[st.rounds] = m; st.key_bytes[st.rounds] = 8; st.passes[st.rounds] = seg_round ? 1u : (u32)p2.npass;
-        st.h[st.rounds] = hh;
-        st.rounds++;
+        if (keymode != 2) {   // (a chain round is ONE entry -- its first pass's: every entry is a doubling of h, so the rounds stay <= 32)
+            st.m[st.rounds] = m; st.key_bytes[st.rounds] = 8; st.passes[st.rounds] = seg_round ? 1u : (u32)p2.npass;
+            st.h[st.rounds] = hh;
+            st.rounds++;
+        } else {
+            st.passes[st.rounds - 1]++;
+        }
         m = fetch_m();
         trace("round: groups", mm);
         cur ^= 1;
