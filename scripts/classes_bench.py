@@ -78,7 +78,15 @@ classes = {
     "repeat_1MiB": lambda: repeat(1 << 20),
     "repeat_4KiB": lambda: repeat(1 << 12),
     "all_A": lambda: torch.full((n,), 65, dtype=torch.uint8, device="cuda"),
+    "acgt_nrun": lambda: nrun(),      # an assembly with gaps: iid ACGT, one run of n / 64 'N's and sixteen of n / 4096
 }
+def nrun():
+    t = torch.tensor([65, 67, 71, 84], dtype=torch.uint8, device="cuda")[rnd(4, 0).long()]
+    t[n // 3:n // 3 + n // 64] = 78
+    for i in range(16):
+        a = (2 * i + 1) * (n // 40)
+        t[a:a + n // 4096] = 78
+    return t.contiguous()
 cap = n + 2
 d_cnt = torch.empty(cap, dtype=torch.int32, device="cuda"); d_val = torch.empty(cap, dtype=torch.int16, device="cuda")
 d_out = torch.empty(n, dtype=torch.uint8, device="cuda")
