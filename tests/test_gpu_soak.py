@@ -29,6 +29,10 @@ SLICES = [
     ("fuzz_chain.py", ["150", "112", "30000"], {"TC_SA_CHAIN": "2", "TC_SA_DENSE": "1", "TC_SA_SEG_MIN": "1"}),
     ("fuzz_chain.py", ["80", "113", "120000"], {"TC_SA_CHAIN": "2", "TC_SA_DENSE": "1", "TC_SA_SEG_MIN": "1", "TC_SA_BIN_MIN_LOG2": "0"}),
     ("fuzz_long.py", ["60", "114", "60000"], {"TC_SA_CHAIN": "2", "TC_SA_DENSE": "1", "TC_SA_SEG_MIN": "1"}),
+    # ... and with SPARSE ranks (flags from the members through the rank table / the sorted keys; row blocks without a
+    # position on path skipped), also behind the MSD round 0
+    ("fuzz_chain.py", ["120", "115", "60000"], {"TC_SA_CHAIN": "2", "TC_SA_SEG_MIN": "1", "TC_SA_ACCEL_MIN": "1"}),
+    ("fuzz_long.py", ["60", "116", "200000"], {"TC_SA_CHAIN": "2", "TC_SA_SEG_MIN": "1", "TC_SA_MSD": "2", "TC_SA_MSD_MIN_LOG2": "10"}),
     ("fuzz_raw.py", ["150", "106"], {}),
     ("fuzz_raw.py", ["100", "107"], {"TC_MTF_TS": "2"}),
     ("fuzz_fm.py", ["60", "108"], {}),

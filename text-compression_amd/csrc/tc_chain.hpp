@@ -21,9 +21,12 @@
 // (chain_flags_kernel: streaming over the dense rank array + one gather of ref), then a three-phase scan over the
 // (row block, column) grid of the N / h x h matrix of positions: block summaries (A), their scan down every column (B),
 // the codes (C).  Both sorts are the segmented sort of the ordinary rounds (tc_seg.hpp), the groups group_kernel<REFINE>.
-// Dense ranks only (a text that ties nearly everything); chosen by the host when a round shed next to nothing.
+// Dense ranks (a text that ties nearly everything: flags from the rank array) and sparse ranks (a periodic stretch, a long run
+// of one symbol inside a larger text: flags from the members through rank_of; row blocks without a position on path are
+// skipped); chosen by the host when a plain round shed next to nothing.
 #pragma once
 #include "tc_common.hpp"
+#include "tc_sa.hpp"   // RankLookup, rank_of
 
 #define CHAIN_NONE 0xffffffffu
 #define CHAIN_THREADS_LOG2 18     // (row block, column) cells the scan is cut into, about
@@ -46,8 +49,10 @@ static inline ChainDims chain_dims(u64 N, u64 h) {
     d.nb = (u32)((d.rows + d.bk - 1) / d.bk);
     return d;
 }
-// words of the block summaries (nb * h <= 2^18 + h < 2^19 whenever nb > 1)
-static inline size_t chain_summ_words() { return ((size_t)2 << CHAIN_THREADS_LOG2) + 64; }
+// words of the block summaries (nb * h <= 2^18 + h < 2^19 whenever nb > 1), then one word per row block (nb <= 2^18):
+// does the block hold a position that is on path at all
+static inline size_t chain_any_offset() { return ((size_t)2 << CHAIN_THREADS_LOG2) + 64; }
+static inline size_t chain_summ_words() { return chain_any_offset() + ((size_t)1 << CHAIN_THREADS_LOG2) + 64; }
 
 #ifdef __HIPCC__
 
@@ -56,16 +61,18 @@ static inline size_t chain_summ_words() { return ((size_t)2 << CHAIN_THREADS_LOG
 // so the last member is the one nearest the end of the text, the very one that deviates on periodic text.)  The members
 // of a group are contiguous in the active set and fill the group's slots: its size is the last member's slot - head + 1.
 __global__ __launch_bounds__(256) void chain_ref_kernel(const u32 *__restrict__ slot, const u32 *__restrict__ idx,
-                                                        const u32 *__restrict__ grp, const u32 *__restrict__ isa, u32 m, u32 h,
-                                                        u32 N, u32 *__restrict__ ref) {
+                                                        const u32 *__restrict__ grp, RankLookup r, u32 m, u32 h,
+                                                        u32 *__restrict__ ref) {
+    __shared__ u16 s_lut[256];
+    s_lut[threadIdx.x] = r.lut[threadIdx.x];
+    __syncthreads();
     const u64 k = (u64)blockIdx.x * 256 + threadIdx.x;
     if (k >= m) return;
     const u32 g = grp[k];
     if (k + 1 < m && grp[k + 1] == g) return;
     u32 size = slot[k] - g + 1u;
     if ((u64)size > k + 1) size = (u32)(k + 1);   // (cannot happen while the invariant above holds)
-    const u64 p = (u64)idx[k - size / 2] + h;
-    ref[g] = p < N ? isa[p] : 0u;
+    ref[g] = rank_of(r, s_lut, (u64)idx[k - size / 2] + h);
 }
 
 // on-path / sign bits of every position (one 64-bit word per wave and turn)
@@ -89,6 +96,46 @@ __global__ __launch_bounds__(256) void chain_flags_kernel(const u32 *__restrict_
             signbits[w] = bs;
         }
     }
+}
+
+// the same bits from the MEMBERS (sparse ranks: the tied set is a small part of the text, and the rank of a position comes
+// through the rank table / the sorted keys -- rank_of): every member's position gets its bits by atomicOr into zeroed bitmaps
+__global__ __launch_bounds__(256) void chain_flags_members_kernel(const u32 *__restrict__ idx, const u32 *__restrict__ grp,
+                                                                  RankLookup r, u32 m, u32 h, const u32 *__restrict__ ref,
+                                                                  u64 *__restrict__ pathbits, u64 *__restrict__ signbits) {
+    __shared__ u16 s_lut[256];
+    s_lut[threadIdx.x] = r.lut[threadIdx.x];
+    __syncthreads();
+    for (u64 k = (u64)blockIdx.x * 256 + threadIdx.x; k < m; k += (u64)gridDim.x * 256) {
+        const u32 i = idx[k];
+        const u32 rf = ref[grp[k]];
+        if (rf == CHAIN_NONE) continue;   // (every group of the set has one)
+        const u32 nxt = rank_of(r, s_lut, (u64)i + h);
+        if (nxt == rf) atomicOr((unsigned long long *)&pathbits[i >> 6], 1ull << (i & 63));
+        else if (nxt > rf) atomicOr((unsigned long long *)&signbits[i >> 6], 1ull << (i & 63));
+    }
+}
+
+// any[b]: does row block b (positions [b * bk * h, (b + 1) * bk * h)) hold a position on path?  A block without one is
+// all terminals: its summaries are known and none of its positions needs a code (k = 0: the sign bit alone)
+__global__ __launch_bounds__(256) void chain_blockany_kernel(const u64 *__restrict__ pathbits, ChainDims d, u32 *__restrict__ any) {
+    __shared__ u32 s_any;
+    const u32 b = blockIdx.x;
+    if (threadIdx.x == 0) s_any = 0;
+    __syncthreads();
+    const u64 p0 = (u64)b * d.bk * d.h;
+    u64 p1 = p0 + (u64)d.bk * d.h;
+    if (p1 > d.N) p1 = d.N;
+    u64 acc = 0;
+    for (u64 w = (p0 >> 6) + threadIdx.x; w <= ((p1 - 1) >> 6); w += 256) {
+        u64 x = pathbits[w];
+        if (w == (p0 >> 6)) x &= ~0ull << (p0 & 63);
+        if (w == ((p1 - 1) >> 6) && ((p1 & 63) != 0)) x &= (1ull << (p1 & 63)) - 1ull;
+        acc |= x;
+    }
+    if (acc) atomicOr(&s_any, 1u);
+    __syncthreads();
+    if (threadIdx.x == 0) any[b] = s_any;
 }
 
 // state of a walk up a column: k on-path steps seen, s the terminal's sign; `thru`: no terminal met yet in this block
@@ -118,10 +165,15 @@ __device__ __forceinline__ void chain_fetch4(const u64 *__restrict__ pathbits, c
 
 // phase A: summary of block b of column c -- walked from its last row up to its first
 __global__ __launch_bounds__(256) void chain_scan_a_kernel(const u64 *__restrict__ pathbits, const u64 *__restrict__ signbits,
-                                                           ChainDims d, u32 *__restrict__ summ) {
+                                                           ChainDims d, const u32 *__restrict__ any, u32 *__restrict__ summ) {
     const u64 t = (u64)blockIdx.x * 256 + threadIdx.x;
     if (t >= (u64)d.nb * d.h) return;
     const u32 b = (u32)(t / d.h), c = (u32)(t - (u64)b * d.h);
+    if (!any[b]) {   // (all terminals: what the block hands upwards is its first row's cell -- k = 0 and that cell's sign)
+        const u64 q0 = (u64)b * d.bk * d.h + c;
+        summ[t] = chain_pack(false, q0 < d.N && chain_bit(signbits, q0) ? 1u : 0u, 0);
+        return;
+    }
     const u32 row0 = b * d.bk;
     const u32 row1 = row0 + d.bk < d.rows ? row0 + d.bk : d.rows;
     bool thru = true;
@@ -157,10 +209,12 @@ __global__ __launch_bounds__(256) void chain_scan_b_kernel(u32 *__restrict__ sum
 
 // phase C: the codes -- s = 0: k, s = 1: 0xffffffff - k
 __global__ __launch_bounds__(256) void chain_scan_c_kernel(const u64 *__restrict__ pathbits, const u64 *__restrict__ signbits,
-                                                           ChainDims d, const u32 *__restrict__ summ, u32 *__restrict__ code) {
+                                                           ChainDims d, const u32 *__restrict__ any, const u32 *__restrict__ summ,
+                                                           u32 *__restrict__ code) {
     const u64 t = (u64)blockIdx.x * 256 + threadIdx.x;
     if (t >= (u64)d.nb * d.h) return;
     const u32 b = (u32)(t / d.h), c = (u32)(t - (u64)b * d.h);
+    if (!any[b]) return;   // (no position of the block is on path: their codes are their sign bits -- chain_code_of)
     const u32 row0 = b * d.bk;
     const u32 row1 = row0 + d.bk < d.rows ? row0 + d.bk : d.rows;
     u32 k = 0, s = 0;
@@ -185,49 +239,57 @@ __global__ __launch_bounds__(256) void chain_scan_c_kernel(const u64 *__restrict
     }
 }
 
-// TC_SA_TRACE: what the chain tables look like -- [0] tied positions (ref known), [1] of them on path, [2] codes with k = 0,
-// [3] the largest k, [4] positions whose group's ref is the group itself
-__global__ __launch_bounds__(256) void chain_diag_kernel(const u32 *__restrict__ isa, const u32 *__restrict__ ref,
-                                                         const u64 *__restrict__ pathbits, const u32 *__restrict__ code, u32 N,
-                                                         unsigned long long *__restrict__ out) {
-    unsigned long long tied = 0, on = 0, k0 = 0, kmax = 0, self = 0;
-    for (u64 q = (u64)blockIdx.x * 256 + threadIdx.x; q < N; q += (u64)gridDim.x * 256) {
-        const u32 g = isa[q], r = ref[g];
-        if (r == CHAIN_NONE) continue;
-        tied++;
-        if ((pathbits[q >> 6] >> (q & 63)) & 1ull) on++;
-        const u32 cd = code[q];
+// the code of position i: from the table when i is on path (its block has been walked), else k = 0 and the sign bit
+__device__ __forceinline__ u32 chain_code_of(const u64 *__restrict__ pathbits, const u64 *__restrict__ signbits,
+                                             const u32 *__restrict__ code, u32 i) {
+    if ((pathbits[i >> 6] >> (i & 63)) & 1ull) return code[i];
+    return ((signbits[i >> 6] >> (i & 63)) & 1ull) ? 0xffffffffu : 0u;
+}
+
+// TC_SA_TRACE: what the chain tables look like over the members -- [0] on path, [1] k = 0, [2] the largest k, [3] members whose
+// group refers to itself
+__global__ __launch_bounds__(256) void chain_diag_kernel(const u32 *__restrict__ idx, const u32 *__restrict__ grp, u32 m,
+                                                         const u64 *__restrict__ pathbits, const u64 *__restrict__ signbits,
+                                                         const u32 *__restrict__ code, unsigned long long *__restrict__ out) {
+    unsigned long long on = 0, k0 = 0, kmax = 0;
+    for (u64 j = (u64)blockIdx.x * 256 + threadIdx.x; j < m; j += (u64)gridDim.x * 256) {
+        const u32 i = idx[j];
+        if ((pathbits[i >> 6] >> (i & 63)) & 1ull) on++;
+        const u32 cd = chain_code_of(pathbits, signbits, code, i);
         const u32 k = (cd >> 31) ? ~cd : cd;
         if (k == 0) k0++;
         if (k > kmax) kmax = k;
-        if (r == g) self++;
     }
-    atomicAdd(&out[0], tied); atomicAdd(&out[1], on); atomicAdd(&out[2], k0); atomicMax(&out[3], kmax); atomicAdd(&out[4], self);
+    atomicAdd(&out[0], on); atomicAdd(&out[1], k0); atomicMax(&out[2], kmax);
 }
 
-// pass 1: key2 = group << 32 | code of the member's position
+// pass 1: key2 = group << 32 | code of the member's position (vals_out: the suffix start sorted along -- dense ranks only)
 __global__ __launch_bounds__(256) void chain_key1_kernel(const u32 *__restrict__ idx, const u32 *__restrict__ grp,
+                                                         const u64 *__restrict__ pathbits, const u64 *__restrict__ signbits,
                                                          const u32 *__restrict__ code, u32 m, u64 *__restrict__ keys,
                                                          u32 *__restrict__ vals_out) {
     const u64 k = (u64)blockIdx.x * 256 + threadIdx.x;
     if (k >= m) return;
     const u32 i = idx[k];
-    keys[k] = ((u64)grp[k] << 32) | code[i];
-    vals_out[k] = i;
+    keys[k] = ((u64)grp[k] << 32) | chain_code_of(pathbits, signbits, code, i);
+    if (vals_out) vals_out[k] = i;
 }
 
 // pass 2: key2 = group << 32 | the rank the member's terminal sees: rank[i + (k + 1) h]
 __global__ __launch_bounds__(256) void chain_key2_kernel(const u32 *__restrict__ idx, const u32 *__restrict__ grp,
-                                                         const u32 *__restrict__ code, const u32 *__restrict__ isa, u32 m,
-                                                         u32 h, u32 N, u64 *__restrict__ keys, u32 *__restrict__ vals_out) {
-    const u64 k = (u64)blockIdx.x * 256 + threadIdx.x;
-    if (k >= m) return;
-    const u32 i = idx[k];
-    const u32 cd = code[i];
-    const u32 steps = (cd >> 31) ? ~cd : cd;
-    const u64 p = (u64)i + ((u64)steps + 1) * h;
-    keys[k] = ((u64)grp[k] << 32) | (p < N ? isa[p] : 0u);
-    vals_out[k] = i;
+                                                         const u64 *__restrict__ pathbits, const u64 *__restrict__ signbits,
+                                                         const u32 *__restrict__ code, RankLookup r, u32 m, u32 h,
+                                                         u64 *__restrict__ keys, u32 *__restrict__ vals_out) {
+    __shared__ u16 s_lut[256];
+    s_lut[threadIdx.x] = r.lut[threadIdx.x];
+    __syncthreads();
+    for (u64 k = (u64)blockIdx.x * 256 + threadIdx.x; k < m; k += (u64)gridDim.x * 256) {
+        const u32 i = idx[k];
+        const u32 cd = chain_code_of(pathbits, signbits, code, i);
+        const u32 steps = (cd >> 31) ? ~cd : cd;
+        keys[k] = ((u64)grp[k] << 32) | rank_of(r, s_lut, (u64)i + ((u64)steps + 1) * h);
+        if (vals_out) vals_out[k] = i;
+    }
 }
 
 #endif  // __HIPCC__

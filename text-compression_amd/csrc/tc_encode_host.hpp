@@ -985,9 +985,9 @@ static void sa_run(tc_ctx *ctx, SaBuffers &b, const u8 *d_text, u64 n, u32 *d_sa
     int cur = 0;
     if (env_int("TC_SA_H_START", 0) > 0) h_start = (u64)env_int("TC_SA_H_START", 0);  // experiments: any h <= sorted depth is valid
     u64 h = h_start;
-    // chain rounds (tc_chain.hpp): when a dense round sheds next to nothing (periodic text) the next one orders every group
+    // chain rounds (tc_chain.hpp): when a round sheds next to nothing (periodic text, a long run of one symbol) the next one orders every group
     // by how long its members keep seeing the same thing at + h, + 2 h, .. -- two passes of the same sort at one h.
-    // TC_SA_CHAIN: 0 never, 1 (default) after a PLAIN round that resolved < 1/256 of a set of >= 2^20 members, 2 every dense round.
+    // TC_SA_CHAIN: 0 never, 1 (default) after a PLAIN round that resolved < 1/256 of a set of >= 2^20 members, 2 every round.
     // (Not in the very first doubling round, however few suffixes round 0 resolved: a chain is cut wherever two residue classes
     // of the period share their h symbols -- members of the merged group see two different ranks at + h, one of them is not the
     // reference -- and the cut repeats with the period, so all members of a class get the SAME k.  One such coincidence in a
@@ -1027,27 +1027,43 @@ static void sa_run(tc_ctx *ctx, SaBuffers &b, const u8 *d_text, u64 n, u32 *d_sa
         const bool fuse_hist = mm >= (1u << 20) && !seg_round && keymode == 0;
         const bool vals_idx = dense;
         if (fuse_hist) tc_memset_async(ctx, b.hist, 0, sizeof(u32) * RDX_MAX_PASSES * RDX_BINS);
-        if (keymode == 0 && dense && seg_round && hh >= 4 && h < N && chain_env != 0 &&
+        // (both bitmaps are copied into the reference table's memory once the flags are made -- the table is dead by then --
+        // so that they survive the sort of pass 1: pass 2 asks again which members were on path)
+        const u32 chain_words = (u32)(N / 64 + 1);
+        u64 *chain_path = reinterpret_cast<u64 *>(b.chain_ref), *chain_sign = chain_path + chain_words;
+        if (keymode == 0 && seg_round && hh >= 4 && h < N && chain_env != 0 &&
             (chain_env == 2 || (mm >= (1u << 20) && prev_mm > 0 && (prev_mm - m) * 256 < prev_mm))) {
-            // reference ranks, on-path / sign bits of every position, their scan along stride h -> a code per position
+            // reference ranks, on-path / sign bits of every tied position, their scan along stride h -> a code per position
             const ChainDims cd = chain_dims(N, hh);
-            const u32 nwords = (u32)(N / 64 + 1);
-            u64 *pathbits = b.t_bits, *signbits = b.seg.ybits;   // (both free here: sparse-mode bitmap; the sort's, zeroed again below)
+            u64 *pathbits = b.seg.segbits, *signbits = b.seg.ybits;   // (free here: the sort writes them anew)
+            u32 *any = b.chain_summ + chain_any_offset();
             tc_memset_async(ctx, b.chain_ref, 0xff, (size_t)N * sizeof(u32));
-            chain_ref_kernel<<<tc_cdiv(mm, 256), 256, 0, s>>>(b.act[cur][0], b.act[cur][1], b.act[cur][2], b.isa, mm, hh, (u32)N, b.chain_ref);
+            chain_ref_kernel<<<tc_cdiv(mm, 256), 256, 0, s>>>(b.act[cur][0], b.act[cur][1], b.act[cur][2], rl, mm, hh, b.chain_ref);
             TC_LAUNCH_CHECK(ctx);
-            u32 fgrid = tc_cdiv(nwords, 4);
-            if (fgrid > 16384) fgrid = 16384;
-            chain_flags_kernel<<<fgrid, 256, 0, s>>>(b.isa, b.chain_ref, (u32)N, hh, pathbits, signbits, nwords);
+            if (dense) {
+                u32 fgrid = tc_cdiv(chain_words, 4);
+                if (fgrid > 16384) fgrid = 16384;
+                chain_flags_kernel<<<fgrid, 256, 0, s>>>(b.isa, b.chain_ref, (u32)N, hh, pathbits, signbits, chain_words);
+            } else {
+                tc_memset_async(ctx, pathbits, 0, (size_t)chain_words * sizeof(u64));
+                tc_memset_async(ctx, signbits, 0, (size_t)chain_words * sizeof(u64));
+                u32 fgrid = tc_cdiv(mm, 256);
+                if (fgrid > 16384) fgrid = 16384;
+                chain_flags_members_kernel<<<fgrid, 256, 0, s>>>(b.act[cur][1], b.act[cur][2], rl, mm, hh, b.chain_ref, pathbits, signbits);
+            }
+            TC_LAUNCH_CHECK(ctx);
+            TC_HIP(ctx, hipMemcpyAsync(chain_path, pathbits, (size_t)chain_words * sizeof(u64), hipMemcpyDeviceToDevice, s));
+            TC_HIP(ctx, hipMemcpyAsync(chain_sign, signbits, (size_t)chain_words * sizeof(u64), hipMemcpyDeviceToDevice, s));
+            chain_blockany_kernel<<<cd.nb, 256, 0, s>>>(chain_path, cd, any);
             TC_LAUNCH_CHECK(ctx);
             const u32 cgrid = (u32)tc_cdiv((u64)cd.nb * cd.h, 256);
             if (cd.nb > 1) {
-                chain_scan_a_kernel<<<cgrid, 256, 0, s>>>(pathbits, signbits, cd, b.chain_summ);
+                chain_scan_a_kernel<<<cgrid, 256, 0, s>>>(chain_path, chain_sign, cd, any, b.chain_summ);
                 TC_LAUNCH_CHECK(ctx);
                 chain_scan_b_kernel<<<tc_cdiv(cd.h, 256), 256, 0, s>>>(b.chain_summ, cd);
                 TC_LAUNCH_CHECK(ctx);
             }
-            chain_scan_c_kernel<<<cgrid, 256, 0, s>>>(pathbits, signbits, cd, b.chain_summ, b.chain_code);
+            chain_scan_c_kernel<<<cgrid, 256, 0, s>>>(chain_path, chain_sign, cd, any, b.chain_summ, b.chain_code);
             TC_LAUNCH_CHECK(ctx);
             keymode = 1;
             st.chain_rounds++;
@@ -1055,19 +1071,21 @@ static void sa_run(tc_ctx *ctx, SaBuffers &b, const u8 *d_text, u64 n, u32 *d_sa
             if (trace_on) {
                 unsigned long long *dg = reinterpret_cast<unsigned long long *>(b.hist);
                 tc_memset_async(ctx, dg, 0, 8 * sizeof(u64));
-                chain_diag_kernel<<<4096, 256, 0, s>>>(b.isa, b.chain_ref, pathbits, b.chain_code, (u32)N, dg);
+                chain_diag_kernel<<<4096, 256, 0, s>>>(b.act[cur][1], b.act[cur][2], mm, chain_path, chain_sign, b.chain_code, dg);
                 u64 hd[8];
                 tc_d2h(ctx, hd, dg, sizeof hd);
                 (void)hipStreamSynchronize(s);
-                fprintf(stderr, "textcomp:   chain tables (h = %u, %u x %u cells of %u rows): tied positions %llu, on path %llu, k = 0: %llu, largest k %llu, groups referring to themselves: %llu positions\n",
-                        hh, cd.nb, cd.h, cd.bk, (unsigned long long)hd[0], (unsigned long long)hd[1], (unsigned long long)hd[2], (unsigned long long)hd[3], (unsigned long long)hd[4]);
+                fprintf(stderr, "textcomp:   chain tables (h = %u, %u x %u cells of %u rows, %s ranks): members %u, on path %llu, k = 0: %llu, largest k %llu\n",
+                        hh, cd.nb, cd.h, cd.bk, dense ? "dense" : "sparse", mm, (unsigned long long)hd[0], (unsigned long long)hd[1], (unsigned long long)hd[2]);
                 trace_t0 = std::chrono::steady_clock::now();
             }
         }
         if (keymode == 1) {
-            chain_key1_kernel<<<tc_cdiv(mm, 256), 256, 0, s>>>(b.act[cur][1], b.act[cur][2], b.chain_code, mm, k2, kv);
+            chain_key1_kernel<<<tc_cdiv(mm, 256), 256, 0, s>>>(b.act[cur][1], b.act[cur][2], chain_path, chain_sign, b.chain_code, mm, k2, vals_idx ? kv : nullptr);
         } else if (keymode == 2) {
-            chain_key2_kernel<<<tc_cdiv(mm, 256), 256, 0, s>>>(b.act[cur][1], b.act[cur][2], b.chain_code, b.isa, mm, hh, (u32)N, k2, kv);
+            u32 kgrid = tc_cdiv(mm, 256);
+            if (kgrid > 65536) kgrid = 65536;
+            chain_key2_kernel<<<kgrid, 256, 0, s>>>(b.act[cur][1], b.act[cur][2], chain_path, chain_sign, b.chain_code, rl, mm, hh, k2, vals_idx ? kv : nullptr);
         } else {
             // one lookup per thread for small sets (latency-bound); coarser when histograms are kept
             u32 kgrid = fuse_hist ? tc_cdiv(mm, 256 * 8) : tc_cdiv(mm, 256);
