@@ -250,12 +250,14 @@ def host_path_leg(ctx, lib, torch, d_text, n, ms_step):
     return res
 
 
-CLASSES = (("genome_like", 2, 0x6E0E), ("zipf_words", 3, 0x21BF), ("runs_p0.9", 4, 0x9A75), ("repeat_4KiB", 5, 0x4B1B))
+CLASSES = (("genome_like", 2, 0x6E0E), ("zipf_words", 3, 0x21BF), ("runs_p0.9", 4, 0x9A75), ("repeat_4KiB", 5, 0x4B1B),
+           ("acgt_gaps", 6, 0x6A95))
 
 
 def classes_leg(ctx, lib, torch, n=1 << 28):
-    """Away from iid ACGTN, after the timed region: four records of 2^28 bytes from the device-side generators
-    (tc_generate_dev kinds 2 .. 5: repeat-rich DNA, Zipf-distributed words, runs, a 4 KiB block repeated), each
+    """Away from iid ACGTN, after the timed region: five records of 2^28 bytes from the device-side generators
+    (tc_generate_dev kinds 2 .. 6: repeat-rich DNA, Zipf-distributed words, runs, a 4 KiB block repeated, an assembly
+    with gaps -- iid ACGT with one run of n / 64 'N's and sixteen of n / 4096), each
     encoded twice by the same call as the headline (tc_encode_dev; best of the two), decoded, and compared with the
     text on the device.  `rounds` / `m` are the prefix-doubling rounds and their tied sets (tc_stats); `chain_rounds`: how many
     of them ran as chain rounds (tc_chain.hpp: the periodic record is done in 3 rounds instead of 25)."""

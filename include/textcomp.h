@@ -339,7 +339,8 @@ int tc_comm_broadcast(tc_comm *comm, int root, uint8_t *d_buf, uint64_t bytes);
 /* kind 0: iid ACGTN, kind 1: printable ASCII; the classes away from iid text that bench.py reports beside the headline
  * (round 4; every byte a function of (kind, seed, position) alone): 2 genome-like (iid ACGT with a 300-bp repeat family in
  * ~10 % of the sequence, poly-A tracts, (CA)n), 3 Zipf-distributed words of 2 .. 9 letters from a 20 000-word vocabulary,
- * 4 runs (a letter repeats with probability 0.9), 5 a 4096-byte block repeated.  d_out is a device pointer. */
+ * 4 runs (a letter repeats with probability 0.9), 5 a 4096-byte block repeated, 6 an assembly with gaps (iid ACGT, one run of
+ * n / 64 'N's and sixteen of n / 4096).  d_out is a device pointer. */
 int tc_generate_dev(tc_ctx *ctx, int kind, uint64_t seed, uint64_t n, uint8_t *d_out);
 
 #ifdef __cplusplus

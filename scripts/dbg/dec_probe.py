@@ -5,7 +5,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)
 sys.path.insert(0, os.path.join(ROOT, "text-compression_amd"))
 import torch, textcomp
 from textcomp import Block
-n = 1 << 30
+n = 1 << (int(sys.argv[2]) if len(sys.argv) > 2 else 30)
 ctx = textcomp.Context(0); lib = ctx.lib
 g = torch.Generator(device="cuda"); g.manual_seed(7)
 t = torch.tensor([65, 67, 71, 84], dtype=torch.uint8, device="cuda")[torch.randint(0, 4, (n,), generator=g, device="cuda").long()]

@@ -119,7 +119,7 @@ def genome_like(n, seed=0x6E0E):
     return t
 
 
-# ---- the device-side generators of the bench's classes leg (tc_generate_dev kinds 2 .. 5, csrc/textcomp.hip), restated in
+# ---- the device-side generators of the bench's classes leg (tc_generate_dev kinds 2 .. 6, csrc/textcomp.hip), restated in
 # numpy: the same integer function of (kind, seed, position), so that the oracle can encode what the device generates
 
 def _mix(seed, i):
@@ -197,9 +197,26 @@ def dev_zipf_words(n, seed=0x21BF, vocab=20000):
     return out[:n]
 
 
+def dev_gaps(n, seed=0x6A95):
+    out = np.empty(n, dtype=np.uint8)
+    g0, gl, cell, sl = n // 3, n // 64, n // 40, n // 4096
+    for lo in range(0, n, _CHUNK):
+        hi = min(n, lo + _CHUNK)
+        i = np.arange(lo, hi, dtype=np.uint64)
+        b = _ACGT[_scaled(_mix(seed, i), 4).astype(np.int64)]
+        big = (i >= np.uint64(g0)) & (i < np.uint64(g0 + gl))
+        if cell:
+            c = i // np.uint64(cell)
+            small = ((c & np.uint64(1)) == 1) & (c < np.uint64(32)) & (i - c * np.uint64(cell) < np.uint64(sl))
+        else:
+            small = np.zeros(hi - lo, dtype=bool)
+        out[lo:hi] = np.where(big | small, np.uint8(78), b)
+    return out
+
+
 CLASSES = {"zipf_words": zipf_words, "bytes256": bytes256, "ascii96": ascii96, "acgt4": acgt4, "genome_like": genome_like,
-           "dev_genome_like": dev_genome_like, "dev_zipf_words": dev_zipf_words, "dev_runs": dev_runs, "dev_periodic": dev_periodic}
-DEV_KINDS = {"dev_genome_like": (2, 0x6E0E), "dev_zipf_words": (3, 0x21BF), "dev_runs": (4, 0x9A75), "dev_periodic": (5, 0x4B1B)}
+           "dev_genome_like": dev_genome_like, "dev_zipf_words": dev_zipf_words, "dev_runs": dev_runs, "dev_periodic": dev_periodic, "dev_gaps": dev_gaps}
+DEV_KINDS = {"dev_genome_like": (2, 0x6E0E), "dev_zipf_words": (3, 0x21BF), "dev_runs": (4, 0x9A75), "dev_periodic": (5, 0x4B1B), "dev_gaps": (6, 0x6A95)}
 
 
 def make(name, n):

@@ -1,4 +1,4 @@
-"""tc_generate_dev kinds 2 .. 5 (the non-iid records of bench.py's classes leg) against their numpy restatements in
+"""tc_generate_dev kinds 2 .. 6 (the non-iid records of bench.py's classes leg) against their numpy restatements in
 tests/classgen.py: every byte is the same integer function of (kind, seed, position) on both sides, which is what lets the
 CPU oracle encode exactly what the device generates (tests/golden/classes_digest.json: dev_periodic)."""
 import ctypes as C

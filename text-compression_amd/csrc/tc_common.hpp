@@ -43,6 +43,8 @@ struct tc_ctx {
     int reserved_cus = 0;  // CUs left to a tc_comm's stream: the partition levels split their work over the others
     void *hostpipe = nullptr;   // page-locked staging ring + persistent device buffers of the host entry points (textcomp.hip)
     u32 stats_ws_grown = 0;  // how often a chunked workspace grew in place
+    int mtf_fastin_failed = 0;  // the one-kernel MTF + RLE of this encode could not recover a tile's list by its backward scan:
+                                // the two-stage path that follows starts with the summaries (the same scan would fail again)
     int live_comms = 0;    // communicators created on this context and not yet destroyed
     int safe_tickets = 0;  // set after a look-back spin overflow: single ticket counter
     u32 ticket_fallbacks = 0;  // how often that happened (reported in tc_stats)

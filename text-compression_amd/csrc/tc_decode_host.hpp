@@ -27,9 +27,13 @@
 
 #ifdef __HIPCC__
 
-// the splitter of block q = r / 256 sits at offset -(byte sum of q) mod 256; block 0: row 0
+// the splitter of block q = r / 256 sits at a HASHED offset (the top bits of q times an odd constant); block 0: row 0.
+// (Rounds 1-3: -(byte sum of q) mod 256 -- enough against walks that keep their row mod 256 (periodic text: 211 s for
+// 256 MiB before it), but an arithmetic progression in q itself: a walk that advances by a constant 17 rows per step -- the
+// rows of N^k x, k = 1, 2, .., of an assembly with 17 gaps lie 17 apart -- shifts its residues by -1 per block exactly as the
+// offsets did and missed the splitters for tens of thousands of steps: the 2^28-byte record's walk kernel 38 ms instead of 5.)
 __device__ __forceinline__ u32 ibwt_split_off(u32 q) {
-    return (0u - (q + (q >> 8) + (q >> 16))) & (u32)(IBWT_S - 1);
+    return (q * 0x9E3779B1u) >> (32 - IBWT_SBITS);
 }
 __device__ __forceinline__ u32 ibwt_split_row(u32 q) { return q * IBWT_S + ibwt_split_off(q); }
 __device__ __forceinline__ bool ibwt_is_splitter(u32 r) {

@@ -1274,7 +1274,9 @@ static void mtf_encode_device(tc_ctx *ctx, Arena &A, Acc acc, u64 N, const u32 *
         for (int v = 0; v < 257; v++) lut.v[v] = (u8)al.code_of_sym[v];
         // fast path: every tile recovers its incoming list by a short backward scan
         bool fast_ok = false;
-        if (env_int("TC_MTF_FASTIN", 1) != 0) {
+        const bool scan_failed = ctx->mtf_fastin_failed != 0;   // (this record's one-kernel attempt: long runs in the column)
+        ctx->mtf_fastin_failed = 0;
+        if (env_int("TC_MTF_FASTIN", 1) != 0 && !scan_failed) {
             u32 *flag = reinterpret_cast<u32 *>(ctx->d_scalars + 15);
             tc_memset_async(ctx, flag, 0, sizeof(u64));
             if (d_idx8 && al.sigma <= 8 && env_int("TC_MTF_SMALL", 1) != 0)   // (a DNA record: the list in 32 bits)
@@ -1495,7 +1497,10 @@ static bool mtf_rle_device(tc_ctx *ctx, Arena &A, BwtAcc acc, u64 N, const u32 *
         tc_memset_async(ctx, ctx->d_scalars + 112, 0, sizeof h);
     }
 #endif
-    if ((u32)ctx->h_scalars[15] != 0) return false;
+    if ((u32)ctx->h_scalars[15] != 0) {
+        ctx->mtf_fastin_failed = 1;
+        return false;
+    }
     const u64 perm = ctx->h_scalars[8];
     for (u32 i = 0; i < al.sigma; i++) out->final_list[i] = al.sym_of_code[(perm >> (4 * i)) & 15];
     *sigma = al.sigma;

@@ -341,6 +341,7 @@ __device__ __forceinline__ u8 gen_acgt(u32 k) { return (u8)(0x54474341u >> (8 * 
 //     per 20 000-byte cell a poly-A tract of 15 .. 59; per 100 000-byte cell 100 bytes of (CA)n
 //   4 runs: a new run starts at a position with probability 1/10, the run's letter is drawn at its start
 //   5 periodic: a 4096-byte iid ACGT block repeated
+//   6 an assembly with gaps: iid ACGT with runs of 'N' (a function of the position AND the length n)
 // (3, Zipf words, needs the word boundaries: generate_words_kernel below)
 __global__ __launch_bounds__(256) void generate_kernel(int kind, u64 seed, u64 n, u8 *out) {
     for (u64 i = (u64)blockIdx.x * 256 + threadIdx.x; i < n; i += (u64)gridDim.x * 256) {
@@ -370,6 +371,15 @@ __global__ __launch_bounds__(256) void generate_kernel(int kind, u64 seed, u64 n
             u64 j = i;
             for (int back = 0; back < 512 && j > 0 && gen_scaled(gen_mix(seed, j), 10) != 0; back++) j--;
             b = gen_acgt((u32)(gen_mix(seed + 1, j) >> 40));
+        } else if (kind == 6) {
+            // an assembly with gaps: iid ACGT, one run of n / 64 'N's from n / 3 on, sixteen of n / 4096 at the odd multiples of n / 40
+            b = gen_acgt(gen_scaled(z, 4));
+            const u64 g0 = n / 3, cell = n / 40;
+            if (i >= g0 && i < g0 + n / 64) b = 78;
+            else if (cell) {
+                const u64 c = i / cell;
+                if ((c & 1) && c < 32 && i - c * cell < n / 4096) b = 78;
+            }
         } else {
             b = gen_acgt(gen_scaled(gen_mix(seed, i & 4095), 4));
         }
@@ -994,7 +1004,7 @@ int tc_encode(tc_ctx *ctx, const uint8_t *text, uint64_t n, tc_block *out) {
 // ============================================================ synthetic input
 int tc_generate_dev(tc_ctx *ctx, int kind, uint64_t seed, uint64_t n, uint8_t *d_out) {
     TC_API_BEGIN(ctx)
-    if (kind < 0 || kind > 5) TC_FAIL(ctx, TC_ERR_ARG, "bad kind");
+    if (kind < 0 || kind > 6) TC_FAIL(ctx, TC_ERR_ARG, "bad kind");
     if (n == 0) return TC_OK;
     if (!d_out) TC_FAIL(ctx, TC_ERR_ARG, "null buffer");
     if (kind == 3) {
@@ -1572,6 +1582,8 @@ static void encode_container_device(tc_ctx *ctx, const u8 *d_text, u64 n, u8 *d_
                     seal(a.totals, fesc);
                     one_kernel = true;
                     fused = true;
+                } else {
+                    ctx->mtf_fastin_failed = 1;
                 }
             }
         }
