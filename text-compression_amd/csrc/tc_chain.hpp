@@ -118,24 +118,21 @@ __global__ __launch_bounds__(256) void chain_flags_members_kernel(const u32 *__r
 
 // any[b]: does row block b (positions [b * bk * h, (b + 1) * bk * h)) hold a position on path?  A block without one is
 // all terminals: its summaries are known and none of its positions needs a code (k = 0: the sign bit alone)
+// (gridDim.y workgroups share a block's words: late rounds have few, huge row blocks; `any` is zeroed by the host)
 __global__ __launch_bounds__(256) void chain_blockany_kernel(const u64 *__restrict__ pathbits, ChainDims d, u32 *__restrict__ any) {
-    __shared__ u32 s_any;
     const u32 b = blockIdx.x;
-    if (threadIdx.x == 0) s_any = 0;
-    __syncthreads();
     const u64 p0 = (u64)b * d.bk * d.h;
     u64 p1 = p0 + (u64)d.bk * d.h;
     if (p1 > d.N) p1 = d.N;
+    const u64 w0 = p0 >> 6, w1 = (p1 - 1) >> 6;   // first / last word of the block
     u64 acc = 0;
-    for (u64 w = (p0 >> 6) + threadIdx.x; w <= ((p1 - 1) >> 6); w += 256) {
+    for (u64 w = w0 + (u64)blockIdx.y * 256 + threadIdx.x; w <= w1; w += (u64)gridDim.y * 256) {
         u64 x = pathbits[w];
-        if (w == (p0 >> 6)) x &= ~0ull << (p0 & 63);
-        if (w == ((p1 - 1) >> 6) && ((p1 & 63) != 0)) x &= (1ull << (p1 & 63)) - 1ull;
+        if (w == w0) x &= ~0ull << (p0 & 63);
+        if (w == w1 && ((p1 & 63) != 0)) x &= (1ull << (p1 & 63)) - 1ull;
         acc |= x;
     }
-    if (acc) atomicOr(&s_any, 1u);
-    __syncthreads();
-    if (threadIdx.x == 0) any[b] = s_any;
+    if (__ballot(acc != 0ull) != 0ull && lane_id() == 0) atomicOr(&any[b], 1u);
 }
 
 // state of a walk up a column: k on-path steps seen, s the terminal's sign; `thru`: no terminal met yet in this block
@@ -198,12 +195,21 @@ __global__ __launch_bounds__(256) void chain_scan_b_kernel(u32 *__restrict__ sum
     const u32 c = blockIdx.x * 256 + threadIdx.x;
     if (c >= d.h) return;
     u32 k = 0, s = 0;
-    for (u32 b = d.nb; b-- > 0;) {
-        const size_t at = (size_t)b * d.h + c;
-        const u32 x = summ[at];
-        summ[at] = chain_pack(false, s, k);
-        if (x & 0x80000000u) k += x & 0x3fffffffu;
-        else { k = x & 0x3fffffffu; s = (x >> 30) & 1u; }
+    // (eight summaries fetched together: the addresses do not depend on the carry -- one load per turn was nb memory latencies
+    // in a row, 6 ms of a 1 GiB record's chain round at h = 42)
+    for (u32 b = d.nb; b > 0;) {
+        const u32 nr = b < 8u ? b : 8u;
+        u32 x[8];
+#pragma unroll
+        for (u32 j = 0; j < 8; j++) x[j] = j < nr ? summ[(size_t)(b - 1u - j) * d.h + c] : 0u;
+#pragma unroll
+        for (u32 j = 0; j < 8; j++) {
+            if (j >= nr) break;
+            summ[(size_t)(b - 1u - j) * d.h + c] = chain_pack(false, s, k);
+            if (x[j] & 0x80000000u) k += x[j] & 0x3fffffffu;
+            else { k = x[j] & 0x3fffffffu; s = (x[j] >> 30) & 1u; }
+        }
+        b -= nr;
     }
 }
 

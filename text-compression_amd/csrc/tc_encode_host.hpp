@@ -1054,8 +1054,13 @@ static void sa_run(tc_ctx *ctx, SaBuffers &b, const u8 *d_text, u64 n, u32 *d_sa
             TC_LAUNCH_CHECK(ctx);
             TC_HIP(ctx, hipMemcpyAsync(chain_path, pathbits, (size_t)chain_words * sizeof(u64), hipMemcpyDeviceToDevice, s));
             TC_HIP(ctx, hipMemcpyAsync(chain_sign, signbits, (size_t)chain_words * sizeof(u64), hipMemcpyDeviceToDevice, s));
-            chain_blockany_kernel<<<cd.nb, 256, 0, s>>>(chain_path, cd, any);
-            TC_LAUNCH_CHECK(ctx);
+            {   // (row blocks that hold a position on path; a block's words are shared by up to 1024 workgroups)
+                tc_memset_async(ctx, any, 0, (size_t)cd.nb * sizeof(u32));
+                u64 parts = ((u64)cd.bk * cd.h / 64) / 4096 + 1;
+                if (parts > 1024) parts = 1024;
+                chain_blockany_kernel<<<dim3(cd.nb, (u32)parts), 256, 0, s>>>(chain_path, cd, any);
+                TC_LAUNCH_CHECK(ctx);
+            }
             const u32 cgrid = (u32)tc_cdiv((u64)cd.nb * cd.h, 256);
             if (cd.nb > 1) {
                 chain_scan_a_kernel<<<cgrid, 256, 0, s>>>(chain_path, chain_sign, cd, any, b.chain_summ);
