@@ -996,6 +996,12 @@ static void sa_run(tc_ctx *ctx, SaBuffers &b, const u8 *d_text, u64 n, u32 *d_sa
     const int chain_env = env_int("TC_SA_CHAIN", 1);
     int keymode = 0;      // 0: key2 = rank[i + h]; 1: the chain code; 2: the rank the member's terminal sees
     u64 prev_mm = 0;      // members of the last plain doubling round (0: none yet, or a chain round came since)
+    // back-off: text that is repetitive without being periodic (a Fibonacci or Thue-Morse word: every round keeps nearly all of it
+    // tied, but its chains are short) would pay a chain round -- two passes -- at every other doubling for nothing (2^28 bytes:
+    // 762 instead of 538 ms).  A chain round that resolved less than an eighth of its members makes the next attempt wait
+    // 2, 4 plain rounds; after three such rounds there are no more (forced rounds, TC_SA_CHAIN=2, ignore this)
+    int chain_fail = 0, chain_wait = 0;
+    u64 chain_m0 = 0;
     while (m > 0) {
         if (st.rounds >= TC_MAX_ROUNDS) TC_FAIL(ctx, TC_ERR_INTERNAL, "suffix sort did not converge");
         u32 mm = (u32)m;
@@ -1032,7 +1038,7 @@ static void sa_run(tc_ctx *ctx, SaBuffers &b, const u8 *d_text, u64 n, u32 *d_sa
         const u32 chain_words = (u32)(N / 64 + 1);
         u64 *chain_path = reinterpret_cast<u64 *>(b.chain_ref), *chain_sign = chain_path + chain_words;
         if (keymode == 0 && seg_round && hh >= 4 && h < N && chain_env != 0 &&
-            (chain_env == 2 || (mm >= (1u << 20) && prev_mm > 0 && (prev_mm - m) * 256 < prev_mm))) {
+            (chain_env == 2 || (mm >= (1u << 20) && prev_mm > 0 && (prev_mm - m) * 256 < prev_mm && chain_wait == 0 && chain_fail < 3))) {
             // reference ranks, on-path / sign bits of every tied position, their scan along stride h -> a code per position
             const ChainDims cd = chain_dims(N, hh);
             u64 *pathbits = b.seg.segbits, *signbits = b.seg.ybits;   // (free here: the sort writes them anew)
@@ -1071,6 +1077,7 @@ static void sa_run(tc_ctx *ctx, SaBuffers &b, const u8 *d_text, u64 n, u32 *d_sa
             chain_scan_c_kernel<<<cgrid, 256, 0, s>>>(chain_path, chain_sign, cd, any, b.chain_summ, b.chain_code);
             TC_LAUNCH_CHECK(ctx);
             keymode = 1;
+            chain_m0 = m;
             st.chain_rounds++;
             trace("chain round: codes", N);
             if (trace_on) {
@@ -1142,6 +1149,9 @@ static void sa_run(tc_ctx *ctx, SaBuffers &b, const u8 *d_text, u64 n, u32 *d_sa
         cur ^= 1;
         if (keymode == 1) keymode = 2;   // (the second pass of a chain round: same h)
         else {
+            if (keymode == 2) {
+                if ((chain_m0 - m) * 8 < chain_m0) chain_wait = 1 << ++chain_fail;
+            } else if (chain_wait > 0) chain_wait--;
             prev_mm = keymode == 2 ? 0 : mm;
             keymode = 0;
             h *= 2;
