@@ -437,6 +437,7 @@ static void sa_run(tc_ctx *ctx, SaBuffers &b, const u8 *d_text, u64 n, u32 *d_sa
     u64 m = 0;
     u32 fm_dropped = 0;
     bool hopeless = false, isa_ready = false;
+    bool many_ties = false;   // the LSD way's finish pass drowned in ties: the full path that follows will want dense ranks
     u64 h_start = cfg.h0;
     bool have_groups = false;
     tc_memset_async(ctx, ctx->d_scalars, 0, 16 * sizeof(u64));
@@ -852,6 +853,8 @@ static void sa_run(tc_ctx *ctx, SaBuffers &b, const u8 *d_text, u64 n, u32 *d_sa
                     m = m2;
                     h_start = cfg.h0;   // every tie now shares the whole key
                 }
+            } else if (!msd && fm > b.sparse_cap - 1024) {
+                many_ties = true;
             }
             }   // way
         }
@@ -876,8 +879,10 @@ static void sa_run(tc_ctx *ctx, SaBuffers &b, const u8 *d_text, u64 n, u32 *d_sa
         GroupArgs g0 = {};
         g0.keys = skeys; g0.count = (u32)N; g0.vals = sa;
         g0.out_slot = b.act[0][0]; g0.out_idx = b.act[0][1]; g0.out_grp = b.act[0][2]; g0.out_tpos = b.act[0][3];
-        if (hopeless) { g0.isa = b.isa; isa_ready = true; }  // many ties expected: ranks in the same pass
-        const bool g0_pairs = hopeless && N >= bin_min && part_act1_ok;
+        // many ties expected (the sample, or a finish pass that just met them -- a text of a period longer than the sample sees:
+        // one group pass less, 11 ms per GiB): ranks in the same pass
+        if (hopeless || many_ties) { g0.isa = b.isa; isa_ready = true; }
+        const bool g0_pairs = (hopeless || many_ties) && N >= bin_min && part_act1_ok;
         if (g0_pairs) g0.pairs = rb.keys_alt;
         run_group(true, g0, sa);
         if (g0_pairs) apply_pairs(rb.keys_alt, (u32)N, part_act1);
